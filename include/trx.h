@@ -1,0 +1,144 @@
+/*
+ * trx.h -- C ABI of libtrx.so, the MI355X (gfx950) implementation of the
+ * marginal-likelihood hot path of stevengiacalone/triceratops.
+ *
+ * The reference has no FFI: this path sits behind plain in-process Python functions
+ * (triceratops/likelihoods.py, triceratops/marginal_likelihoods.py,
+ * triceratops/_numerics.py) plus the third-party pytransit.QuadraticModel object.
+ * Each entry point below names the reference interface it replaces; INTEGRATION.md
+ * shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no C++/torch types; every buffer is caller-owned;
+ *   - pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()) unless the
+ *     function name ends in _host;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream) and the call returns without synchronising; no allocation, no
+ *     host-device sync, no global mutable state: safe to capture into a hipGraph and
+ *     to call concurrently on different streams / devices;
+ *   - return value: 0 = ok, TRX_ERR_* otherwise (never throws); trx_last_error()
+ *     gives a thread-local message for the last non-zero return on this thread;
+ *   - numerical exclusions travel in-band exactly as in the reference:
+ *     +inf in chi^2/2 = excluded draw, -inf / NaN log-weights = zero weight.
+ */
+#ifndef TRX_H
+#define TRX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* model families */
+#define TRX_MODEL_TP       0  /* transiting planet:  simulate_TP_transit_p, likelihoods.py:302-358 */
+#define TRX_MODEL_EB       1  /* eclipsing binary:   simulate_EB_transit_p, likelihoods.py:361-439;
+                                 lnL +inf where secondary depth >= 1.5 sigma, :534-538 */
+#define TRX_MODEL_EB_TWIN  2  /* twin EB (q>=0.95 at 2 P_orb): same light curve as EB, no secondary
+                                 cut, likelihoods.py:542-587 */
+#define TRX_MODEL_RAW      3  /* bare pytransit-shaped evaluate_pv (no unit conversion, no dilution);
+                                 trx_flux_grid only */
+
+/* flags (bit-or) */
+#define TRX_FLAG_COMPANION_IS_HOST 1 /* `companion_is_host=True`, likelihoods.py:352, 427 */
+#define TRX_FLAG_SCALAR_K          2 /* scalar-path radius-ratio rule `abs(k-1)<1e-6`, 1/k for the
+                                        secondary (likelihoods.py:121-123, 137) instead of the vector
+                                        path's `(k-1)<1e-6` on both (likelihoods.py:406, 418) */
+
+/* parameter-block rows, SoA [n_param][n] contiguous fp64 (reference argument order):
+ *   TP  (10): R_p[R_earth] P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio
+ *   EB  (11): R_EB[R_sun] EB_fluxratio P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio
+ *   RAW  (9): k t0 p a(in stellar radii) i[rad] e w[rad] u1 u2      (pvp columns + ldc)            */
+#define TRX_NPARAM_TP  10
+#define TRX_NPARAM_EB  11
+#define TRX_NPARAM_RAW 9
+
+/* status codes */
+#define TRX_OK              0
+#define TRX_ERR_ARG         1  /* NULL pointer, negative size, unknown model ... */
+#define TRX_ERR_HIP         2  /* a HIP runtime call failed (see trx_last_error) */
+#define TRX_ERR_WORKSPACE   3  /* workspace too small */
+#define TRX_ERR_NTOTAL      4  /* N_total != len(logw): the reference raises ValueError,
+                                  _numerics.py:40-45 */
+
+/* Replaces lnL_TP_p / lnL_EB_p / lnL_EB_twin_p (likelihoods.py:443-587), i.e. the light-curve
+ * model + 0.5*sum((flux-model)^2/sigma^2, axis=1), fused: the (n x n_time) grid is never
+ * materialised.  out_halfchi2[n] receives +chi^2/2 (+inf where model==EB and secondary depth
+ * >= 1.5*sigma).  Unlike the reference it does not convert the caller's `inc` to radians in
+ * place (likelihoods.py:344, 410). */
+int trx_lnl_batch(int model, int flags,
+                  const double* time, const double* flux, int n_time, double sigma,
+                  const double* params, long n,
+                  double exptime, int nsupersample,
+                  double* out_halfchi2, void* stream);
+
+/* Replaces simulate_TP_transit_p / simulate_EB_transit_p (likelihoods.py:302-439) and, with
+ * model == TRX_MODEL_RAW, pytransit's QuadraticModel.set_data + evaluate_pv
+ * (likelihoods.py:348-349, 414-415).  out_flux is (n, n_time) row-major; out_secdepth[n] may be
+ * NULL (written for EB / EB_TWIN only). */
+int trx_flux_grid(int model, int flags,
+                  const double* time, int n_time,
+                  const double* params, long n,
+                  double exptime, int nsupersample,
+                  double* out_flux, double* out_secdepth, void* stream);
+
+/* The reference's reduction over a materialised model grid,
+ * 0.5*np.sum((flux-model)**2/sigma**2, axis=1) (likelihoods.py:486, 537, 586): HBM-bound row
+ * reduction over model_grid (n, n_time). */
+int trx_chi2_grid(const double* flux, const double* model_grid, int n_time, long n, double sigma,
+                  double* out_halfchi2, void* stream);
+
+/* Bytes of device scratch the reductions below need (a small constant). */
+size_t trx_workspace_bytes(void);
+
+/* Replaces _log_mean_exp(logw, N_total=...) (_numerics.py:12-51): log(mean(exp(logw))) with
+ * -inf / NaN = zero weight still counted in the denominator, any +inf -> +inf, no finite entry
+ * -> -inf.  n_total must equal n (TRX_ERR_NTOTAL otherwise, nothing enqueued).  out: 1 double. */
+int trx_log_mean_exp(const double* logw, long n, long n_total, double* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused evidence of one scenario branch, the tail of every lnZ_* in marginal_likelihoods.py
+ * (e.g. lnZ_TTP 117-154):  lnL_i = -0.5 ln(2 pi) - lnsigma - chi2half_i (+ lnprior_i),
+ * lnZ = log( sum_i exp(lnL_i) / n_total ), where the n rows are the draws that passed the
+ * geometry mask and the other n_total - n draws have weight zero.
+ *   lnprior  [n] or NULL  (lnprior_companion of the P/S/D/B scenarios, already masked)
+ *   out_halfchi2 [n]      chi^2/2 per masked draw (needed by the caller for the best-100 table)
+ *   out_lnz  1 double */
+int trx_lnz_scenario(int model, int flags,
+                     const double* time, const double* flux, int n_time, double sigma,
+                     const double* params, long n,
+                     double exptime, int nsupersample,
+                     const double* lnprior, long n_total, double lnsigma,
+                     double* out_halfchi2, double* out_lnz,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* The tail of trx_lnz_scenario on its own: lnZ from chi^2/2 values already on the device. */
+int trx_lnz_from_halfchi2(const double* halfchi2, const double* lnprior, long n, long n_total,
+                          double lnsigma, double* out_lnz,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-pointer conveniences: stage host buffers to the current device, run the kernels above,
+ * copy back and synchronise.  For callers without a device allocator (a ctypes binding on
+ * numpy arrays).  They are GPU paths, not CPU fallbacks. */
+int trx_lnl_batch_host(int model, int flags,
+                       const double* time, const double* flux, int n_time, double sigma,
+                       const double* params, long n,
+                       double exptime, int nsupersample, double* out_halfchi2);
+int trx_flux_grid_host(int model, int flags,
+                       const double* time, int n_time,
+                       const double* params, long n,
+                       double exptime, int nsupersample,
+                       double* out_flux, double* out_secdepth);
+int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out);
+
+/* Tuning knob for benchmarks/tests: rows staged per wavefront (1,2,4,8,16; 0 = automatic). */
+int trx_set_rows_per_wave(int rows);
+
+const char* trx_version(void);
+const char* trx_last_error(void);
+int trx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRX_H */

@@ -1,0 +1,220 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64 path): chi^2/2 relative 1e-9, flux absolute 5e-13, lnZ absolute 1e-9.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O
+from triceratops_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL_H = 1e-9
+ATOL_FLUX = 5e-13
+
+
+def _lc(n_time, seed=0):
+    rng = np.random.default_rng(synth.SEED + seed)
+    t = synth.time_grid(n_time)
+    curve = O.flux_grid(O.MODEL_TP, t, synth.reference_tp_row())[0][0]
+    return rng, t, synth.noisy_light_curve(rng, curve)
+
+
+def _cmp_h(got, want):
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isposinf(want), np.isposinf(got))
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    if fin.any():
+        rel = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)
+        assert rel.max() < RTOL_H, rel.max()
+
+
+@pytest.mark.parametrize("n_time", [200, 77, 2000])
+@pytest.mark.parametrize("fam", synth.FAMILIES, ids=[f[0] for f in synth.FAMILIES])
+def test_lnl_batch_matches_oracle(fam, n_time):
+    name, model, is_host, has_comp = fam
+    rng, t, flux = _lc(n_time, seed=[f[0] for f in synth.FAMILIES].index(name))
+    n = 257 if n_time < 2000 else 96
+    rows = synth.family_rows(rng, fam, n)
+    flags = _lib.FLAG_COMPANION_IS_HOST if is_host else 0
+    got = _lib.lnl_batch(model, flags, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows),
+                         synth.EXPTIME, synth.NSAMPLES).cpu().numpy()
+    want = O.lnl_batch(model, t, flux, synth.SIGMA, rows, companion_is_host=is_host)
+    _cmp_h(got, want)
+
+
+@pytest.mark.parametrize("stepping", [0, 1])
+@pytest.mark.parametrize("rows_per_wave", [0, 1, 4, 16])
+def test_launch_knobs_do_not_change_results(stepping, rows_per_wave):
+    rng, t, flux = _lc(150)
+    rows = synth.eb_rows(rng, 333, has_companion=True)
+    L = _lib.lib()
+    try:
+        L.trx_set_kepler_stepping(stepping)
+        L.trx_set_rows_per_wave(rows_per_wave)
+        got = _lib.lnl_batch(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA,
+                             _lib.dev(rows), synth.EXPTIME, synth.NSAMPLES).cpu().numpy()
+    finally:
+        L.trx_set_kepler_stepping(1)
+        L.trx_set_rows_per_wave(0)
+    want = O.lnl_batch(O.MODEL_EB, t, flux, synth.SIGMA, rows)
+    _cmp_h(got, want)
+
+
+@pytest.mark.parametrize("model,is_host", [(0, False), (0, True), (1, False), (1, True), (2, False)])
+def test_flux_grid_matches_oracle(model, is_host):
+    rng, t, _ = _lc(300)
+    rows = synth.tp_rows(rng, 200, True) if model == 0 else synth.eb_rows(rng, 200, model == 2, True)
+    flags = _lib.FLAG_COMPANION_IS_HOST if is_host else 0
+    grid, sec = _lib.flux_grid(model, flags, _lib.dev(t), _lib.dev(rows), synth.EXPTIME, synth.NSAMPLES)
+    wgrid, wsec = O.flux_grid(model, t, rows, companion_is_host=is_host)
+    assert np.abs(grid.cpu().numpy() - wgrid).max() < ATOL_FLUX
+    if model != 0:
+        assert np.abs(sec.cpu().numpy() - wsec).max() < ATOL_FLUX
+
+
+def test_raw_evaluate_pv_matches_oracle():
+    rng = np.random.default_rng(5)
+    n = 300
+    t = np.linspace(-0.3, 0.3, 123)
+    k = rng.uniform(0.01, 1.0, n)
+    k[:40] = rng.uniform(1.0, 25.0, 40)   # occulter larger than the star (secondary-eclipse regime)
+    t0 = rng.normal(0, 0.02, n)
+    p = rng.uniform(0.8, 20, n)
+    a = rng.uniform(2.0, 30, n)
+    b = rng.uniform(0, 1.2, n)
+    inc = np.arccos(np.clip(b / a, 0, 1))
+    e = rng.uniform(0, 0.9, n) * (rng.uniform(size=n) > 0.3)
+    w = rng.uniform(0, 2 * np.pi, n)
+    u1, u2 = rng.uniform(0, 0.8, n), rng.uniform(-0.1, 0.5, n)
+    rows = np.ascontiguousarray(np.stack([k, t0, p, a, inc, e, w, u1, u2]))
+    grid, _ = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), 0.02, 7, want_secdepth=False)
+    want = O.evaluate_pv(t, rows[:7].T, rows[7:].T, 0.02, 7)
+    err = np.abs(grid.cpu().numpy() - want).max(axis=1)
+    assert err[40:].max() < ATOL_FLUX, (err[40:].max(), int(err[40:].argmax()) + 40)
+    # k > 1: the Mandel-Agol coefficients grow like k^4 and both sides lose digits (oracle header)
+    assert err[:40].max() < 1e-9, err[:40].max()
+
+
+def test_long_baseline_unfolded_light_curve():
+    """several orbital periods in one time array: the transit window must wrap correctly"""
+    rng = np.random.default_rng(11)
+    t = np.sort(rng.uniform(-20.0, 20.0, 900))
+    rows = synth.tp_rows(rng, 64)
+    rows[1] = rng.uniform(1.0, 6.0, 64)  # short periods -> many transits in the baseline
+    grid, _ = _lib.flux_grid(0, 0, _lib.dev(t), _lib.dev(rows), synth.EXPTIME, 5, want_secdepth=False)
+    want, _ = O.flux_grid(0, t, rows, nsamples=5)
+    assert np.abs(grid.cpu().numpy() - want).max() < ATOL_FLUX
+    assert (want < 1 - 1e-6).any()
+
+
+def test_scalar_k_rule_and_edge_rows():
+    rng, t, flux = _lc(120)
+    rows = synth.eb_rows(rng, 64)
+    rows[0, :8] = rows[5, :8]            # R_EB == R_s exactly -> k rule fires both ways
+    rows[0, 8:12] = rows[5, 8:12] * (1 + 5e-7)
+    rows[1, 12] = 0.0                     # EB_fluxratio = 0 -> nan secondary -> +inf (EB)
+    rows[10, 13] = np.nan                 # NaN parameter -> NaN row
+    for scalar_k in (False, True):
+        flags = _lib.FLAG_SCALAR_K if scalar_k else 0
+        got = _lib.lnl_batch(1, flags, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows),
+                             synth.EXPTIME, synth.NSAMPLES).cpu().numpy()
+        want = O.lnl_batch(1, t, flux, synth.SIGMA, rows, scalar_k=scalar_k)
+        _cmp_h(got, want)
+        assert np.isposinf(got[12]) and np.isposinf(got[13])
+
+
+def test_empty_and_single():
+    rng, t, flux = _lc(50)
+    rows = synth.tp_rows(rng, 1)
+    got = _lib.lnl_batch(0, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20)
+    _cmp_h(got.cpu().numpy(), O.lnl_batch(0, t, flux, synth.SIGMA, rows))
+    empty = torch.empty((10, 0), dtype=torch.float64, device="cuda")
+    out = _lib.lnl_batch(0, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, empty, synth.EXPTIME, 20)
+    assert out.numel() == 0
+
+
+def test_chi2_grid_matches_fused_and_oracle():
+    rng, t, flux = _lc(400)
+    rows = synth.tp_rows(rng, 500, True)
+    t_d, f_d, r_d = _lib.dev(t), _lib.dev(flux), _lib.dev(rows)
+    grid, _ = _lib.flux_grid(0, 0, t_d, r_d, synth.EXPTIME, synth.NSAMPLES, want_secdepth=False)
+    h_grid = _lib.chi2_grid(f_d, grid, synth.SIGMA).cpu().numpy()
+    h_fused = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, synth.NSAMPLES).cpu().numpy()
+    want = O.chi2_grid(flux, grid.cpu().numpy(), synth.SIGMA)
+    assert np.abs(h_grid / want - 1).max() < 1e-12
+    assert np.abs(h_fused / want - 1).max() < 1e-12
+    # odd n_time -> scalar path
+    grid2 = grid[:, :399].contiguous()
+    h2 = _lib.chi2_grid(f_d[:399].contiguous(), grid2, synth.SIGMA).cpu().numpy()
+    assert np.abs(h2 / O.chi2_grid(flux[:399], grid2.cpu().numpy(), synth.SIGMA) - 1).max() < 1e-12
+
+
+LME_CASES = {
+    "very_negative": np.full(1000, -2000.0),
+    "spread": np.array([-1001.0, -1002.0, -1003.0, -1004.0, -1005.0] + [-np.inf] * 5),
+    "one_finite": np.array([-1.0] + [-np.inf] * 9),
+    "all_neginf": np.full(10, -np.inf),
+    "nan_is_neginf": np.array([-1.0, np.nan, -np.inf, np.nan, -np.inf]),
+    "posinf": np.array([-1.0, np.inf, -3.0]),
+    "single": np.array([-7.25]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LME_CASES))
+def test_log_mean_exp_known_answers(name):
+    x = LME_CASES[name]
+    got = float(_lib.log_mean_exp(_lib.dev(x), x.size).cpu()[0])
+    want = O.log_mean_exp(x, x.size)
+    if np.isfinite(want):
+        assert abs(got - want) < 1e-12
+    else:
+        assert got == want
+
+
+def test_log_mean_exp_stress_and_guard():
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 65, 4097, 1_000_003):
+        x = rng.uniform(-3000, -1, n)
+        x[rng.uniform(size=n) < 0.9] = -np.inf
+        x[rng.uniform(size=n) < 0.01] = np.nan
+        got = float(_lib.log_mean_exp(_lib.dev(x), n).cpu()[0])
+        want = O.log_mean_exp(x, n)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) < 1e-11
+    with pytest.raises(ValueError):
+        _lib.log_mean_exp(_lib.dev(np.zeros(5)), 7)
+
+
+def test_lnz_scenario_fused_matches_oracle():
+    rng, t, flux = _lc(200)
+    rows = synth.eb_rows(rng, 3000, has_companion=True)
+    n_total = 40_000
+    lnprior = rng.uniform(-8, 0, 3000)
+    lnprior[::17] = -np.inf
+    h, lnz = _lib.lnz_scenario(1, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows),
+                               synth.EXPTIME, synth.NSAMPLES, _lib.dev(lnprior), n_total,
+                               np.log(synth.SIGMA))
+    want_h = O.lnl_batch(1, t, flux, synth.SIGMA, rows)
+    _cmp_h(h.cpu().numpy(), want_h)
+    lnL = np.full(n_total, -np.inf)
+    lnL[:3000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h + lnprior
+    assert abs(float(lnz.cpu()[0]) - O.log_mean_exp(lnL, n_total)) < 1e-9
+
+
+def test_full_size_properties():
+    """BASELINE config-2 row size (2000 points): properties that need no oracle.
+    chi^2 of the noise-free generating row is ~0; time-reversal symmetry of a circular orbit;
+    fused == materialised."""
+    t = synth.time_grid(2000)
+    ref = synth.reference_tp_row()
+    t_d = _lib.dev(t)
+    grid, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(ref), synth.EXPTIME, synth.NSAMPLES, want_secdepth=False)
+    curve = grid[0]
+    h = _lib.lnl_batch(0, 0, t_d, curve.contiguous(), synth.SIGMA, _lib.dev(ref), synth.EXPTIME, synth.NSAMPLES)
+    assert float(h[0]) == 0.0
+    c = curve.cpu().numpy()
+    assert np.abs(c - c[::-1]).max() < 1e-13
+    assert c.min() < 1 - 0.07 ** 2 and c.max() == 1.0

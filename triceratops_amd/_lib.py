@@ -1,0 +1,220 @@
+"""Loader and thin typed wrappers for libtrx.so (C ABI in include/trx.h).
+
+The HIP library is the only compute backend of this package: if it is missing or fails to
+load, importing the compute entry points raises -- there is no CPU fallback.
+torch is used for device memory, streams and torch.distributed only.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # noqa: F401  (imported first so libtrx binds to the HIP runtime torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrx.so")
+
+MODEL_TP, MODEL_EB, MODEL_EB_TWIN, MODEL_RAW = 0, 1, 2, 3
+FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K = 1, 2
+N_PARAM = {MODEL_TP: 10, MODEL_EB: 11, MODEL_EB_TWIN: 11, MODEL_RAW: 9}
+ERR_NTOTAL = 4
+
+# every symbol include/trx.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "trx_lnl_batch", "trx_flux_grid", "trx_chi2_grid", "trx_workspace_bytes",
+    "trx_log_mean_exp", "trx_lnz_scenario", "trx_lnz_from_halfchi2", "trx_lnl_batch_host", "trx_flux_grid_host",
+    "trx_log_mean_exp_host", "trx_set_rows_per_wave", "trx_version", "trx_last_error",
+    "trx_device_count",
+)
+
+
+class TrxError(RuntimeError):
+    pass
+
+
+_vp = ctypes.c_void_p
+_lib = None
+
+
+def lib():
+    """Load libtrx.so (once).  Raises TrxError if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TrxError(
+            "triceratops_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_long, c_double, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_size_t
+    L.trx_lnl_batch.restype = c_int
+    L.trx_lnl_batch.argtypes = [c_int, c_int, _vp, _vp, c_int, c_double, _vp, c_long, c_double,
+                                c_int, _vp, _vp]
+    L.trx_flux_grid.restype = c_int
+    L.trx_flux_grid.argtypes = [c_int, c_int, _vp, c_int, _vp, c_long, c_double, c_int, _vp, _vp, _vp]
+    L.trx_chi2_grid.restype = c_int
+    L.trx_chi2_grid.argtypes = [_vp, _vp, c_int, c_long, c_double, _vp, _vp]
+    L.trx_workspace_bytes.restype = c_size_t
+    L.trx_workspace_bytes.argtypes = []
+    L.trx_log_mean_exp.restype = c_int
+    L.trx_log_mean_exp.argtypes = [_vp, c_long, c_long, _vp, _vp, c_size_t, _vp]
+    L.trx_lnz_scenario.restype = c_int
+    L.trx_lnz_scenario.argtypes = [c_int, c_int, _vp, _vp, c_int, c_double, _vp, c_long, c_double,
+                                   c_int, _vp, c_long, c_double, _vp, _vp, _vp, c_size_t, _vp]
+    L.trx_lnz_from_halfchi2.restype = c_int
+    L.trx_lnz_from_halfchi2.argtypes = [_vp, _vp, c_long, c_long, c_double, _vp, _vp, c_size_t, _vp]
+    L.trx_lnl_batch_host.restype = c_int
+    L.trx_lnl_batch_host.argtypes = [c_int, c_int, _vp, _vp, c_int, c_double, _vp, c_long,
+                                     c_double, c_int, _vp]
+    L.trx_flux_grid_host.restype = c_int
+    L.trx_flux_grid_host.argtypes = [c_int, c_int, _vp, c_int, _vp, c_long, c_double, c_int, _vp, _vp]
+    L.trx_log_mean_exp_host.restype = c_int
+    L.trx_log_mean_exp_host.argtypes = [_vp, c_long, c_long, _vp]
+    L.trx_set_rows_per_wave.restype = c_int
+    L.trx_set_rows_per_wave.argtypes = [c_int]
+    L.trx_set_kepler_stepping.restype = c_int
+    L.trx_set_kepler_stepping.argtypes = [c_int]
+    L.trx_version.restype = ctypes.c_char_p
+    L.trx_last_error.restype = ctypes.c_char_p
+    L.trx_device_count.restype = c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc:
+        msg = lib().trx_last_error().decode()
+        if rc == ERR_NTOTAL:
+            raise ValueError(msg)
+        raise TrxError("libtrx error %d: %s" % (rc, msg))
+
+
+def version():
+    return lib().trx_version().decode()
+
+
+def require_gpu():
+    if not torch.cuda.is_available() or lib().trx_device_count() < 1:
+        raise TrxError("triceratops_amd needs an AMD GPU (gfx950); none is visible and there is no "
+                       "CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------
+# device helpers
+def dev(x, device=None):
+    """float64 contiguous device tensor from array-like / tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=device or "cuda", dtype=torch.float64)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).to(device or "cuda")
+    return t.contiguous()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_ws = {}
+
+
+def workspace(device):
+    key = (device.type, device.index)
+    if key not in _ws:
+        nbytes = lib().trx_workspace_bytes()
+        _ws[key] = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=device)
+    return _ws[key]
+
+
+def pack_params(model, cols, n=None):
+    """SoA [n_param][n] host block from per-sample columns (reference argument order)."""
+    assert len(cols) == N_PARAM[model], (len(cols), N_PARAM[model])
+    if n is None:
+        n = max(int(np.size(c)) for c in cols)
+    out = np.empty((len(cols), n), dtype=np.float64)
+    for i, c in enumerate(cols):
+        out[i] = c
+    return out
+
+
+def lnl_batch(model, flags, time_d, flux_d, sigma, params_d, exptime, nsamples, out=None):
+    """chi^2/2 per row on the GPU.  All tensors are fp64 CUDA tensors; params_d is [n_param][n]."""
+    require_gpu()
+    n = params_d.shape[1]
+    assert params_d.shape[0] == N_PARAM[model] and params_d.is_contiguous()
+    if out is None:
+        out = torch.empty(n, dtype=torch.float64, device=params_d.device)
+    with torch.cuda.device(params_d.device):
+        check(lib().trx_lnl_batch(model, flags, time_d.data_ptr(), flux_d.data_ptr(),
+                                  time_d.numel(), float(sigma), params_d.data_ptr(), n,
+                                  float(exptime), int(nsamples), out.data_ptr(), _stream(params_d)))
+    return out
+
+
+def flux_grid(model, flags, time_d, params_d, exptime, nsamples, want_secdepth=True):
+    require_gpu()
+    n = params_d.shape[1]
+    assert params_d.shape[0] == N_PARAM[model] and params_d.is_contiguous()
+    out = torch.empty((n, time_d.numel()), dtype=torch.float64, device=params_d.device)
+    sec = torch.zeros(n, dtype=torch.float64, device=params_d.device) if want_secdepth else None
+    with torch.cuda.device(params_d.device):
+        check(lib().trx_flux_grid(model, flags, time_d.data_ptr(), time_d.numel(),
+                                  params_d.data_ptr(), n, float(exptime), int(nsamples),
+                                  out.data_ptr(), sec.data_ptr() if sec is not None else None,
+                                  _stream(params_d)))
+    return out, sec
+
+
+def chi2_grid(flux_d, grid_d, sigma):
+    require_gpu()
+    n, nt = grid_d.shape
+    assert grid_d.is_contiguous() and flux_d.numel() == nt
+    out = torch.empty(n, dtype=torch.float64, device=grid_d.device)
+    with torch.cuda.device(grid_d.device):
+        check(lib().trx_chi2_grid(flux_d.data_ptr(), grid_d.data_ptr(), nt, n, float(sigma),
+                                  out.data_ptr(), _stream(grid_d)))
+    return out
+
+
+def log_mean_exp(logw_d, n_total):
+    """Device log-mean-exp; returns a 1-element device tensor (no sync)."""
+    require_gpu()
+    ws = workspace(logw_d.device)
+    out = torch.empty(1, dtype=torch.float64, device=logw_d.device)
+    with torch.cuda.device(logw_d.device):
+        check(lib().trx_log_mean_exp(logw_d.data_ptr(), logw_d.numel(), int(n_total),
+                                     out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                     _stream(logw_d)))
+    return out
+
+
+def lnz_scenario(model, flags, time_d, flux_d, sigma, params_d, exptime, nsamples, lnprior_d,
+                 n_total, lnsigma):
+    """Fused chi^2/2 -> log-mean-exp.  Returns (halfchi2[n], lnz[1]) device tensors."""
+    require_gpu()
+    n = params_d.shape[1]
+    device = params_d.device
+    h = torch.empty(max(n, 1), dtype=torch.float64, device=device)
+    out = torch.empty(1, dtype=torch.float64, device=device)
+    ws = workspace(device)
+    with torch.cuda.device(device):
+        check(lib().trx_lnz_scenario(model, flags, time_d.data_ptr(), flux_d.data_ptr(),
+                                     time_d.numel(), float(sigma), params_d.data_ptr(), n,
+                                     float(exptime), int(nsamples),
+                                     lnprior_d.data_ptr() if lnprior_d is not None else None,
+                                     int(n_total), float(lnsigma), h.data_ptr(), out.data_ptr(),
+                                     ws.data_ptr(), ws.numel() * 8, _stream(params_d)))
+    return h[:n], out
+
+
+def lnz_from_halfchi2(h_d, lnprior_d, n_total, lnsigma):
+    """lnZ (1-element device tensor) from device chi^2/2 values of the masked draws."""
+    require_gpu()
+    device = h_d.device
+    out = torch.empty(1, dtype=torch.float64, device=device)
+    ws = workspace(device)
+    with torch.cuda.device(device):
+        check(lib().trx_lnz_from_halfchi2(h_d.data_ptr() if h_d.numel() else None,
+                                          lnprior_d.data_ptr() if lnprior_d is not None else None,
+                                          h_d.numel(), int(n_total), float(lnsigma),
+                                          out.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                          _stream(h_d)))
+    return out

@@ -1,0 +1,632 @@
+// libtrx.so: HIP kernels + C ABI (include/trx.h) for gfx950.
+//
+// Kernels
+//   rows_kernel<MODE, STEP>   one wavefront (64-thread workgroup) per batch of B Monte-Carlo
+//                             rows.  Phase 1: lanes < B derive the per-row constant block
+//                             (unit conversion, radius-ratio rule, orbit constants, transit
+//                             window, dilution, limb weights) and stage it in LDS.
+//                             Phase 2 (EB): the B x 25 secondary-eclipse cells are spread
+//                             over the lanes.  Phase 3: lanes < B reduce them to the
+//                             secondary depth / exclusion flag.  Phase 4: for each row the
+//                             lanes stride the time axis (coalesced time/flux loads), run the
+//                             supersampled model, and either wave-reduce chi^2 (MODE_LNL,
+//                             shuffle butterfly) or store the model row (MODE_GRID).
+//   chi2_grid_kernel          row reduction over a materialised (n, n_time) grid, HBM bound.
+//   lme_partial_kernel / lme_final_kernel
+//                             log-mean-exp: single pass online (max, sum exp) per thread,
+//                             wave shuffle + LDS block combine, fixed-order final combine.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/trx.h"
+#include "trx_device.hpp"
+
+namespace {
+
+using namespace trx;
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, const char* a = "", long b = 0)
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+#define TRX_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipGetErrorString(e_), (long)e_); \
+    } while (0)
+
+constexpr int MODE_LNL = 0;
+constexpr int MODE_GRID = 1;
+
+struct RowsArgs {
+    int model, flags;
+    const double* time;
+    const double* flux;
+    int n_time;
+    double sigma;
+    const double* params;
+    long n;
+    double exptime;
+    int S;
+    double* out;       // MODE_LNL: [n] chi2/2 ; MODE_GRID: [n][n_time]
+    double* out_sec;   // MODE_GRID: [n] or null
+    int B;
+    long nbatch;
+};
+
+// radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
+__device__ __forceinline__ double k_rule(double k, bool scalar_rule)
+{
+    if (scalar_rule) { if (fabs(k - 1.0) < 1e-6) k *= 0.999; }
+    else             { if ((k - 1.0) < 1e-6) k *= 0.999; }
+    return k;
+}
+
+template <int MODE, bool STEP>
+__global__ __launch_bounds__(64) void rows_kernel(RowsArgs a)
+{
+    extern __shared__ double lds[];
+    const int B = a.B;
+    RowC* rows = reinterpret_cast<RowC*>(lds);
+    RowC* srows = rows + B;                                           // secondary-eclipse orbits
+    double* sec = lds + 2 * (size_t)B * kRowDoubles;                  // [B][25]
+    const int lane = threadIdx.x;
+    const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
+    const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
+    const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
+    const long n = a.n;
+    const double s2 = a.sigma * a.sigma;
+
+    for (long batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+        const long base = batch * B;
+        const int nb = (int)((n - base < B) ? (n - base) : B);
+        double ysec = 0.0;
+
+        // ---- phase 1: per-row constants ------------------------------------------------
+        if (lane < nb) {
+            const double* p = a.params + base + lane;
+            RowC c;
+            double u1, u2;
+            if (a.model == TRX_MODEL_RAW) {
+                u1 = p[7 * n]; u2 = p[8 * n];
+                orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
+                c.xeb = 0.0; c.fdil = 0.0;
+            } else {
+                double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
+                if (a.model == TRX_MODEL_TP) {
+                    const double R_p = p[0];
+                    per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
+                    u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
+                    k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
+                } else {
+                    const double R_EB = p[0], eb_fr = p[1 * n];
+                    per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
+                    u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
+                    feb = eb_fr / (1.0 - eb_fr);                            // :401
+                    k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
+                    ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
+                }
+                const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
+                const double a_R = acm / (R_s * kRsun);                     // :343, :409
+                const double inc_r = inc * (kPi / 180.0);                   // :344, :410
+                const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
+                orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+                if (!eblike) {
+                    c.xeb = 0.0;
+                    c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
+                } else {
+                    RowC sc;
+                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
+                    orbit_init(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                    const Limb L = limb_weights(u1, u2);
+                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
+                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                    srows[lane] = sc;
+                    if (is_host) {                                          // :427-432
+                        c.xeb = feb / fcomp;
+                        ysec = fcomp / feb;
+                        c.fdil = 1.0 / (fcomp + feb);
+                    } else {                                                // :433-438
+                        c.xeb = feb / 1.0;
+                        ysec = 1.0 / feb;
+                        c.fdil = fcomp / (1.0 + feb);
+                    }
+                }
+            }
+            const Limb L = limb_weights(u1, u2);
+            c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
+            c.excl = 0.0;
+            rows[lane] = c;
+        }
+        __syncthreads();
+
+        // ---- phases 2+3: secondary eclipse depth (EB families) --------------------------
+        if (eblike) {
+            for (int it = lane; it < nb * kSecPoints; it += 64) {
+                const int r = it / kSecPoints, j = it - r * kSecPoints;
+                const RowC sc = srows[r];
+                const Limb L{sc.cle, sc.cld, sc.ced};
+                // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
+                double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
+                if (j == kSecPoints - 1) ts = 0.05;
+                sec[it] = exposure_flux<false>(sc, L, ts, 0.0, 1);
+            }
+            __syncthreads();
+            if (lane < nb) {
+                double m = INFINITY;
+                bool has_nan = false;
+                for (int j = 0; j < kSecPoints; ++j) {
+                    const double f = sec[lane * kSecPoints + j];
+                    has_nan = has_nan || (f != f);
+                    m = (f < m) ? f : m;
+                }
+                if (has_nan) m = NAN;                                       // np.min propagates NaN
+                const double fd = rows[lane].fdil;
+                m = (m + ysec) / (1.0 + ysec);
+                const double secdepth = 1.0 - (m + fd) / (1.0 + fd);
+                rows[lane].excl = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;   // :535
+                if (MODE == MODE_GRID && a.out_sec) a.out_sec[base + lane] = secdepth;
+            }
+            __syncthreads();
+        }
+
+        // ---- phase 4: the light-curve model over the time axis --------------------------
+        for (int r = 0; r < nb; ++r) {
+            const RowC c = rows[r];
+            const Limb L{c.cle, c.cld, c.ced};
+            double acc = 0.0;
+            for (int j = lane; j < a.n_time; j += 64) {
+                double m = exposure_flux<STEP>(c, L, a.time[j], a.exptime, a.S);
+                if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
+                if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
+                if (MODE == MODE_GRID) {
+                    a.out[(size_t)(base + r) * a.n_time + j] = m;
+                } else {
+                    const double d = a.flux[j] - m;
+                    acc += (d * d) / s2;                                    // :486, :537, :586
+                }
+            }
+            if (MODE == MODE_LNL) {
+                double h = 0.5 * wave_sum(acc);
+                if (a.model == TRX_MODEL_EB && c.excl != 0.0) h = INFINITY; // :535-538
+                if (lane == 0) a.out[base + r] = h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 0.5 * sum_t (flux_t - model[r][t])^2 / sigma^2, one wavefront per row, 16 B/lane loads.
+__global__ __launch_bounds__(256) void chi2_grid_kernel(const double* __restrict__ flux,
+                                                        const double* __restrict__ grid,
+                                                        int n_time, long n, double sigma,
+                                                        double* __restrict__ out, int vec_ok)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const double s2 = sigma * sigma;
+    for (long r = wave0; r < n; r += nwaves) {
+        const double* row = grid + (size_t)r * n_time;
+        double acc = 0.0;
+        if (vec_ok) {
+            typedef double dvec2 __attribute__((ext_vector_type(2)));
+            const dvec2* row2 = reinterpret_cast<const dvec2*>(row);
+            const dvec2* fl2 = reinterpret_cast<const dvec2*>(flux);
+            const int nv = n_time >> 1;
+            for (int j = lane; j < nv; j += 64) {
+                const dvec2 m = __builtin_nontemporal_load(&row2[j]);
+                const dvec2 f = fl2[j];
+                const double d0 = f.x - m.x, d1 = f.y - m.y;
+                acc += (d0 * d0) / s2;
+                acc += (d1 * d1) / s2;
+            }
+        } else {
+            for (int j = lane; j < n_time; j += 64) {
+                const double d = flux[j] - row[j];
+                acc += (d * d) / s2;
+            }
+        }
+        const double tot = wave_sum(acc);
+        if (lane == 0) out[r] = 0.5 * tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// log-mean-exp.  Partial state per thread: running max m (finite or -inf), s = sum exp(x - m),
+// pinf = saw +inf.  NaN and -inf carry zero weight (_numerics.py:48).
+struct Lme {
+    double m, s;
+    int pinf;
+};
+
+__device__ __forceinline__ void lme_merge(Lme& a, const Lme& b)
+{
+    a.pinf |= b.pinf;
+    if (b.m == -INFINITY) return;
+    if (a.m == -INFINITY) { a.m = b.m; a.s = b.s; return; }
+    if (b.m > a.m) { a.s = fma(a.s, exp(a.m - b.m), b.s); a.m = b.m; }
+    else           { a.s = fma(b.s, exp(b.m - a.m), a.s); }
+}
+
+// x_i = c0 - h_i + lnprior_i (fused lnZ tail) when h != null, else x_i = logw_i
+__device__ __forceinline__ double lme_value(const double* logw, const double* h,
+                                            const double* lnprior, double c0, long i)
+{
+    if (!h) return logw[i];  // plain log-weights
+    double x = c0 - h[i];
+    if (lnprior) x += lnprior[i];
+    return x;
+}
+
+// fold four values into the running (max, sum) state: one rescale, exps only for terms that can
+// reach the sum: s >= 1 always (the max contributes exp(0)), so a term with d = x - max < -80
+// is < 1.8e-35 and even 2^60 of them stay below fp64 resolution of s (also covers -inf)
+__device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double x2, double x3)
+{
+    double x[4] = {x0, x1, x2, x3};
+    double cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double v = x[u];
+        if (v == INFINITY) { st.pinf = 1; v = -INFINITY; }
+        if (!(v == v)) v = -INFINITY;
+        x[u] = v;
+        cm = fmax(cm, v);
+    }
+    if (cm == -INFINITY) return;
+    if (cm > st.m) {
+        const double d = st.m - cm;
+        st.s = (d > -80.0) ? st.s * exp(d) : 0.0;
+        st.m = cm;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double d = x[u] - st.m;
+        if (d > -80.0) st.s += exp(d);
+    }
+}
+
+__global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
+                                                          const double* __restrict__ h,
+                                                          const double* __restrict__ lnprior,
+                                                          double c0, long n, int vec_ok,
+                                                          double* __restrict__ ws)
+{
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    Lme st{-INFINITY, 0.0, 0};
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec_ok) {
+        // 16 B per lane per load, two independent loads in flight per trip
+        const long nv = n >> 1;
+        const dvec2* src = reinterpret_cast<const dvec2*>(h ? h : logw);
+        const dvec2* pri = reinterpret_cast<const dvec2*>(lnprior);
+        for (long v = tid; v < nv; v += 2 * stride) {
+            const long v2 = v + stride;
+            const bool has2 = v2 < nv;
+            dvec2 a = __builtin_nontemporal_load(&src[v]);
+            dvec2 b = has2 ? __builtin_nontemporal_load(&src[v2]) : dvec2{-INFINITY, -INFINITY};
+            if (h) {
+                a = c0 - a;
+                if (has2) b = c0 - b;
+                if (pri) {
+                    a += __builtin_nontemporal_load(&pri[v]);
+                    if (has2) b += __builtin_nontemporal_load(&pri[v2]);
+                }
+            }
+            lme_fold4(st, a.x, a.y, b.x, b.y);
+        }
+        if ((n & 1) && tid == 0) lme_fold4(st, lme_value(logw, h, lnprior, c0, n - 1), -INFINITY, -INFINITY, -INFINITY);
+    } else {
+        for (long i0 = tid * 4; i0 < n; i0 += stride * 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                x[u] = (i0 + u < n) ? lme_value(logw, h, lnprior, c0, i0 + u) : -INFINITY;
+            lme_fold4(st, x[0], x[1], x[2], x[3]);
+        }
+    }
+    // wave combine (fixed butterfly order => deterministic)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Lme other;
+        other.m = __shfl_xor(st.m, o, 64);
+        other.s = __shfl_xor(st.s, o, 64);
+        other.pinf = __shfl_xor(st.pinf, o, 64);
+        lme_merge(st, other);
+    }
+    __shared__ double sm[4], ss[4];
+    __shared__ int sp[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[wave] = st.m; ss[wave] = st.s; sp[wave] = st.pinf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Lme t{sm[0], ss[0], sp[0]};
+        for (int w = 1; w < 4; ++w) { Lme o{sm[w], ss[w], sp[w]}; lme_merge(t, o); }
+        ws[3 * blockIdx.x + 0] = t.m;
+        ws[3 * blockIdx.x + 1] = t.s;
+        ws[3 * blockIdx.x + 2] = (double)t.pinf;
+    }
+}
+
+__global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict__ ws, int nparts,
+                                                       long n_total, double* __restrict__ out)
+{
+    // lane l folds partials l, l+64, ... in order, then a fixed butterfly: deterministic
+    Lme t{-INFINITY, 0.0, 0};
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+        Lme o{ws[3 * i], ws[3 * i + 1], ws[3 * i + 2] != 0.0};
+        lme_merge(t, o);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Lme other;
+        other.m = __shfl_xor(t.m, o, 64);
+        other.s = __shfl_xor(t.s, o, 64);
+        other.pinf = __shfl_xor(t.pinf, o, 64);
+        lme_merge(t, other);
+    }
+    if (threadIdx.x != 0) return;
+    double r;
+    if (t.pinf) r = INFINITY;                                   // _numerics.py:46-47
+    else if (t.m == -INFINITY) r = -INFINITY;                   // :49-50
+    else r = log(t.s) + t.m - log((double)n_total);             // :51
+    out[0] = r;
+}
+
+// ---------------------------------------------------------------------------------------
+constexpr int kLmeMaxBlocks = 2048;
+int g_rows_per_wave = 0;  // 0 = auto
+int g_step = 1;           // sub-exposure Kepler stepping (0 = full solve per sub-exposure)
+
+int n_params(int model)
+{
+    switch (model) {
+        case TRX_MODEL_TP: return TRX_NPARAM_TP;
+        case TRX_MODEL_EB:
+        case TRX_MODEL_EB_TWIN: return TRX_NPARAM_EB;
+        case TRX_MODEL_RAW: return TRX_NPARAM_RAW;
+        default: return -1;
+    }
+}
+
+int pick_rows_per_wave(int n_time, long n)
+{
+    if (g_rows_per_wave > 0) return g_rows_per_wave;
+    // keep the serial per-row prologue below ~2% of a batch while leaving enough batches
+    // to balance 256 CUs: B * n_time >~ 1024
+    int B = 1;
+    while (B < 16 && (long)B * n_time < 1024) B <<= 1;
+    while (B > 1 && n / B < 8192) B >>= 1;
+    return B;
+}
+
+template <int MODE>
+int launch_rows(const RowsArgs& a0, hipStream_t st)
+{
+    RowsArgs a = a0;
+    a.B = pick_rows_per_wave(a.n_time, a.n);
+    a.nbatch = (a.n + a.B - 1) / a.B;
+    const long max_grid = 1L << 20;
+    const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
+    const size_t lds = (size_t)a.B * (2 * kRowDoubles + kSecPoints) * sizeof(double);
+    if (g_step) hipLaunchKernelGGL((rows_kernel<MODE, true>), dim3(grid), dim3(64), lds, st, a);
+    else        hipLaunchKernelGGL((rows_kernel<MODE, false>), dim3(grid), dim3(64), lds, st, a);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
+
+int launch_lme(const double* logw, const double* h, const double* lnprior, double c0, long n,
+               long n_total, double* out, void* workspace, size_t workspace_bytes, hipStream_t st)
+{
+    if (workspace_bytes < trx_workspace_bytes() || !workspace)
+        return fail(TRX_ERR_WORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)trx_workspace_bytes());
+    long want = (n + 256L * 8 - 1) / (256L * 8);
+    int blocks = (int)(want < 1 ? 1 : (want > kLmeMaxBlocks ? kLmeMaxBlocks : want));
+    double* ws = static_cast<double*>(workspace);
+    const uintptr_t al = (uintptr_t)(h ? h : logw) | (uintptr_t)lnprior;
+    const int vec_ok = (al % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(lme_partial_kernel, dim3(blocks), dim3(256), 0, st, logw, h, lnprior, c0, n,
+                       vec_ok, ws);
+    TRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lme_final_kernel, dim3(1), dim3(64), 0, st, ws, blocks, n_total, out);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
+
+int check_rows(int model, const double* time, int n_time, const double* params, long n, int S)
+{
+    if (n_params(model) < 0) return fail(TRX_ERR_ARG, "unknown model%s %ld", "", (long)model);
+    if (n < 0 || n_time < 0) return fail(TRX_ERR_ARG, "negative size%s (n=%ld)", "", n);
+    if (S < 1) return fail(TRX_ERR_ARG, "nsupersample must be >= 1%s (got %ld)", "", (long)S);
+    if (n > 0 && n_time > 0 && (!time || !params)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
+    return TRX_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+int trx_lnl_batch(int model, int flags, const double* time, const double* flux, int n_time,
+                  double sigma, const double* params, long n, double exptime, int nsupersample,
+                  double* out_halfchi2, void* stream)
+{
+    if (int rc = check_rows(model, time, n_time, params, n, nsupersample)) return rc;
+    if (model == TRX_MODEL_RAW) return fail(TRX_ERR_ARG, "TRX_MODEL_RAW has no likelihood%s", "", 0);
+    if (n == 0) return TRX_OK;
+    if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
+    RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
+               out_halfchi2, nullptr, 0, 0};
+    return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
+}
+
+int trx_flux_grid(int model, int flags, const double* time, int n_time, const double* params,
+                  long n, double exptime, int nsupersample, double* out_flux, double* out_secdepth,
+                  void* stream)
+{
+    if (int rc = check_rows(model, time, n_time, params, n, nsupersample)) return rc;
+    if (n == 0) return TRX_OK;
+    if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
+    RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
+               out_flux, out_secdepth, 0, 0};
+    return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
+}
+
+int trx_chi2_grid(const double* flux, const double* model_grid, int n_time, long n, double sigma,
+                  double* out_halfchi2, void* stream)
+{
+    if (n < 0 || n_time < 0) return fail(TRX_ERR_ARG, "negative size%s (n=%ld)", "", n);
+    if (n == 0) return TRX_OK;
+    if (!out_halfchi2 || (n_time > 0 && (!flux || !model_grid))) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
+    const int vec_ok = (n_time % 2 == 0) && (((uintptr_t)flux | (uintptr_t)model_grid) % 16 == 0);
+    long blocks = (n + 3) / 4;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    hipLaunchKernelGGL(chi2_grid_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), flux, model_grid, n_time, n, sigma,
+                       out_halfchi2, vec_ok);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
+
+size_t trx_workspace_bytes(void) { return (size_t)kLmeMaxBlocks * 3 * sizeof(double); }
+
+int trx_log_mean_exp(const double* logw, long n, long n_total, double* out, void* workspace,
+                     size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || !out || (n > 0 && !logw)) return fail(TRX_ERR_ARG, "bad argument%s", "", 0);
+    if (n_total != n)
+        return fail(TRX_ERR_NTOTAL, "N_total must equal len(logw)%s (len=%ld)", "", n);
+    return launch_lme(logw, nullptr, nullptr, 0.0, n, n_total, out, workspace, workspace_bytes,
+                      static_cast<hipStream_t>(stream));
+}
+
+int trx_lnz_from_halfchi2(const double* halfchi2, const double* lnprior, long n, long n_total,
+                          double lnsigma, double* out_lnz, void* workspace,
+                          size_t workspace_bytes, void* stream)
+{
+    if (!out_lnz || n < 0 || (n > 0 && !halfchi2)) return fail(TRX_ERR_ARG, "bad argument%s", "", 0);
+    if (n_total < n || n_total < 1) return fail(TRX_ERR_NTOTAL, "n_total must be >= n%s (n=%ld)", "", n);
+    const double c0 = -0.5 * log(kTwoPi) - lnsigma;   // marginal_likelihoods.py:130 etc.
+    return launch_lme(nullptr, halfchi2, lnprior, c0, n, n_total, out_lnz, workspace,
+                      workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int trx_lnz_scenario(int model, int flags, const double* time, const double* flux, int n_time,
+                     double sigma, const double* params, long n, double exptime, int nsupersample,
+                     const double* lnprior, long n_total, double lnsigma, double* out_halfchi2,
+                     double* out_lnz, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (int rc = trx_lnl_batch(model, flags, time, flux, n_time, sigma, params, n, exptime,
+                               nsupersample, out_halfchi2, stream))
+        return rc;
+    return trx_lnz_from_halfchi2(out_halfchi2, lnprior, n, n_total, lnsigma, out_lnz, workspace,
+                                 workspace_bytes, stream);
+}
+
+// ---- host-pointer conveniences -----------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    double* d() { return static_cast<double*>(p); }
+};
+}  // namespace
+
+int trx_lnl_batch_host(int model, int flags, const double* time, const double* flux, int n_time,
+                       double sigma, const double* params, long n, double exptime,
+                       int nsupersample, double* out_halfchi2)
+{
+    if (int rc = check_rows(model, time, n_time, params, n, nsupersample)) return rc;
+    if (n == 0) return TRX_OK;
+    if (model == TRX_MODEL_RAW) return fail(TRX_ERR_ARG, "TRX_MODEL_RAW has no likelihood%s", "", 0);
+    const int np = n_params(model);
+    DevBuf dt, df, dp, dout;
+    TRX_HIP(dt.alloc(sizeof(double) * n_time));
+    TRX_HIP(df.alloc(sizeof(double) * n_time));
+    TRX_HIP(dp.alloc(sizeof(double) * np * n));
+    TRX_HIP(dout.alloc(sizeof(double) * n));
+    TRX_HIP(hipMemcpy(dt.p, time, sizeof(double) * n_time, hipMemcpyHostToDevice));
+    TRX_HIP(hipMemcpy(df.p, flux, sizeof(double) * n_time, hipMemcpyHostToDevice));
+    TRX_HIP(hipMemcpy(dp.p, params, sizeof(double) * np * n, hipMemcpyHostToDevice));
+    if (int rc = trx_lnl_batch(model, flags, dt.d(), df.d(), n_time, sigma, dp.d(), n, exptime,
+                               nsupersample, dout.d(), nullptr))
+        return rc;
+    TRX_HIP(hipMemcpy(out_halfchi2, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TRX_OK;
+}
+
+int trx_flux_grid_host(int model, int flags, const double* time, int n_time, const double* params,
+                       long n, double exptime, int nsupersample, double* out_flux,
+                       double* out_secdepth)
+{
+    if (int rc = check_rows(model, time, n_time, params, n, nsupersample)) return rc;
+    if (n == 0) return TRX_OK;
+    const int np = n_params(model);
+    DevBuf dt, dp, dout, dsec;
+    TRX_HIP(dt.alloc(sizeof(double) * n_time));
+    TRX_HIP(dp.alloc(sizeof(double) * np * n));
+    TRX_HIP(dout.alloc(sizeof(double) * n * n_time));
+    TRX_HIP(dsec.alloc(sizeof(double) * n));
+    TRX_HIP(hipMemcpy(dt.p, time, sizeof(double) * n_time, hipMemcpyHostToDevice));
+    TRX_HIP(hipMemcpy(dp.p, params, sizeof(double) * np * n, hipMemcpyHostToDevice));
+    TRX_HIP(hipMemset(dsec.p, 0, sizeof(double) * n));
+    if (int rc = trx_flux_grid(model, flags, dt.d(), n_time, dp.d(), n, exptime, nsupersample,
+                               dout.d(), dsec.d(), nullptr))
+        return rc;
+    TRX_HIP(hipMemcpy(out_flux, dout.p, sizeof(double) * n * n_time, hipMemcpyDeviceToHost));
+    if (out_secdepth) TRX_HIP(hipMemcpy(out_secdepth, dsec.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TRX_OK;
+}
+
+int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
+{
+    if (n < 0 || !out || (n > 0 && !logw)) return fail(TRX_ERR_ARG, "bad argument%s", "", 0);
+    if (n_total != n)
+        return fail(TRX_ERR_NTOTAL, "N_total must equal len(logw)%s (len=%ld)", "", n);
+    DevBuf dx, dws, dout;
+    TRX_HIP(dx.alloc(sizeof(double) * n));
+    TRX_HIP(dws.alloc(trx_workspace_bytes()));
+    TRX_HIP(dout.alloc(sizeof(double)));
+    TRX_HIP(hipMemcpy(dx.p, logw, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (int rc = trx_log_mean_exp(dx.d(), n, n_total, dout.d(), dws.p, trx_workspace_bytes(), nullptr))
+        return rc;
+    TRX_HIP(hipMemcpy(out, dout.p, sizeof(double), hipMemcpyDeviceToHost));
+    return TRX_OK;
+}
+
+int trx_set_rows_per_wave(int rows)
+{
+    if (rows != 0 && rows != 1 && rows != 2 && rows != 4 && rows != 8 && rows != 16)
+        return fail(TRX_ERR_ARG, "rows per wave must be 0,1,2,4,8,16%s (got %ld)", "", (long)rows);
+    g_rows_per_wave = rows;
+    return TRX_OK;
+}
+
+/* test/bench knob (not in the public header): 0 = full Kepler solve per sub-exposure */
+int trx_set_kepler_stepping(int on)
+{
+    g_step = on ? 1 : 0;
+    return TRX_OK;
+}
+
+const char* trx_version(void) { return "triceratops_amd libtrx 0.1.0 (gfx950)"; }
+const char* trx_last_error(void) { return g_err; }
+
+int trx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"
