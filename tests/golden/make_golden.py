@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own Python
+(/root/reference/triceratops: priors.py, funcs.py, likelihoods.py, marginal_likelihoods.py,
+_numerics.py) in the build container.
+
+The reference cannot be imported as-is here (astropy, pytransit, numba, mechanicalsoup, bs4 are
+not installed and there is no network), so this script installs throw-away `sys.modules` shims
+-- five astropy cgs constants, empty stubs for the web/FITS modules, and the CPU oracle's
+`QuadraticModel` at the pytransit seam -- and then runs the reference unmodified.  Only DATA
+leaves this script: inputs, seeds, every per-draw block the reference hands to its likelihood
+functions, their outputs, the log-weights it reduces, lnZ and the best-fit tables.  No reference
+source is copied.  Re-run:  python tests/golden/make_golden.py   (needs /root/reference).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import oracle as O  # noqa: E402
+
+
+def install_shims():
+    class _Q:
+        def __init__(self, v):
+            self.cgs = types.SimpleNamespace(value=v)
+
+    const = types.ModuleType("astropy.constants")
+    const.G = _Q(6.6743e-08)
+    const.M_sun = _Q(1.988409870698051e+33)
+    const.R_sun = _Q(69570000000.0)
+    const.R_earth = _Q(637810000.0)
+    const.au = _Q(14959787070000.0)
+    astropy = types.ModuleType("astropy")
+    astropy.constants = const
+    io = types.ModuleType("astropy.io")
+    fits = types.ModuleType("astropy.io.fits")
+    io.fits = fits
+    astropy.io = io
+    ms = types.ModuleType("mechanicalsoup")
+    ms.StatefulBrowser = object
+    bs4 = types.ModuleType("bs4")
+    bs4.BeautifulSoup = object
+    pt = types.ModuleType("pytransit")
+    pt.QuadraticModel = O.QuadraticModel
+    sys.modules.update({"astropy": astropy, "astropy.constants": const, "astropy.io": io,
+                        "astropy.io.fits": fits, "mechanicalsoup": ms, "bs4": bs4, "pytransit": pt})
+    sys.path.insert(0, REF)
+
+
+def write_trilegal(path, rng, n=400):
+    """synthetic TRILEGAL table with the columns funcs.trilegal_results reads + 2 trailer rows"""
+    import pandas as pd
+    mass = rng.uniform(0.12, 1.6, n)
+    logg = rng.uniform(3.2, 5.1, n)
+    logTe = np.log10(rng.uniform(3000, 11000, n))
+    mh = rng.uniform(-1.5, 0.4, n)
+    tess = rng.uniform(9.0, 21.0, n)
+    j = tess - rng.uniform(0.3, 1.2, n)
+    h = j - rng.uniform(0.1, 0.7, n)
+    ks = h - rng.uniform(0.0, 0.3, n)
+    df = pd.DataFrame({"Mact": mass, "logg": logg, "logTe": logTe, "[M/H]": mh, "TESS": tess,
+                       "J": j, "H": h, "Ks": ks})
+    trailer = pd.DataFrame({c: [np.nan, np.nan] for c in df.columns})
+    pd.concat([df, trailer]).to_csv(path)
+
+
+def write_contrast_curve(path):
+    sep = np.linspace(0.05, 4.0, 40)
+    con = 8.0 * (1 - np.exp(-sep / 0.8))
+    np.savetxt(path, np.stack([sep, con]).T, delimiter=",", fmt="%.6f")
+
+
+def synthetic_light_curve(n_time, seed):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(-0.2, 0.2, n_time)
+    Rsun, Rearth = 69570000000.0, 637810000.0
+    row = np.array([[0.085 * Rsun / Rearth], [3.3], [88.0], [11.0 * 0.8 * Rsun], [0.8], [0.45],
+                    [0.2], [0.0], [0.0], [0.0]])
+    curve = O.flux_grid(O.MODEL_TP, t, row)[0][0]
+    sigma = 6e-4
+    return t, curve + rng.normal(0, sigma, n_time), sigma
+
+
+def binned_toi1228(n_bins=200, half_width=0.4):
+    """TOI-1228 folded light curve of the reference's examples/, prepared like
+    examples/TSCIII_tutorial.ipynb cells 3-5 and 20: flux = y + 1, |t| < 0.4 d, 200 equal time
+    bins (mean per bin; the notebook uses lightkurve's .bin), sigma = std of the first 50 bins."""
+    import pandas as pd
+    lc = pd.read_csv(os.path.join(REF, "examples", "TOI1228_folded_lightcurve.csv"))
+    t, y = lc.x_fold.values.astype(float), lc.y.values.astype(float) + 1.0
+    keep = np.abs(t) < half_width
+    t, y = t[keep], y[keep]
+    width = 2 * np.max(t) / n_bins
+    idx = np.minimum(((t - t.min()) / width).astype(int), n_bins - 1)
+    tb = np.array([t[idx == i].mean() for i in range(n_bins) if np.any(idx == i)])
+    fb = np.array([y[idx == i].mean() for i in range(n_bins) if np.any(idx == i)])
+    return tb, fb, float(np.std(fb[:50]))
+
+
+def main():
+    install_shims()
+    import triceratops.funcs as rfuncs
+    import triceratops.likelihoods as rlik
+    import triceratops.marginal_likelihoods as rml
+    import triceratops.priors as rpri
+    from triceratops import _numerics as rnum
+
+    out = {}
+    rng = np.random.default_rng(1234)
+
+    # ---- (1) priors / funcs on fixed inputs ------------------------------------------------
+    x = np.concatenate([rng.uniform(0, 1, 500), [0.0, 1.0, 1e-12, 1 - 1e-12]])
+    out["uniforms"] = x
+    for M in (1.3, 1.0, 0.7, 0.3, 0.25, 0.1, 0.05):
+        out["sample_q_%g" % M] = rpri.sample_q(x.copy(), M)
+        out["sample_qc_%g" % M] = rpri.sample_q_companion(x.copy(), M)
+    Ms = rng.uniform(0.1, 1.5, x.size)
+    out["rp_masses"] = Ms
+    out["sample_rp"] = rpri.sample_rp(x.copy(), Ms, False)
+    out["sample_rp_flat"] = rpri.sample_rp(x.copy(), Ms, True)
+    out["sample_inc"] = rpri.sample_inc(x.copy())
+    out["sample_w"] = rpri.sample_w(x.copy())
+    for planet, P in ((True, 3.0), (False, 3.0), (False, 20.0)):
+        np.random.seed(77)
+        out["sample_ecc_%d_%g" % (planet, P)] = rpri.sample_ecc(x.copy(), planet, P)
+    masses = np.concatenate([rng.uniform(0.05, 3.0, 300), [0.63, 0.1, 0.26]])
+    out["sr_masses"] = masses
+    r_, t_ = rfuncs.stellar_relations(masses, np.full(masses.size, 1.1), np.full(masses.size, 6100.0))
+    out["sr_radii"], out["sr_teffs"] = r_, t_
+    for band in ("TESS", "Vis", "J", "H", "K"):
+        out["flux_relation_" + band] = rfuncs.flux_relation(masses, band)
+    dm = np.abs(rng.normal(3, 2.5, 400))
+    out["prior_dmags"] = dm
+    cc_path = os.path.join(HERE, "contrast_curve_synth.csv")
+    write_contrast_curve(cc_path)
+    seps, cons = rfuncs.file_to_contrast_curve(cc_path)
+    for M in (1.25, 0.8):
+        for plx in (12.5, np.nan):
+            tag = "%g_%s" % (M, "nan" if np.isnan(plx) else "%g" % plx)
+            out["bound_TP_" + tag] = rpri.lnprior_bound_TP(M, plx, dm, seps, cons)
+            out["bound_EB_" + tag] = rpri.lnprior_bound_EB(M, plx, dm, seps, cons)
+            out["bound_TP_nocc_" + tag] = rpri.lnprior_bound_TP(M, plx, dm, np.array([2.2]), np.array([1.0]))
+    out["background"] = rpri.lnprior_background(391, dm, seps, cons)
+    fl, fe = rfuncs.renorm_flux(np.array([1.0, 0.999, 0.9985]), 5e-4, 0.37)
+    out["renorm_flux"], out["renorm_err"] = fl, np.array([fe])
+    np.savez_compressed(os.path.join(HERE, "priors_funcs.npz"), **out)
+
+    # ---- (2) _numerics -------------------------------------------------------------------------
+    num = {}
+    vecs = {
+        "a": np.full(1000, -2000.0),
+        "b": np.array([-1001.0, -1002.0, -1003.0, -1004.0, -1005.0] + [-np.inf] * 5),
+        "c": np.array([-1.0] + [-np.inf] * 9),
+        "d": np.full(10, -np.inf),
+        "e": np.array([-1.0, np.nan, -np.inf, np.nan, -np.inf]),
+        "f": np.array([-1.0, np.inf, -3.0]),
+        "g": rng.uniform(-3000, -1, 5000),
+    }
+    vecs["g"][rng.uniform(size=5000) < 0.9] = -np.inf
+    for k, v in vecs.items():
+        num["lme_in_" + k] = v
+        num["lme_out_" + k] = np.array([rnum._log_mean_exp(v, N_total=v.size)])
+    lz = {"ok": np.array([-10.0, -11.0, -np.inf, -9.5]), "allneg": np.full(4, -np.inf),
+          "anom": np.array([-1.0, np.nan, -2.0])}
+    for k, v in lz.items():
+        p, st = rnum._normalize_probabilities(v)
+        num["norm_in_" + k], num["norm_out_" + k], num["norm_status_" + k] = v, p, np.array([st])
+    np.savez_compressed(os.path.join(HERE, "numerics.npz"), **num)
+
+    # ---- (3) the ten lnZ_* with every kernel-side block captured -----------------------------
+    tri_path = os.path.join(HERE, "trilegal_synth.csv")
+    write_trilegal(tri_path, np.random.default_rng(99))
+    t, f, sigma = synthetic_light_curve(60, 5)
+    star = dict(M_s=0.82, R_s=0.8, Teff=5100.0, Z=0.0, plx=14.2, Tmag=10.4, Jmag=9.5, Hmag=9.1,
+                Kmag=9.0)
+    captured = []
+
+    def wrap(name):
+        fn = getattr(rlik, name)
+
+        def inner(time, flux, sig, *cols, **kw):
+            args = [np.array(c, dtype=float, copy=True) for c in cols]
+            res = fn(time, flux, sig, *cols, **kw)
+            captured.append((name, args, dict(kw), np.array(res, copy=True)))
+            return res
+        return inner
+
+    logws = []
+
+    def lme(logw, *, N_total):
+        logws.append(np.array(logw, copy=True))
+        return rnum._log_mean_exp(logw, N_total=N_total)
+
+    for nm in ("lnL_TP_p", "lnL_EB_p", "lnL_EB_twin_p", "lnL_TP", "lnL_EB", "lnL_EB_twin"):
+        setattr(rml, nm, wrap(nm))
+    rml._log_mean_exp = lme
+
+    N = 2000
+    b = (t, f, sigma)
+    s = star
+    plan = {
+        "TTP": lambda P, par: rml.lnZ_TTP(*b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], N, par),
+        "TEB": lambda P, par: rml.lnZ_TEB(*b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], N, par),
+        "PTP": lambda P, par, cc=None, filt="TESS": rml.lnZ_PTP(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["plx"], cc, filt, N, par),
+        "PEB": lambda P, par, cc=None, filt="TESS": rml.lnZ_PEB(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["plx"], cc, filt, N, par),
+        "STP": lambda P, par, cc=None, filt="TESS": rml.lnZ_STP(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["plx"], cc, filt, N, par),
+        "SEB": lambda P, par, cc=None, filt="TESS": rml.lnZ_SEB(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["plx"], cc, filt, N, par),
+        "DTP": lambda P, par, cc=None, filt="TESS": rml.lnZ_DTP(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["Tmag"], s["Jmag"], s["Hmag"],
+            s["Kmag"], tri_path, cc, filt, N, par),
+        "DEB": lambda P, par, cc=None, filt="TESS": rml.lnZ_DEB(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Z"], s["Tmag"], s["Jmag"], s["Hmag"],
+            s["Kmag"], tri_path, cc, filt, N, par),
+        "BTP": lambda P, par, cc=None, filt="TESS": rml.lnZ_BTP(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Tmag"], s["Jmag"], s["Hmag"], s["Kmag"],
+            tri_path, cc, filt, N, par),
+        "BEB": lambda P, par, cc=None, filt="TESS": rml.lnZ_BEB(
+            *b, P, s["M_s"], s["R_s"], s["Teff"], s["Tmag"], s["Jmag"], s["Hmag"], s["Kmag"],
+            tri_path, cc, filt, N, par),
+    }
+    gold = {"time": t, "flux": f, "sigma": np.array([sigma]), "N": np.array([N]),
+            "star": np.array([star[k] for k in ("M_s", "R_s", "Teff", "Z", "plx", "Tmag", "Jmag",
+                                                "Hmag", "Kmag")])}
+    cases = []
+    seed = 1000
+    for name, fn in plan.items():
+        variants = [("par", 3.3, True, {}), ("range", [2.5, 4.0], True, {})]
+        if name not in ("TTP", "TEB"):
+            variants.append(("ccJ", 3.3, True, {"cc": cc_path, "filt": "J"}))
+        variants.append(("serial", 3.3, False, {}))
+        for vname, P, par, kw in variants:
+            if not par:
+                rml_N = 300   # the serial path is a Python loop over draws in the reference
+            seed += 1
+            np.random.seed(seed)
+            del captured[:], logws[:]
+            if par:
+                res = fn(P, par, **kw)
+            else:
+                # smaller N for the per-draw loop
+                old = N
+                res = _with_N(plan, name, rml, b, s, tri_path, 300, P, kw)
+            case = "%s_%s" % (name, vname)
+            cases.append(case)
+            dicts = res if isinstance(res, tuple) else (res,)
+            gold[case + "_seed"] = np.array([seed])
+            gold[case + "_nres"] = np.array([len(dicts)])
+            for i, d in enumerate(dicts):
+                gold["%s_lnZ%d" % (case, i)] = np.array([d["lnZ"]])
+                for k, v in d.items():
+                    if k != "lnZ":
+                        gold["%s_res%d_%s" % (case, i, k)] = np.asarray(v, dtype=float)
+            for i, lw in enumerate(logws):
+                gold["%s_logw%d" % (case, i)] = lw
+            if par:
+                for i, (cname, args, kw_, outv) in enumerate(captured):
+                    gold["%s_call%d_name" % (case, i)] = np.array([cname])
+                    gold["%s_call%d_block" % (case, i)] = np.stack(
+                        [np.broadcast_to(a, args[0].shape) for a in args]
+                        + [np.broadcast_to(kw_["companion_fluxratio"], args[0].shape)])
+                    gold["%s_call%d_is_host" % (case, i)] = np.array([bool(kw_.get("companion_is_host", False))])
+                    gold["%s_call%d_out" % (case, i)] = outv
+            else:
+                gold[case + "_ncalls"] = np.array([len(captured)])
+    gold["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "lnz_cases.npz"), **gold)
+
+    # ---- (4) BASELINE config 1: TOI-1228, TP scenario, N = 1e4 -------------------------------
+    tb, fb, sg = binned_toi1228()
+    np.random.seed(20260424 % (2 ** 32))
+    del captured[:], logws[:]
+    # TIC 300038935: mass, radius, Teff from the stars table shown in TSCIII_tutorial.ipynb cell 14
+    res = rml.lnZ_TTP(tb, fb, sg, 29.04992, 2.13, 1.79626, 8557.0, 0.0, 10000, True)
+    np.savez_compressed(os.path.join(HERE, "toi1228_ttp.npz"), time=tb, flux=fb,
+                        sigma=np.array([sg]), P_orb=np.array([29.04992]),
+                        star=np.array([2.13, 1.79626, 8557.0, 0.0]), N=np.array([10000]),
+                        seed=np.array([20260424]), lnZ=np.array([res["lnZ"]]),
+                        logw=logws[0], block=np.stack(captured[0][1] + [np.zeros_like(captured[0][1][0])]),
+                        out=captured[0][3],
+                        **{"res_" + k: np.asarray(v, dtype=float) for k, v in res.items() if k != "lnZ"})
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+def _with_N(plan, name, rml, b, s, tri_path, n, P, kw):
+    """serial-path call with a smaller N (the reference loops over draws in Python)"""
+    cc, filt = kw.get("cc"), kw.get("filt", "TESS")
+    base = (*b, P, s["M_s"], s["R_s"], s["Teff"])
+    mags = (s["Tmag"], s["Jmag"], s["Hmag"], s["Kmag"], tri_path, cc, filt, n, False)
+    bound = (s["Z"], s["plx"], cc, filt, n, False)
+    table = {
+        "TTP": lambda: rml.lnZ_TTP(*base, s["Z"], n, False),
+        "TEB": lambda: rml.lnZ_TEB(*base, s["Z"], n, False),
+        "PTP": lambda: rml.lnZ_PTP(*base, *bound), "PEB": lambda: rml.lnZ_PEB(*base, *bound),
+        "STP": lambda: rml.lnZ_STP(*base, *bound), "SEB": lambda: rml.lnZ_SEB(*base, *bound),
+        "DTP": lambda: rml.lnZ_DTP(*base, s["Z"], *mags), "DEB": lambda: rml.lnZ_DEB(*base, s["Z"], *mags),
+        "BTP": lambda: rml.lnZ_BTP(*base, *mags), "BEB": lambda: rml.lnZ_BEB(*base, *mags),
+    }
+    return table[name]()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/trx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "trx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = _declared()
+    for must in ("trx_lnl_batch", "trx_flux_grid", "trx_log_mean_exp", "trx_lnz_scenario",
+                 "trx_version", "trx_device_count"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    lib_path = g.build()
+    lib = ctypes.CDLL(lib_path)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    lib.trx_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.trx_version()
+
+
+def test_python_binding_lists_the_same_symbols():
+    from triceratops_amd import _lib
+    assert sorted(_lib.ABI_SYMBOLS) == _declared()
+
+
+def test_argument_checks_need_no_gpu():
+    from triceratops_amd import _lib
+    L = _lib.lib()
+    # N_total guard of _log_mean_exp (_numerics.py:40-45) is checked before anything is enqueued
+    rc = L.trx_log_mean_exp(None, 5, 7, None, None, 0, None)
+    assert rc != 0
+    rc = L.trx_lnl_batch(9, 0, None, None, 0, 1.0, None, 0, 0.0, 1, None, None)
+    assert rc == 1 and b"unknown model" in L.trx_last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from triceratops_amd import _lib
+    with pytest.raises(_lib.TrxError):
+        _lib.require_gpu()
+
+
+def test_product_never_touches_the_oracle():
+    """nothing under triceratops_amd/ may import, link or even name the CPU checker"""
+    pkg = os.path.join(ROOT, "triceratops_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read().lower()
+                assert "oracle" not in src, f

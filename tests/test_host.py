@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference (priors, funcs, _numerics, marginal_likelihoods, calc_probs)
+against golden vectors produced by the imported reference (tests/golden/make_golden.py).
+
+These run on a CPU-only box: the device entry points are replaced by an oracle-backed stand-in
+(tests/helpers.py) so that what is under test is the host logic -- draw order on the global
+numpy stream, derived columns, masks, priors, evidence bookkeeping, best-fit tables.  The real
+kernels are exercised by the -m gpu tests with the same golden files.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLD, gold, install_cpu_device_fakes
+from triceratops_amd import funcs, priors
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------
+def test_samplers_bit_identical_to_reference():
+    g = gold("priors_funcs.npz")
+    x = g["uniforms"]
+    for M in (1.3, 1.0, 0.7, 0.3, 0.25, 0.1, 0.05):
+        assert _same(priors.sample_q(x.copy(), M), g["sample_q_%g" % M]), M
+        assert _same(priors.sample_q_companion(x.copy(), M), g["sample_qc_%g" % M]), M
+    assert _same(priors.sample_rp(x.copy(), g["rp_masses"], False), g["sample_rp"])
+    assert _same(priors.sample_rp(x.copy(), g["rp_masses"], True), g["sample_rp_flat"])
+    assert _same(priors.sample_inc(x.copy()), g["sample_inc"])
+    assert _same(priors.sample_w(x.copy()), g["sample_w"])
+    for planet, P in ((True, 3.0), (False, 3.0), (False, 20.0)):
+        np.random.seed(77)
+        assert _same(priors.sample_ecc(x.copy(), planet, P), g["sample_ecc_%d_%g" % (planet, P)])
+    # samplers do not touch the caller's array (the reference mutates it in place)
+    y = x.copy()
+    priors.sample_q(y, 0.7)
+    priors.sample_rp(y, g["rp_masses"], False)
+    assert _same(y, x)
+
+
+def test_stellar_and_flux_relations_bit_identical():
+    g = gold("priors_funcs.npz")
+    m = g["sr_masses"]
+    r, t = funcs.stellar_relations(m, np.full(m.size, 1.1), np.full(m.size, 6100.0))
+    assert _same(r, g["sr_radii"]) and _same(t, g["sr_teffs"])
+    for band in ("TESS", "Vis", "J", "H", "K"):
+        assert _same(funcs.flux_relation(m, band), g["flux_relation_" + band])
+    fl, fe = funcs.renorm_flux(np.array([1.0, 0.999, 0.9985]), 5e-4, 0.37)
+    assert _same(fl, g["renorm_flux"]) and fe == g["renorm_err"][0]
+
+
+def test_companion_priors_bit_identical():
+    g = gold("priors_funcs.npz")
+    dm = g["prior_dmags"]
+    seps, cons = funcs.file_to_contrast_curve(os.path.join(GOLD, "contrast_curve_synth.csv"))
+    for M in (1.25, 0.8):
+        for plx in (12.5, np.nan):
+            tag = "%g_%s" % (M, "nan" if np.isnan(plx) else "%g" % plx)
+            assert _same(priors.lnprior_bound_TP(M, plx, dm, seps, cons), g["bound_TP_" + tag])
+            assert _same(priors.lnprior_bound_EB(M, plx, dm, seps, cons), g["bound_EB_" + tag])
+            assert _same(priors.lnprior_bound_TP(M, plx, dm, np.array([2.2]), np.array([1.0])),
+                         g["bound_TP_nocc_" + tag])
+    assert _same(priors.lnprior_background(391, dm, seps, cons), g["background"])
+    # natural log of (N/0.1)(1/3600)^2 sep^2 (reference tests/test_background_prior_log_base.py)
+    sep = np.interp(dm, cons, seps)
+    assert np.allclose(priors.lnprior_background(391, dm, seps, cons),
+                       np.log((391 / 0.1) * (1 / 3600) ** 2 * sep ** 2), rtol=1e-15)
+
+
+def test_normalize_probabilities_and_lme_guard(monkeypatch):
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd._numerics import _log_mean_exp, _normalize_probabilities
+    g = gold("numerics.npz")
+    for k in ("ok", "allneg", "anom"):
+        p, st = _normalize_probabilities(g["norm_in_" + k])
+        assert st == str(g["norm_status_" + k][0]) and np.allclose(p, g["norm_out_" + k], atol=1e-16)
+    for k in "abcdefg":
+        x, want = g["lme_in_" + k], g["lme_out_" + k][0]
+        got = _log_mean_exp(x, N_total=x.size)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) < 1e-12
+    with pytest.raises(ValueError):
+        _log_mean_exp(np.zeros(5), N_total=4)
+
+
+# ---------------------------------------------------------------------------------------
+def _star(g):
+    return dict(zip(("M_s", "R_s", "Teff", "Z", "plx", "Tmag", "Jmag", "Hmag", "Kmag"), g["star"]))
+
+
+def _call(ml, name, g, P, N, parallel, cc, filt):
+    s = _star(g)
+    t, f, sigma = g["time"], g["flux"], float(g["sigma"][0])
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    base = (t, f, sigma, P, float(s["M_s"]), float(s["R_s"]), float(s["Teff"]))
+    fn = getattr(ml, "lnZ_" + name)
+    if name in ("TTP", "TEB"):
+        return fn(*base, 0.0, N, parallel)
+    if name in ("PTP", "PEB", "STP", "SEB"):
+        return fn(*base, 0.0, float(s["plx"]), cc, filt, N, parallel)
+    mags = tuple(float(s[k]) for k in ("Tmag", "Jmag", "Hmag", "Kmag"))
+    if name in ("DTP", "DEB"):
+        return fn(*base, 0.0, *mags, tri, cc, filt, N, parallel)
+    return fn(*base, *mags, tri, cc, filt, N, parallel)
+
+
+CASES = [str(c) for c in gold("lnz_cases.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lnz_functions_reproduce_reference_draw_for_draw(case, monkeypatch):
+    """same np.random.seed -> same per-draw log-weights, lnZ and best-fit tables as the reference
+    (whose model calls went through the oracle's QuadraticModel)"""
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("lnz_cases.npz")
+    name, variant = case.split("_")
+    P = [2.5, 4.0] if variant == "range" else 3.3
+    cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
+    filt = "J" if variant == "ccJ" else "TESS"
+    parallel = variant != "serial"
+    N = int(g["N"][0]) if parallel else 300
+    captured = []
+    real = ml._lib.lnz_scenario
+
+    def spy(model, flags, t, f, sigma, params, exptime, nsamples, lnprior, n_total, lnsigma):
+        h, lnz = real(model, flags, t, f, sigma, params, exptime, nsamples, lnprior, n_total, lnsigma)
+        captured.append((params.numpy().copy(), h.numpy().copy()))
+        return h, lnz
+
+    monkeypatch.setattr(ml._lib, "lnz_scenario", spy)
+    np.random.seed(int(g[case + "_seed"][0]))
+    res = _call(ml, name, g, P, N, parallel, cc, filt)
+    dicts = res if isinstance(res, tuple) else (res,)
+    assert len(dicts) == int(g[case + "_nres"][0])
+    for i, d in enumerate(dicts):
+        want_lnz = g["%s_lnZ%d" % (case, i)][0]
+        if np.isfinite(want_lnz):
+            assert abs(d["lnZ"] - want_lnz) < 1e-10, (case, i, d["lnZ"], want_lnz)
+        else:
+            assert d["lnZ"] == want_lnz
+        assert isinstance(d["lnZ"], float)
+        logw = g["%s_logw%d" % (case, i)]
+        n_fin = int(np.isfinite(logw).sum())
+        for k in ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
+                  "R_EB", "fluxratio_EB", "fluxratio_comp"):
+            want = g["%s_res%d_%s" % (case, i, k)]
+            assert d[k].shape == (100,)
+            # rows beyond the finite draws are ties at -inf whose order is arbitrary
+            top = min(n_fin, 100) if k not in ("M_s", "R_s", "u1", "u2") or d[k].std() > 0 else 100
+            assert np.allclose(d[k][:top], want[:top], rtol=1e-13, atol=0), (case, i, k)
+    if parallel:
+        # the parameter blocks handed to the kernels are the reference's, bit for bit
+        for i, (block, h) in enumerate(captured):
+            want_block = g["%s_call%d_block" % (case, i)]
+            assert _same(block, want_block), (case, i)
+            want_h = g["%s_call%d_out" % (case, i)]
+            fin = np.isfinite(want_h)
+            assert np.array_equal(np.isposinf(h), np.isposinf(want_h))
+            assert np.allclose(h[fin], want_h[fin], rtol=1e-12, atol=0)
+
+
+def test_toi1228_config1(monkeypatch):
+    """BASELINE configs[0]: TOI-1228 folded light curve, TP scenario, N = 1e4"""
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("toi1228_ttp.npz")
+    M, R, Teff, Z = (float(v) for v in g["star"])
+    np.random.seed(int(g["seed"][0]))
+    res = ml.lnZ_TTP(g["time"], g["flux"], float(g["sigma"][0]), float(g["P_orb"][0]), M, R, Teff,
+                     Z, int(g["N"][0]), True)
+    assert abs(res["lnZ"] - g["lnZ"][0]) < 1e-10
+    for k in ("P_orb", "inc", "b", "R_p", "ecc", "argp"):
+        assert np.allclose(res[k], g["res_" + k], rtol=1e-13)
+
+
+def test_numpy_scalar_period_takes_the_range_branch(monkeypatch):
+    """`type(P_orb) not in [float, int]` (marginal_likelihoods.py:67): a numpy float is a range"""
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("lnz_cases.npz")
+    with pytest.raises((IndexError, TypeError)):
+        ml.lnZ_TTP(g["time"], g["flux"], 6e-4, np.float64(3.3), 0.8, 0.8, 5100.0, 0.0, 50, True)
+
+
+def test_missing_ldc_combination_raises_like_the_reference(monkeypatch):
+    """SEB allows rounded companion Teff up to 13000 K, past the 10000 K end of the grid
+    (marginal_likelihoods.py:1181): .item() on the empty match raises ValueError"""
+    from triceratops_amd import marginal_likelihoods as ml
+    tab = ml._ldc("TESS")
+    u1, u2 = tab.companions(0.0, np.array([5000.0, 9900.0]), np.array([4.4, 4.1]), 13000)
+    assert u1.shape == (2,)
+    with pytest.raises(ValueError):
+        tab.companions(0.0, np.array([12400.0]), np.array([4.0]), 13000)

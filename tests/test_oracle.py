@@ -1,0 +1,205 @@
+"""Pinning the CPU oracle (oracle/trx_oracle.c).
+
+ * _log_mean_exp / _normalize_probabilities: against values produced by the imported reference
+   module (tests/golden/numerics.npz) and the exact known answers the reference's own
+   tests/test_log_mean_exp.py asserts.
+ * unit conversion, radius-ratio rule, dilution, secondary depth, chi^2/2, +inf rule: against the
+   blocks and outputs captured from the reference's own likelihoods.py while it ran on top of the
+   oracle's QuadraticModel (tests/golden/lnz_cases.npz, made by tests/golden/make_golden.py).
+ * the Mandel-Agol / Kepler arithmetic (parity unpinned against pytransit, see oracle header):
+   against closed forms and an independent arbitrary-precision quadrature of the limb-darkened
+   disk.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import gold
+
+
+# ---------------------------------------------------------------------------------------
+# _numerics
+def test_lme_matches_reference_outputs():
+    g = gold("numerics.npz")
+    for k in "abcdefg":
+        x, want = g["lme_in_" + k], g["lme_out_" + k][0]
+        got = O.log_mean_exp(x, x.size)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) < 1e-12, k
+
+
+def test_lme_known_answers_of_reference_tests():
+    # values asserted in the reference's tests/test_log_mean_exp.py (24-270)
+    assert abs(O.log_mean_exp(np.full(1000, -2000.0), 1000) - (-2000.0)) < 1e-10
+    x = np.array([-1001.0, -1002.0, -1003.0, -1004.0, -1005.0] + [-np.inf] * 5)
+    m = x[:5].max()
+    want = m + np.log(np.sum(np.exp(x[:5] - m))) - np.log(10)
+    assert abs(O.log_mean_exp(x, 10) - want) < 1e-12
+    assert abs(O.log_mean_exp(np.array([-1.0] + [-np.inf] * 9), 10) - (-1 - np.log(10))) < 1e-14
+    assert abs(O.log_mean_exp(np.array([-1.0, np.nan, -np.inf, np.nan, -np.inf]), 5) - (-1 - np.log(5))) < 1e-14
+    for n in (1, 10, 100000):
+        assert O.log_mean_exp(np.full(n, -np.inf), n) == -np.inf
+    assert O.log_mean_exp(np.array([-1.0, np.inf]), 2) == np.inf
+    assert O.log_mean_exp(np.array([-3.5]), 1) == -3.5
+    with pytest.raises(ValueError):
+        O.log_mean_exp(np.zeros(4), 3)
+
+
+def test_normalize_matches_reference_outputs():
+    g = gold("numerics.npz")
+    for k in ("ok", "allneg", "anom"):
+        p, st = O.normalize_probabilities(g["norm_in_" + k])
+        assert st == str(g["norm_status_" + k][0])
+        assert np.allclose(p, g["norm_out_" + k], rtol=0, atol=1e-15)
+    p, st = O.normalize_probabilities(np.array([0.0, 1.0]))
+    assert st == "ok" and abs(p[1] / p[0] - np.e) < 1e-12
+    p, _ = O.normalize_probabilities(np.array([-np.inf, -5.0]))
+    assert p[0] == 0.0 and p[1] == 1.0
+
+
+# ---------------------------------------------------------------------------------------
+# likelihoods.py, as driven by the reference itself
+def _calls(g):
+    for case in g["cases"]:
+        i = 0
+        while "%s_call%d_name" % (case, i) in g.files:
+            yield case, i
+            i += 1
+
+
+def test_lnl_matches_reference_likelihoods_on_captured_blocks():
+    g = gold("lnz_cases.npz")
+    t, f, sigma = g["time"], g["flux"], float(g["sigma"][0])
+    model = {"lnL_TP_p": O.MODEL_TP, "lnL_EB_p": O.MODEL_EB, "lnL_EB_twin_p": O.MODEL_EB_TWIN}
+    n_checked = 0
+    for case, i in _calls(g):
+        name = str(g["%s_call%d_name" % (case, i)][0])
+        block = g["%s_call%d_block" % (case, i)]
+        want = g["%s_call%d_out" % (case, i)]
+        is_host = bool(g["%s_call%d_is_host" % (case, i)][0])
+        if block.shape[1] == 0:
+            continue
+        got = O.lnl_batch(model[name], t, f, sigma, block, companion_is_host=is_host)
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)), (case, i)
+        fin = np.isfinite(want)
+        # the reference sums with numpy's pairwise float64 sum, the oracle in long double
+        assert np.allclose(got[fin], want[fin], rtol=1e-12, atol=0), (case, i)
+        n_checked += fin.sum()
+    assert n_checked > 2000
+
+
+def test_toi1228_config1_block():
+    """BASELINE configs[0]: TOI-1228, TP scenario, N = 1e4, CPU"""
+    g = gold("toi1228_ttp.npz")
+    got = O.lnl_batch(O.MODEL_TP, g["time"], g["flux"], float(g["sigma"][0]), g["block"])
+    assert np.allclose(got, g["out"], rtol=1e-12, atol=0)
+    lnL = g["logw"]
+    assert abs(O.log_mean_exp(lnL, lnL.size) - g["lnZ"][0]) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------
+# transit model known answers
+def test_uniform_disk_closed_forms():
+    k = 0.1
+    assert abs(O.ma_flux(0.0, k, 0, 0) - (1 - k * k)) < 1e-15
+    assert abs(O.ma_flux(0.5, k, 0, 0) - (1 - k * k)) < 1e-15
+    assert O.ma_flux(1.1 + 1e-9, k, 0.4, 0.2) == 1.0
+    assert O.ma_flux(1.1, k, 0.4, 0.2) == 1.0
+    assert O.ma_flux(0.3, 1.5, 0.4, 0.2) == 0.0
+    # lens formula on ingress
+    z = 1.02
+    k0 = np.arccos((k * k + z * z - 1) / (2 * k * z))
+    k1 = np.arccos((1 - k * k + z * z) / (2 * z))
+    lens = (k * k * k0 + k1 - 0.5 * np.sqrt(4 * z * z - (1 + z * z - k * k) ** 2)) / np.pi
+    assert abs(O.ma_flux(z, k, 0, 0) - (1 - lens)) < 1e-15
+
+
+def test_limb_darkened_centre_closed_form():
+    # z = 0: F = 1 - [ (1-c2) k^2 + c2 (2/3)(1 - (1-k^2)^1.5) + u2 k^4/2 ] / (1 - u1/3 - u2/6)
+    for k, u1, u2 in ((0.1, 0.4, 0.25), (0.5, 0.6, -0.1), (0.9, 0.2, 0.3)):
+        c2 = u1 + 2 * u2
+        want = 1 - ((1 - c2) * k * k + c2 * (2 / 3) * (1 - (1 - k * k) ** 1.5) + u2 * k ** 4 / 2) / (1 - u1 / 3 - u2 / 6)
+        assert abs(O.ma_flux(0.0, k, u1, u2) - want) < 2e-15
+
+
+def _quadrature_flux(z, p, u1, u2):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 30
+    z, p, u1, u2 = map(mp.mpf, (z, p, u1, u2))
+    if z >= 1 + p:
+        return mp.mpf(1)
+
+    def intensity(r):
+        mu = mp.sqrt(1 - r * r)
+        return 1 - u1 * (1 - mu) - u2 * (1 - mu) ** 2
+
+    def half_arc(r):
+        if r + z <= p:
+            return mp.pi
+        if abs(z - r) >= p:
+            return mp.mpf(0)
+        return mp.acos((r * r + z * z - p * p) / (2 * r * z))
+
+    pts = sorted({max(mp.mpf(0), z - p), abs(p - z), min(mp.mpf(1), z + p)})
+    pts = [x for x in pts if 0 <= x <= 1]
+    if p > z and pts[0] != 0:
+        pts = [mp.mpf(0)] + pts
+    occ = mp.quad(lambda r: intensity(r) * 2 * half_arc(r) * r, pts)
+    return 1 - occ / (mp.pi * (1 - u1 / 3 - u2 / 6))
+
+
+def test_flux_against_independent_quadrature():
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for i in range(60):
+        p = 10 ** rng.uniform(-2.5, 0) if i % 3 else rng.uniform(0.02, 0.2)
+        mode = i % 5
+        if mode == 0:
+            z = rng.uniform(0, 1 + p)
+        elif mode == 1:
+            z = abs(1 - p) + 10 ** rng.uniform(-10, -2) * rng.choice([-1, 1])
+        elif mode == 2:
+            z = 1 + p - 10 ** rng.uniform(-10, -2)
+        elif mode == 3:
+            z = p + 10 ** rng.uniform(-12, -2) * rng.choice([-1, 1])
+        else:
+            z = 10 ** rng.uniform(-10, 0)
+        z = abs(z)
+        u1, u2 = rng.uniform(0, 0.8), rng.uniform(-0.1, 0.5)
+        err = abs(float(O.ma_flux(z, p, u1, u2)) - float(_quadrature_flux(z, p, u1, u2)))
+        worst = max(worst, err)
+    assert worst < 1e-13, worst
+    # exact special points (z = p, z = 1 - p, p = 1/2) take the closed-form branches
+    for z, p in ((0.3, 0.3), (0.7, 0.3), (0.5, 0.5), (0.2, 0.8), (0.8, 0.8)):
+        err = abs(float(O.ma_flux(z, p, 0.4, 0.25)) - float(_quadrature_flux(z, p, 0.4, 0.25)))
+        assert err < 1e-13, (z, p, err)
+    # occulter larger than the star (secondary-eclipse regime): coefficients grow like p^4
+    for z, p in ((2.5, 3.0), (19.5, 20.0), (20.3, 20.0)):
+        err = abs(float(O.ma_flux(z, p, 0.4, 0.25)) - float(_quadrature_flux(z, p, 0.4, 0.25)))
+        assert err < 1e-10, (z, p, err)
+
+
+def test_kepler_and_orbit_conventions():
+    rng = np.random.default_rng(3)
+    e = rng.uniform(0, 0.95, 500)
+    M = rng.uniform(-10, 10, 500)
+    E = O.kepler_E(M, e)
+    Mr = np.remainder(M + np.pi, 2 * np.pi) - np.pi
+    assert np.abs(E - e * np.sin(E) - Mr).max() < 5e-15
+    # circular, edge-on: mid-transit at t0, symmetric in time, depth k^2-ish at centre
+    t = np.linspace(-0.2, 0.2, 41)
+    f = O.evaluate_pv(t, [[0.1, 0.0, 3.0, 10.0, np.pi / 2, 0.0, 0.0]], [[0.0, 0.0]])[0]
+    assert abs(f[20] - 0.99) < 1e-15 and np.abs(f - f[::-1]).max() < 1e-14
+    # eccentric: w = 90deg - argp puts inferior conjunction at t0 as well
+    for w in (0.3, 2.0, 4.5):
+        f = O.evaluate_pv(t, [[0.1, 0.0, 3.0, 10.0, np.pi / 2, 0.5, w]], [[0.3, 0.2]])[0]
+        assert np.argmin(f) in (19, 20, 21)
+    # half a period later the planet is behind the star: no dip
+    f = O.evaluate_pv(t + 1.5, [[0.1, 0.0, 3.0, 10.0, np.pi / 2, 0.0, 0.0]], [[0.3, 0.2]])[0]
+    assert np.all(f == 1.0)
+    # supersampling = mean of sub-exposures at t + exptime*((s-0.5)/S - 0.5)
+    S, ex = 7, 0.03
+    tt = np.array([0.05])
+    sub = np.array([O.evaluate_pv(tt + ex * ((s - 0.5) / S - 0.5), [[0.1, 0.0, 3.0, 10.0, 1.55, 0.2, 1.0]],
+                                  [[0.3, 0.2]])[0, 0] for s in range(1, S + 1)])
+    got = O.evaluate_pv(tt, [[0.1, 0.0, 3.0, 10.0, 1.55, 0.2, 1.0]], [[0.3, 0.2]], ex, S)[0, 0]
+    assert abs(got - sub.mean()) < 1e-15

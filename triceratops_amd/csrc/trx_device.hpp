@@ -81,7 +81,7 @@ __device__ __forceinline__ Limb limb_weights(double u1, double u2)
 }
 
 // Mandel & Agol (2002) quadratic-law flux for 0 <= z < 1+p, p > 0 (callers handle the
-// unocculted side).  Same case analysis and factored contact-triangle form as the oracle.
+// unocculted side).  Case analysis and factored contact-triangle form: DESIGN.md section 4.
 __device__ double ma_flux(double z, double p, const Limb& L)
 {
     if (p >= 1.0 && z <= p - 1.0) return 0.0;

@@ -1,0 +1,549 @@
+"""Marginal likelihoods (evidences) of the triceratops scenarios on the MI355X kernels.
+
+Same entry points, positional signatures and return conventions as the reference's
+triceratops/marginal_likelihoods.py for the ten functions calc_probs calls:
+  lnZ_TTP (39-172), lnZ_TEB (175-383), lnZ_PTP (386-586), lnZ_PEB (589-866), lnZ_STP (869-1077),
+  lnZ_SEB (1080-1376), lnZ_DTP (1379-1568), lnZ_DEB (1571-1837), lnZ_BTP (1840-2035),
+  lnZ_BEB (2038-2362).
+TP family -> one dict, EB family -> (res, res_twin); every dict holds the 14 best-fit columns
+(100 draws, by decreasing lnL) and 'lnZ' (Python float, may be -inf).
+
+How one call runs:
+  host (numpy)  draw the priors from the *global* numpy stream in the reference's order, derive
+                the per-draw stellar/orbital columns, build the geometry mask and lnprior_companion
+  device (HIP)  the n masked draws are packed into one SoA block; trx_lnz_scenario evaluates the
+                supersampled light-curve model, chi^2/2 per draw and the log-mean-exp evidence
+  host          lnL vector, best-100 table
+`parallel=True` reproduces the reference's vector path, `parallel=False` its per-draw loop
+semantics (draws with Ptra > 1 skipped, scalar radius-ratio rule; App. C of SURVEY.md) -- both
+run on the GPU, there is no Python loop over draws here.
+"""
+from pathlib import Path
+
+import numpy as np
+from pandas import read_csv
+
+from . import _lib
+from ._lib import FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, MODEL_EB, MODEL_EB_TWIN, MODEL_TP
+from ._numerics import _log_mean_exp  # noqa: F401  (same module surface as the reference)
+from .constants import G, Msun, Rearth, Rsun, au, ln2pi, pi  # noqa: F401
+from .funcs import (file_to_contrast_curve, flux_relation, stellar_relations, trilegal_results)
+from .likelihoods import *  # noqa: F401,F403  (the reference re-exports these names)
+from .priors import *  # noqa: F401,F403
+from .priors import (lnprior_background, lnprior_bound_EB, lnprior_bound_TP, sample_ecc, sample_inc,
+                     sample_q, sample_q_companion, sample_rp, sample_w)
+
+np.seterr(divide='ignore')
+
+_DATA_DIR = Path(__file__).parent / "data"
+N_BEST = 100
+
+
+# ---------------------------------------------------------------------------------------
+# limb-darkening tables (Claret grids shipped as data; marginal_likelihoods.py:21-37)
+class _LdcTable:
+    def __init__(self, fname, c1, c2):
+        df = read_csv(_DATA_DIR / fname)
+        self.Zs = np.array(df.Z, dtype=float)
+        self.Teffs = np.array(df.Teff, dtype=int)
+        self.loggs = np.array(df.logg, dtype=float)
+        self.u1s = np.array(df[c1], dtype=float)
+        self.u2s = np.array(df[c2], dtype=float)
+
+    def _one(self, sel):
+        """exactly-one-row lookup; raises ValueError like ndarray.item() on size != 1"""
+        return self.u1s[sel].item(), self.u2s[sel].item()
+
+    def star(self, Z, Teff, logg):
+        """nearest node in Z, Teff and logg independently (e.g. marginal_likelihoods.py:90-98)"""
+        z = self.Zs[np.argmin(np.abs(self.Zs - Z))]
+        t = self.Teffs[np.argmin(np.abs(self.Teffs - Teff))]
+        g = self.loggs[np.argmin(np.abs(self.loggs - logg))]
+        return self._one((self.Zs == z) & (self.Teffs == t) & (self.loggs == g))
+
+    def companions(self, Z, Teffs, loggs, teff_cap):
+        """per-draw coefficients on the rounded (Teff/250, logg/0.5) grid at the nearest Z
+        (marginal_likelihoods.py:945-972; cap 10000 K for STP, 13000 K for SEB :1181)."""
+        atZ = self.Zs == self.Zs[np.abs(self.Zs - Z).argmin()]
+        tz, gz, a1, a2 = self.Teffs[atZ], self.loggs[atZ], self.u1s[atZ], self.u2s[atZ]
+        rg = np.round(loggs / 0.5) * 0.5
+        rg[rg < 3.5] = 3.5
+        rg[rg > 5.0] = 5.0
+        rt = np.round(Teffs / 250) * 250
+        rt[rt < 3500] = 3500
+        rt[rt > teff_cap] = teff_cap
+        pairs, inv = np.unique(np.stack([rt, rg]), axis=1, return_inverse=True)
+        c1, c2 = np.empty(pairs.shape[1]), np.empty(pairs.shape[1])
+        for j in range(pairs.shape[1]):
+            sel = (tz == pairs[0, j]) & (gz == pairs[1, j])
+            c1[j], c2[j] = a1[sel].item(), a2[sel].item()
+        inv = np.ravel(inv)
+        return c1[inv], c2[inv]
+
+    def field_stars(self, Teffs, loggs, Zs):
+        """per-background-star coefficients: nearest Teff and logg, then the nearest Z among the
+        rows of that (Teff, logg) (marginal_likelihoods.py:1913-1924)."""
+        t = self.Teffs[np.argmin(np.abs(self.Teffs[None, :] - Teffs[:, None]), axis=1)]
+        g = self.loggs[np.argmin(np.abs(self.loggs[None, :] - loggs[:, None]), axis=1)]
+        cell = (self.Teffs[None, :] == t[:, None]) & (self.loggs[None, :] == g[:, None])
+        dz = np.where(cell, np.abs(self.Zs[None, :] - Zs[:, None]), np.inf)
+        z = self.Zs[np.argmin(dz, axis=1)]
+        row = cell & (self.Zs[None, :] == z[:, None])
+        if not np.all(row.sum(axis=1) == 1):
+            raise ValueError("can only convert an array of size 1 to a Python scalar")
+        idx = np.argmax(row, axis=1)
+        return self.u1s[idx], self.u2s[idx]
+
+
+_tables = {}
+
+
+def _ldc(mission):
+    key = "TESS" if mission == "TESS" else "Kepler"
+    if key not in _tables:
+        _tables[key] = (_LdcTable("ldc_tess.csv", "aLSM", "bLSM") if key == "TESS"
+                        else _LdcTable("ldc_kepler.csv", "a", "b"))
+    return _tables[key]
+
+
+# ---------------------------------------------------------------------------------------
+# shared pieces of every scenario
+def _periods(P_orb, N):
+    """fixed period, or a uniform draw when a [lo, hi] range is given; numpy scalars take the
+    range branch like the reference's `type(P_orb) not in [float, int]` test"""
+    if type(P_orb) not in [float, int]:
+        return np.random.uniform(low=P_orb[0], high=P_orb[-1], size=N)
+    return np.full(N, P_orb)
+
+
+def _sma(M_tot, P_days):
+    return ((G * M_tot * Msun) / (4 * pi ** 2) * (P_days * 86400) ** 2) ** (1 / 3)
+
+
+def _logg(M, R):
+    return np.log10(G * (M * Msun) / (R * Rsun) ** 2)
+
+
+def _flux_share(masses, M_s, filt="TESS"):
+    return flux_relation(masses, filt) / (flux_relation(masses, filt)
+                                          + flux_relation(np.array([M_s]), filt))
+
+
+def _e_corr(eccs, argps):
+    return (1 + eccs * np.sin(argps * pi / 180)) / (1 - eccs ** 2)
+
+
+def _impact(a, eccs, argps, incs, R_host):
+    r = a * (1 - eccs ** 2) / (1 + eccs * np.sin(argps * np.pi / 180))
+    return r * np.cos(incs * pi / 180) / (R_host * Rsun)
+
+
+def _transits(Ptra, incs, parallel):
+    """draws inclined enough to transit.  Vector path: inc_min = 90 where Ptra > 1; serial path:
+    such draws are skipped (`continue`)."""
+    ok = Ptra <= 1.
+    inc_min = np.full(len(Ptra), 90.)
+    inc_min[ok] = np.arccos(Ptra[ok]) * 180. / pi
+    hit = incs >= inc_min
+    return hit if parallel else (hit & ok)
+
+
+def _bound_companions(M_s, N, molusc_file):
+    """mass ratios of unresolved bound companions: prior draw, or a MOLUSC table
+    (marginal_likelihoods.py:455-464)"""
+    if molusc_file is None:
+        return sample_q_companion(np.random.rand(N), M_s)
+    df = read_csv(molusc_file)
+    sma = df["semi-major axis(AU)"].values
+    ecc = df["eccentricity"].values
+    qs = df[sma * (1 - ecc) > 10]["mass ratio"].values
+    qs[qs < 0.1 / M_s] = 0.1 / M_s
+    return np.pad(qs, (0, N - len(qs)))
+
+
+def _clip_prior(lnprior, delta_mags):
+    lnprior[lnprior > 0.0] = 0.0
+    lnprior[delta_mags > 0.0] = -np.inf
+    return lnprior
+
+
+def _bound_prior(kind, M_s, plx, N, molusc_file, contrast_curve_file, fr_tess, fr_cc_fn):
+    """lnprior_companion of the P and S scenarios (e.g. marginal_likelihoods.py:477-509).
+    fr_tess: total companion flux term in the TESS band; fr_cc_fn(): same in the contrast-curve
+    filter (evaluated only when a contrast curve is given)."""
+    if molusc_file is not None:
+        return np.zeros(N)
+    fn = lnprior_bound_TP if kind == "TP" else lnprior_bound_EB
+    if contrast_curve_file is None:
+        delta_mags = 2.5 * np.log10(fr_tess)
+        seps, cons = np.array([2.2]), np.array([1.0])
+    else:
+        delta_mags = 2.5 * np.log10(fr_cc_fn())
+        seps, cons = file_to_contrast_curve(contrast_curve_file)
+    return _clip_prior(fn(M_s, plx, np.abs(delta_mags), seps, cons), delta_mags)
+
+
+class _Field:
+    """TRILEGAL background population fainter than the target
+    (marginal_likelihoods.py:1451-1461, 1887-1898, 2092-2106)"""
+
+    def __init__(self, trilegal_fname, Tmag, Jmag, Hmag, Kmag):
+        (self.Tmags, self.masses, self.loggs, self.Teffs, self.Zs, self.Jmags, self.Hmags,
+         self.Kmags) = trilegal_results(trilegal_fname, Tmag)
+        self.dT = Tmag - self.Tmags
+        self.dJ = Jmag - self.Jmags
+        self.dH = Hmag - self.Hmags
+        self.dK = Kmag - self.Kmags
+        self.fluxratios = 10 ** (self.dT / 2.5) / (1 + 10 ** (self.dT / 2.5))
+        self.N_comp = self.Tmags.shape[0]
+
+    def radii(self):
+        return np.sqrt(G * self.masses * Msun / 10 ** self.loggs) / Rsun
+
+    def band_delta(self, filt):
+        return {"J": self.dJ, "H": self.dH, "K": self.dK}.get(filt, self.dT)
+
+    def band_fluxratio(self, filt):
+        d = self.band_delta(filt)
+        return 10 ** (d / 2.5) / (1 + 10 ** (d / 2.5))
+
+    def prior(self, N, idxs, contrast_curve_file, filt, fr_term=None, fr_term_cc=None):
+        """lnprior_companion of the D and B scenarios (marginal_likelihoods.py:1465-1492,
+        2161-2208).  fr_term / fr_term_cc: total flux terms (BEB adds the EB's share)."""
+        if contrast_curve_file is None:
+            if fr_term is None:
+                fr_term = self.fluxratios[idxs] / (1 - self.fluxratios[idxs])
+            delta_mags = 2.5 * np.log10(fr_term)
+            lnprior = np.full(N, np.log((self.N_comp / 0.1) * (1 / 3600) ** 2 * 2.2 ** 2))
+        else:
+            if fr_term_cc is None:
+                delta_mags = self.band_delta(filt)[idxs]
+            else:
+                delta_mags = 2.5 * np.log10(fr_term_cc)
+            seps, cons = file_to_contrast_curve(contrast_curve_file)
+            lnprior = lnprior_background(self.N_comp, np.abs(delta_mags), seps, cons)
+        return _clip_prior(lnprior, delta_mags)
+
+
+def _evidence(model, is_host, parallel, time, flux, sigma, cols, mask, lnprior, N, exptime,
+              nsamples):
+    """GPU part of a scenario branch: chi^2/2 of the masked draws and log-mean-exp over N.
+    Returns (lnL over all N draws, lnZ)."""
+    lnsigma = np.log(sigma)
+    idx = np.flatnonzero(mask)
+    block = np.empty((len(cols), idx.size), dtype=np.float64)
+    for i, c in enumerate(cols):
+        block[i] = c[idx] if isinstance(c, np.ndarray) else c
+    flags = (FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if parallel else FLAG_SCALAR_K)
+    lp = None if lnprior is None else _lib.dev(lnprior[idx])
+    h, lnz = _lib.lnz_scenario(model, flags, _lib.dev(time), _lib.dev(flux), sigma,
+                               _lib.dev(block), exptime, nsamples, lp, N, lnsigma)
+    lnL = np.full(N, -np.inf)
+    lnL[idx] = -0.5 * ln2pi - lnsigma - h.cpu().numpy()
+    return lnL, float(lnz.cpu()[0])
+
+
+def _table(lnL, lnZ, **cols):
+    """best-N_BEST table, by decreasing lnL (marginal_likelihoods.py:152-171)"""
+    idx = (-lnL).argsort()[:N_BEST]
+    res = {}
+    for key in ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
+                "R_EB", "fluxratio_EB", "fluxratio_comp"):
+        v = cols[key]
+        if isinstance(v, np.ndarray):
+            res[key] = v[idx]
+        else:
+            res[key] = np.zeros(N_BEST) if v is None else np.full(N_BEST, v)
+    res["lnZ"] = lnZ
+    return res
+
+
+def _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs, eccs,
+                   argps, a, M_host, R_host, u1, u2, fr_comp, is_host, extra, lnprior):
+    """common tail of the five *TP scenarios"""
+    size = rps * Rearth + R_host * Rsun
+    Ptra = size / a * _e_corr(eccs, argps)
+    b = _impact(a, eccs, argps, incs, R_host)
+    coll = size > a * (1 - eccs)
+    mask = _transits(Ptra, incs, parallel) & (coll == False)  # noqa: E712
+    if extra is not None:
+        mask = mask & extra
+    a_col = a if isinstance(a, np.ndarray) else np.full(N, a)
+    cols = (rps, P_orb, incs, a_col, R_host, u1, u2, eccs, argps,
+            0.0 if fr_comp is None else fr_comp)
+    lnL, lnZ = _evidence(MODEL_TP, is_host, parallel, time, flux, sigma, cols, mask, lnprior, N,
+                         exptime, nsamples)
+    return _table(lnL, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=P_orb, inc=incs, b=b,
+                  R_p=rps, ecc=eccs, argp=argps, M_EB=None, R_EB=None, fluxratio_EB=None,
+                  fluxratio_comp=fr_comp)
+
+
+def _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs, eccs,
+                     argps, masses, radii, fluxratios, M_host, R_host, u1, u2, fr_comp, is_host,
+                     extra, lnprior):
+    """common tail of the five *EB scenarios: q < 0.95 at P_orb and q >= 0.95 at 2 P_orb"""
+    e_corr = _e_corr(eccs, argps)
+    a = _sma(M_host + masses, P_orb)
+    size = radii * Rsun + R_host * Rsun
+    Ptra = size / a * e_corr
+    a_twin = _sma(M_host + masses, 2 * P_orb)
+    Ptra_twin = size / a_twin * e_corr
+    b = _impact(a, eccs, argps, incs, R_host)
+    b_twin = _impact(a_twin, eccs, argps, incs, R_host)
+    coll = size > a * (1 - eccs)
+    coll_twin = (2 * R_host * Rsun) > a_twin * (1 - eccs)
+
+    hit = _transits(Ptra, incs, parallel)
+    hit_twin = _transits(Ptra_twin, incs, parallel)
+    if not parallel:
+        hit_twin = hit_twin & (Ptra <= 1)   # the serial loop `continue`s before the twin test
+    mask = hit & (coll == False) & (qs < 0.95)  # noqa: E712
+    mask_twin = hit_twin & (coll_twin == False) & (qs >= 0.95)  # noqa: E712
+    if extra is not None:
+        mask, mask_twin = mask & extra, mask_twin & extra
+    frc = 0.0 if fr_comp is None else fr_comp
+    out = []
+    for model, m, per, sma, bb in ((MODEL_EB, mask, P_orb, a, b),
+                                   (MODEL_EB_TWIN, mask_twin, 2 * P_orb, a_twin, b_twin)):
+        cols = (radii, fluxratios, per, incs, sma, R_host, u1, u2, eccs, argps, frc)
+        lnL, lnZ = _evidence(model, is_host, parallel, time, flux, sigma, cols, m, lnprior, N,
+                             exptime, nsamples)
+        out.append(_table(lnL, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=per, inc=incs,
+                          b=bb, R_p=None, ecc=eccs, argp=argps, M_EB=masses, R_EB=radii,
+                          fluxratio_EB=fluxratios, fluxratio_comp=fr_comp))
+    return out[0], out[1]
+
+
+def _draw_planet(N, M_for_rp, P_orb, flatpriors):
+    rps = sample_rp(np.random.rand(N), M_for_rp, flatpriors)
+    incs = sample_inc(np.random.rand(N))
+    eccs = sample_ecc(np.random.rand(N), planet=True, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    return rps, incs, eccs, argps
+
+
+# ---------------------------------------------------------------------------------------
+# target-star scenarios
+def lnZ_TTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N: int = 1000000, parallel: bool = False,
+            mission: str = "TESS", flatpriors: bool = False, exptime: float = 0.00139,
+            nsamples: int = 20):
+    """Transiting planet on the target star (also the NTP scenario of a nearby star)."""
+    P_orb = _periods(P_orb, N)
+    a = _sma(M_s, P_orb)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    rps, incs, eccs, argps = _draw_planet(N, np.full(N, M_s), P_orb, flatpriors)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_s, R_s, u1, u2, None, False, None, None)
+
+
+def lnZ_TEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N: int = 1000000, parallel: bool = False,
+            mission: str = "TESS", flatpriors: bool = False, exptime: float = 0.00139,
+            nsamples: int = 20):
+    """Eclipsing binary on the target star (also NEB / NEBx2P of a nearby star)."""
+    P_orb = _periods(P_orb, N)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), M_s)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    masses = qs * M_s
+    radii, _ = stellar_relations(masses, np.full(N, R_s), np.full(N, Teff))
+    fluxratios = _flux_share(masses, M_s)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_s, R_s, u1, u2, None, False,
+                            None, None)
+
+
+def lnZ_PTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file: str = None,
+            filt: str = "TESS", N: int = 1000000, parallel: bool = False, mission: str = "TESS",
+            flatpriors: bool = False, exptime: float = 0.00139, nsamples: int = 20,
+            molusc_file: str = None):
+    """Planet on the target, diluted by an unresolved bound companion."""
+    P_orb = _periods(P_orb, N)
+    a = _sma(M_s, P_orb)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    qs_comp = _bound_companions(M_s, N, molusc_file)
+    masses_comp = qs_comp * M_s
+    fr_comp = _flux_share(masses_comp, M_s)
+    lnprior = _bound_prior("TP", M_s, plx, N, molusc_file, contrast_curve_file,
+                           fr_comp / (1 - fr_comp),
+                           lambda: (lambda f: f / (1 - f))(_flux_share(masses_comp, M_s, filt)))
+    rps, incs, eccs, argps = _draw_planet(N, np.full(N, M_s), P_orb, flatpriors)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_s, R_s, u1, u2, fr_comp, False, qs_comp != 0.0, lnprior)
+
+
+def lnZ_PEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file: str = None,
+            filt: str = "TESS", N: int = 1000000, parallel: bool = False, mission: str = "TESS",
+            flatpriors: bool = False, exptime: float = 0.00139, nsamples: int = 20,
+            molusc_file: str = None):
+    """EB on the target, diluted by an unresolved bound companion."""
+    P_orb = _periods(P_orb, N)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), M_s)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    qs_comp = _bound_companions(M_s, N, molusc_file)
+    masses = qs * M_s
+    radii, _ = stellar_relations(masses, np.full(N, R_s), np.full(N, Teff))
+    fluxratios = _flux_share(masses, M_s)
+    masses_comp = qs_comp * M_s
+    fr_comp = _flux_share(masses_comp, M_s)
+    lnprior = _bound_prior("EB", M_s, plx, N, molusc_file, contrast_curve_file,
+                           fr_comp / (1 - fr_comp),
+                           lambda: (lambda f: f / (1 - f))(_flux_share(masses_comp, M_s, filt)))
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_s, R_s, u1, u2, fr_comp,
+                            False, qs_comp != 0.0, lnprior)
+
+
+def _companion_host(M_s, R_s, Teff, Z, N, mission, molusc_file, teff_cap):
+    """properties of an unresolved bound companion acting as the host (S scenarios)"""
+    qs_comp = _bound_companions(M_s, N, molusc_file)
+    masses_comp = qs_comp * M_s
+    radii_comp, Teffs_comp = stellar_relations(masses_comp, np.full(N, R_s), np.full(N, Teff))
+    loggs_comp = _logg(masses_comp, radii_comp)
+    fr_comp = _flux_share(masses_comp, M_s)
+    u1s, u2s = _ldc(mission).companions(Z, Teffs_comp, loggs_comp, teff_cap)
+    return qs_comp, masses_comp, radii_comp, Teffs_comp, fr_comp, u1s, u2s
+
+
+def lnZ_STP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file: str = None,
+            filt: str = "TESS", N: int = 1000000, parallel: bool = False, mission: str = "TESS",
+            flatpriors: bool = False, exptime: float = 0.00139, nsamples: int = 20,
+            molusc_file: str = None):
+    """Planet on an unresolved bound companion of the target."""
+    P_orb = _periods(P_orb, N)
+    qs_comp, masses_comp, radii_comp, _, fr_comp, u1s, u2s = _companion_host(
+        M_s, R_s, Teff, Z, N, mission, molusc_file, 10000)
+    lnprior = _bound_prior("TP", M_s, plx, N, molusc_file, contrast_curve_file,
+                           fr_comp / (1 - fr_comp),
+                           lambda: (lambda f: f / (1 - f))(_flux_share(masses_comp, M_s, filt)))
+    rps, incs, eccs, argps = _draw_planet(N, masses_comp, P_orb, flatpriors)
+    a = _sma(masses_comp, P_orb)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, masses_comp, radii_comp, u1s, u2s, fr_comp, True,
+                          qs_comp != 0.0, lnprior)
+
+
+def lnZ_SEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file: str = None,
+            filt: str = "TESS", N: int = 1000000, parallel: bool = False, mission: str = "TESS",
+            flatpriors: bool = False, exptime: float = 0.00139, nsamples: int = 20,
+            molusc_file: str = None):
+    """EB on an unresolved bound companion of the target."""
+    P_orb = _periods(P_orb, N)
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), M_s)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    qs_comp, masses_comp, radii_comp, Teffs_comp, fr_comp, u1s, u2s = _companion_host(
+        M_s, R_s, Teff, Z, N, mission, molusc_file, 13000)
+    masses = qs * masses_comp
+    radii, _ = stellar_relations(masses, radii_comp, Teffs_comp)
+    fluxratios = _flux_share(masses, M_s)
+
+    def cc_term():
+        f_eb, f_c = _flux_share(masses, M_s, filt), _flux_share(masses_comp, M_s, filt)
+        return (f_c / (1 - f_c)) + (f_eb / (1 - f_eb))
+
+    lnprior = _bound_prior("EB", M_s, plx, N, molusc_file, contrast_curve_file,
+                           (fr_comp / (1 - fr_comp)) + (fluxratios / (1 - fluxratios)), cc_term)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, masses_comp, radii_comp, u1s,
+                            u2s, fr_comp, True, qs_comp != 0.0, lnprior)
+
+
+# ---------------------------------------------------------------------------------------
+# chance-aligned field stars (TRILEGAL population)
+def lnZ_DTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file: str = None, filt: str = "TESS", N: int = 1000000,
+            parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+            exptime: float = 0.00139, nsamples: int = 20):
+    """Planet on the target, diluted by an unresolved background star."""
+    P_orb = _periods(P_orb, N)
+    a = _sma(M_s, P_orb)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    field = _Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
+    idxs = np.random.randint(0, field.N_comp - 1, N)   # sic: the last star is never drawn
+    lnprior = field.prior(N, idxs, contrast_curve_file, filt)
+    rps, incs, eccs, argps = _draw_planet(N, np.full(N, M_s), P_orb, flatpriors)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_s, R_s, u1, u2, field.fluxratios[idxs], False, None,
+                          lnprior)
+
+
+def lnZ_DEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file: str = None, filt: str = "TESS", N: int = 1000000,
+            parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+            exptime: float = 0.00139, nsamples: int = 20):
+    """EB on the target, diluted by an unresolved background star."""
+    P_orb = _periods(P_orb, N)
+    u1, u2 = _ldc(mission).star(Z, Teff, _logg(M_s, R_s))
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), M_s)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    masses = qs * M_s
+    radii, _ = stellar_relations(masses, np.full(N, R_s), np.full(N, Teff))
+    fluxratios = _flux_share(masses, M_s)
+    field = _Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
+    idxs = np.random.randint(0, field.N_comp - 1, N)
+    lnprior = field.prior(N, idxs, contrast_curve_file, filt)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_s, R_s, u1, u2,
+                            field.fluxratios[idxs], False, None, lnprior)
+
+
+def lnZ_BTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file: str = None, filt: str = "TESS", N: int = 1000000,
+            parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+            exptime: float = 0.00139, nsamples: int = 20):
+    """Planet on an unresolved background star."""
+    P_orb = _periods(P_orb, N)
+    field = _Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
+    radii_f = field.radii()
+    u1f, u2f = _ldc(mission).field_stars(field.Teffs, field.loggs, field.Zs)
+    idxs = np.random.randint(0, field.N_comp, N)
+    lnprior = field.prior(N, idxs, contrast_curve_file, filt)
+    M_host, R_host = field.masses[idxs], radii_f[idxs]
+    rps, incs, eccs, argps = _draw_planet(N, M_host, P_orb, flatpriors)
+    a = _sma(M_host, P_orb)
+    extra = (field.loggs[idxs] >= 3.5) & (field.Teffs[idxs] <= 10000)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_host, R_host, u1f[idxs], u2f[idxs],
+                          field.fluxratios[idxs], True, extra, lnprior)
+
+
+def lnZ_BEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file: str = None, filt: str = "TESS", N: int = 1000000,
+            parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+            exptime: float = 0.00139, nsamples: int = 20):
+    """EB on an unresolved background star."""
+    P_orb = _periods(P_orb, N)
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), M_s)
+    sample_q_companion(np.random.rand(N), M_s)   # drawn and unused in the reference (:2089)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    field = _Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
+    radii_f = field.radii()
+    u1f, u2f = _ldc(mission).field_stars(field.Teffs, field.loggs, field.Zs)
+    idxs = np.random.randint(0, field.N_comp, N)
+    M_host, R_host = field.masses[idxs], radii_f[idxs]
+    masses = qs * M_host
+    radii, _ = stellar_relations(masses, R_host, field.Teffs[idxs])
+    fr_comp = field.fluxratios[idxs]
+    # the background star sits at another distance: rescale the bound-pair flux share
+    fluxratios = _flux_share(masses, M_s) * (fr_comp / _flux_share(M_host, M_s))
+    fr_term = (fr_comp / (1 - fr_comp)) + (fluxratios / (1 - fluxratios))
+    fr_term_cc = None
+    if contrast_curve_file is not None:
+        fr_comp_cc = field.band_fluxratio(filt)[idxs]
+        fluxratios_cc = _flux_share(masses, M_s, filt) * (fr_comp_cc / _flux_share(M_host, M_s, filt))
+        fr_term_cc = (fr_comp_cc / (1 - fr_comp_cc)) + (fluxratios_cc / (1 - fluxratios_cc))
+    lnprior = field.prior(N, idxs, contrast_curve_file, filt, fr_term, fr_term_cc)
+    extra = (field.loggs[idxs] >= 3.5) & (field.Teffs[idxs] <= 10000)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_host, R_host, u1f[idxs],
+                            u2f[idxs], fr_comp, True, extra, lnprior)

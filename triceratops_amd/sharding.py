@@ -1,0 +1,123 @@
+"""Scenario-level sharding of calc_probs over the GPUs of one node.
+
+The reference runs its (star, lnZ_* call) units strictly one after the other in one Python
+thread (triceratops.py:736-1428).  The units are independent given the light curve, so here
+they are dealt to the ranks of a torch.distributed job (one process per GPU; backend "nccl" is
+RCCL over xGMI) with a longest-processing-time-first schedule, every rank evaluates its own
+units on its own GPU, and ONE all_gather of a small fp64 record table (15 numbers per
+scenario: the best-fit row + lnZ) assembles the result on every rank.  No other collective is
+on the data path; the message is a few KB, i.e. latency-bound, so a single direct all_gather
+is the right primitive (no ring, no bucketing).
+
+Random numbers: the lnZ_* functions draw from the global numpy stream like the reference.
+  world == 1  the stream is consumed sequentially, unit after unit -- identical to the reference
+              under the same np.random.seed (unless per_unit_seed is set);
+  world  > 1  each unit reseeds the stream from (base, unit index), base being one draw of rank
+              0's stream broadcast to all ranks, so the result does not depend on the partition
+              or on the world size (per_unit_seed=True gives the same numbers on one GPU).
+"""
+import numpy as np
+
+RECORD_COLS = ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
+               "R_EB", "fluxratio_EB", "fluxratio_comp", "lnZ")
+per_unit_seed = False
+
+# relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
+# secondary-eclipse scan; companion/background hosts add per-draw stellar relations
+_COST = {"TP": 1.0, "PTP": 1.1, "STP": 1.2, "DTP": 1.1, "BTP": 1.2, "NTP": 1.0,
+         "EB": 1.7, "PEB": 1.8, "SEB": 1.9, "DEB": 1.8, "BEB": 1.9, "NEB": 1.7}
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def schedule(costs, world):
+    """Longest-processing-time-first assignment.  Returns owner[k] for every unit; ties are
+    broken by unit index and rank index so that every rank computes the same table."""
+    order = sorted(range(len(costs)), key=lambda k: (-costs[k], k))
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for k in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        owner[k] = r
+        load[r] += costs[k]
+    return owner
+
+
+def _record(res):
+    """(res,) or (res, res_twin) -> (n, 15) array of the best row + lnZ of each dict"""
+    dicts = res if isinstance(res, tuple) else (res,)
+    out = np.empty((len(dicts), len(RECORD_COLS)))
+    for i, d in enumerate(dicts):
+        for j, c in enumerate(RECORD_COLS):
+            out[i, j] = d[c] if c == "lnZ" else d[c][0]
+    return out
+
+
+def _as_dicts(rec):
+    return tuple({c: rec[i, j] for j, c in enumerate(RECORD_COLS)} for i in range(rec.shape[0]))
+
+
+def run_units(units, verbose=0):
+    """Evaluate the work units of one calc_probs.
+
+    units: list of (first_row, names, star_num, ID, thunk_or_None, key).  Returns, per unit, None
+    (dropped scenario) or a tuple of per-scenario dicts {column: best value, 'lnZ': float}."""
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    live = [k for k, u in enumerate(units) if u[4] is not None]
+    owner = {k: 0 for k in live}
+    base = None
+    if dist:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        b = torch.zeros(1, dtype=torch.int64, device=dev)
+        if rank == 0:
+            b[0] = int(np.random.randint(0, 2 ** 31 - 1))
+        dist.broadcast(b, src=0)
+        base = int(b[0])
+        own = schedule([_COST.get(units[k][5], 1.0) for k in live], world)
+        owner = {k: own[i] for i, k in enumerate(live)}
+    elif per_unit_seed:
+        base = int(np.random.randint(0, 2 ** 31 - 1))
+
+    rows = {k: len(units[k][1]) for k in live}
+    offs, total = {}, 0
+    for k in live:
+        offs[k] = total
+        total += rows[k]
+    table = np.full((total, len(RECORD_COLS)), np.nan)
+    for k in live:
+        if owner[k] != rank:
+            continue
+        j0, names, snum, ID, fn, key = units[k]
+        if verbose == 1:
+            print("Calculating " + ", ".join(names) + " scenario probabilit"
+                  + ("y" if len(names) == 1 else "ies") + " for " + str(ID)
+                  + (" [rank %d]" % rank if dist else "") + ".")
+        if base is not None:
+            np.random.seed((base + 7919 * (k + 1)) % (2 ** 32))
+        table[offs[k]:offs[k] + rows[k]] = _record(fn())
+
+    if dist:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.as_tensor(table).to(dev)
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, mine)          # the single data-path collective
+        g = gathered.cpu().numpy()
+        for k in live:
+            table[offs[k]:offs[k] + rows[k]] = g[owner[k], offs[k]:offs[k] + rows[k]]
+
+    out = []
+    for k, u in enumerate(units):
+        out.append(None if u[4] is None else _as_dicts(table[offs[k]:offs[k] + rows[k]]))
+    return out

@@ -1,0 +1,237 @@
+"""`target`: the calc_probs() driver of the reference, on the MI355X kernels.
+
+Mirrors the compute half of triceratops/triceratops.py `class target`:
+  calc_depths  (triceratops.py:559-671)   aperture flux ratios and per-star transit depths
+  calc_probs   (triceratops.py:673-1485)  scenario loop, probability table, FPP / NFPP
+with the same argument lists and the same result attributes (.probs .lnZ .FPP .NFPP
+.FPP_degenerate .star_num .u1 .u2 .fluxratio_EB .fluxratio_comp).
+
+Out of scope: the catalogue / cut-out / TRILEGAL web queries of
+__init__ and the matplotlib plots.  A `target` here is built from a ready star table (and, for
+calc_depths, pixel coordinates); the TRILEGAL population is a local csv (`trilegal_fname`).
+
+With torch.distributed initialised (one process per GPU, RCCL) calc_probs shards the
+(star, lnZ_* call) units over the ranks and finishes with ONE all_gather of the per-scenario
+results; see triceratops_amd/sharding.py.
+"""
+import warnings
+
+import numpy as np
+from pandas import DataFrame
+from scipy.special import ndtr
+
+from ._numerics import _normalize_probabilities
+from .funcs import renorm_flux
+from .marginal_likelihoods import *  # noqa: F401,F403  (reference re-exports the lnZ_* names)
+from .marginal_likelihoods import (lnZ_BEB, lnZ_BTP, lnZ_DEB, lnZ_DTP, lnZ_PEB, lnZ_PTP, lnZ_SEB,
+                                   lnZ_STP, lnZ_TEB, lnZ_TTP)
+from . import sharding
+
+_COLS = ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB", "R_EB",
+         "fluxratio_EB", "fluxratio_comp")
+
+# (drop key, scenario names, first row index, star_num) of the nine target-star calls, in the
+# reference's order (triceratops.py:784-1340)
+_TARGET_CALLS = (
+    ("TP", ("TP",), 0, 1), ("EB", ("EB", "EBx2P"), 1, 1),
+    ("PTP", ("PTP",), 3, 1), ("PEB", ("PEB", "PEBx2P"), 4, 1),
+    ("STP", ("STP",), 6, 2), ("SEB", ("SEB", "SEBx2P"), 7, 2),
+    ("DTP", ("DTP",), 9, 1), ("DEB", ("DEB", "DEBx2P"), 10, 1),
+    ("BTP", ("BTP",), 12, 2), ("BEB", ("BEB", "BEBx2P"), 13, 2),
+)
+
+
+class target:
+    def __init__(self, ID: int, sectors=None, search_radius: int = 10, mission: str = "TESS",
+                 lightkurve_cache_dir=None, trilegal_fname=None, ra: float = None,
+                 dec: float = None, verify_ssl: bool = True, stars: DataFrame = None,
+                 pix_coords=None):
+        """ID, sectors, search_radius, mission, trilegal_fname as in the reference; `stars` is the
+        table the reference builds from the TIC (columns ID Tmag Jmag Hmag Kmag ra dec mass rad
+        Teff plx [sep PA fluxratio tdepth]); `pix_coords` the per-sector pixel positions of those
+        stars (list of (n_stars, 2) arrays), needed by calc_depths only."""
+        if mission != "TESS" and mission != "Kepler" and mission != "K2":
+            raise ValueError("Introduced invalid mission: " + mission)
+        if stars is None:
+            raise NotImplementedError(
+                "triceratops_amd.target needs a ready `stars` table: the MAST/TIC/TessCut/TRILEGAL "
+                "queries of the reference constructor are outside the accelerated path")
+        self.ID = ID
+        self.mission = mission
+        self.sectors = sectors
+        self.search_radius = search_radius
+        self.N_pix = 2 * search_radius + 2
+        self.trilegal_fname = trilegal_fname
+        self.trilegal_url = None
+        self.stars = stars.reset_index(drop=True)
+        self.pix_coords = pix_coords
+
+    # -----------------------------------------------------------------------------------
+    def calc_depths(self, tdepth: float, all_ap_pixels=None):
+        """Flux share of every star in the extraction apertures (circular Gaussian PSF,
+        sigma = 0.75 px, closed-form pixel integrals) and the transit depth each star would
+        need to produce the observed depth `tdepth` (fractional, like the reference)."""
+        if self.pix_coords is None:
+            raise ValueError("calc_depths needs pix_coords")
+        if all_ap_pixels is None:
+            print("No apertures provided, assuming 5x5 centered on target.")
+            all_ap_pixels = []
+            for coords in self.pix_coords:
+                c = np.round(coords[0])
+                xs = np.arange(c[0] - 2, c[0] + 3, 1)
+                ys = np.arange(c[1] - 2, c[1] + 3, 1)
+                all_ap_pixels.append(np.array([np.repeat(xs, 5), np.tile(ys, 5)]).T)
+        sigma = 0.75
+        Tmag = self.stars.Tmag.values
+        amp = 10 ** ((np.min(Tmag) - Tmag) / 2.5)
+        ratios = np.zeros([len(all_ap_pixels), len(self.stars)])
+        for k, ap in enumerate(all_ap_pixels):
+            px = np.array(ap)
+            mu = np.asarray(self.pix_coords[k])
+            wx = (ndtr((px[:, None, 0] + 0.5 - mu[None, :, 0]) / sigma)
+                  - ndtr((px[:, None, 0] - 0.5 - mu[None, :, 0]) / sigma))
+            wy = (ndtr((px[:, None, 1] + 0.5 - mu[None, :, 1]) / sigma)
+                  - ndtr((px[:, None, 1] - 0.5 - mu[None, :, 1]) / sigma))
+            rel = amp * np.sum(wx * wy, axis=0)
+            ratios[k, :] = rel / np.sum(rel)
+        flux_ratios = np.mean(ratios, axis=0)
+        self.stars["fluxratio"] = flux_ratios
+        tdepths = np.zeros(len(self.stars))
+        nz = flux_ratios != 0
+        tdepths[nz] = 1 - (flux_ratios[nz] - tdepth) / flux_ratios[nz]
+        tdepths[tdepths > 1] = 0
+        self.stars["tdepth"] = tdepths
+        filtered = self.stars[self.stars["tdepth"] > 0]
+        for i, ID in enumerate(filtered["ID"].values):
+            vals = [filtered[c].values[i] for c in ("mass", "rad", "Teff")]
+            if i == 0:
+                vals.append(filtered["plx"].values[i])
+            if np.any(np.isnan(np.array(vals, dtype=float))):
+                print("WARNING: " + str(ID) + " is missing stellar properties"
+                      + (" required for validation." if i == 0
+                         else ". Solar values will be assumed."))
+        return
+
+    # -----------------------------------------------------------------------------------
+    def _units(self, filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file, filt, N,
+               parallel, drop_scenario, flatpriors, exptime, nsamples, molusc_file):
+        """The independent (star, lnZ_* call) work units of one calc_probs, in the reference's
+        order.  Each unit = (first row, scenario names, star_num, ID, thunk or None)."""
+        units = []
+        ok = True
+        for i, ID in enumerate(filtered["ID"].values):
+            row = {c: filtered[c].values[i] for c in ("fluxratio", "mass", "rad", "Teff", "Tmag",
+                                                      "Jmag", "Hmag", "Kmag", "plx")}
+            flux, flux_err = renorm_flux(flux_0, flux_err_0, row["fluxratio"])
+            M_s, R_s, Teff, plx, Z = row["mass"], row["rad"], row["Teff"], row["plx"], 0.0
+            mags = (row["Tmag"], row["Jmag"], row["Hmag"], row["Kmag"])
+            tail = (N, parallel, self.mission, flatpriors, exptime, nsamples)
+            if i == 0:
+                if np.isnan(M_s) or np.isnan(R_s) or np.isnan(Teff) or np.isnan(plx):
+                    print("Insufficient information to validate " + str(ID)
+                          + ". Please ensure a stellar mass (in M_Sun), radius (in R_Sun), Teff "
+                          + "(in K), and plx (in mas) are provided in the .stars dataframe.")
+                    ok = False
+                    break
+                base = (time, flux, flux_err, P_orb, M_s, R_s, Teff)
+                bound = (plx, contrast_curve_file, filt) + tail + (molusc_file,)
+                field = mags + (self.trilegal_fname, contrast_curve_file, filt) + tail
+                calls = {
+                    "TP": lambda b=base: lnZ_TTP(*b, Z, *tail),
+                    "EB": lambda b=base: lnZ_TEB(*b, Z, *tail),
+                    "PTP": lambda b=base: lnZ_PTP(*b, Z, *bound),
+                    "PEB": lambda b=base: lnZ_PEB(*b, Z, *bound),
+                    "STP": lambda b=base: lnZ_STP(*b, Z, *bound),
+                    "SEB": lambda b=base: lnZ_SEB(*b, Z, *bound),
+                    "DTP": lambda b=base: lnZ_DTP(*b, Z, *field),
+                    "DEB": lambda b=base: lnZ_DEB(*b, Z, *field),
+                    "BTP": lambda b=base: lnZ_BTP(*b, *field),
+                    "BEB": lambda b=base: lnZ_BEB(*b, *field),
+                }
+                for key, names, j0, snum in _TARGET_CALLS:
+                    fn = None if key in drop_scenario else calls[key]
+                    units.append((j0, names, snum, ID, fn, key))
+            else:
+                # nearby star: unknown properties default to solar values
+                Teff = 5777 if np.isnan(Teff) else Teff
+                M_s = 1.0 if np.isnan(M_s) else M_s
+                R_s = 1.0 if np.isnan(R_s) else R_s
+                base = (time, flux, flux_err, P_orb, M_s, R_s, Teff, Z) + tail
+                j0 = 15 + 3 * (i - 1)
+                units.append((j0, ("NTP",), 1, ID, lambda b=base: lnZ_TTP(*b), "NTP"))
+                units.append((j0 + 1, ("NEB", "NEBx2P"), 1, ID, lambda b=base: lnZ_TEB(*b), "NEB"))
+        return units, ok
+
+    def calc_probs(self, time, flux_0, flux_err_0: float, P_orb, contrast_curve_file: str = None,
+                   filt: str = "TESS", N: int = 1000000, parallel: bool = False,
+                   drop_scenario: list = [], verbose: int = 1, flatpriors: bool = False,
+                   exptime: float = 0.00139, nsamples: int = 20, molusc_file: str = None):
+        """Relative probability of every scenario, FPP and NFPP (same arguments as the reference).
+
+        `parallel` selects the reference's vector-path or per-draw-loop semantics (App. C of
+        SURVEY.md); both run on the GPU."""
+        time = np.asarray(time, dtype=np.float64)
+        flux_0 = np.asarray(flux_0, dtype=np.float64)
+        keep = ~np.isnan(time) & ~np.isnan(flux_0)
+        time, flux_0 = time[keep], flux_0[keep]
+        filtered = self.stars[self.stars["tdepth"] > 0]
+        n_scen = 3 * len(filtered) + 12
+        targets = np.zeros(n_scen, dtype=np.dtype("i8"))
+        star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
+        scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
+        best = {c: np.zeros(n_scen) for c in _COLS}
+        lnZ = np.zeros(n_scen)
+        needs_field = not all(k in drop_scenario for k in ("DTP", "DEB", "BTP", "BEB"))
+        if self.trilegal_fname is None and needs_field:
+            raise ValueError("trilegal_fname is required for the D and B scenarios (the TRILEGAL "
+                             "web query is outside the accelerated path); pass it to target(...) "
+                             "or drop DTP, DEB, BTP and BEB")
+
+        units, _ok = self._units(filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file,
+                                 filt, N, parallel, drop_scenario, flatpriors, exptime, nsamples,
+                                 molusc_file)
+        results = sharding.run_units(units, verbose=verbose)
+        for (j0, names, snum, ID, fn, key), res in zip(units, results):
+            for off, name in enumerate(names):
+                j = j0 + off
+                targets[j], star_num[j], scenarios[j] = ID, snum, name
+                if res is None:
+                    lnZ[j] = -np.inf
+                    continue
+                r = res[off]
+                for c in _COLS:
+                    best[c][j] = r[c]
+                lnZ[j] = r["lnZ"]
+
+        relative_probs, status = _normalize_probabilities(lnZ)
+        if status == 'anomaly':
+            warnings.warn(
+                "Unexpected NaN or +inf in scenario log-evidences. This indicates a numerical "
+                "anomaly unrelated to geometric exclusions. Inspect self.lnZ for diagnostics.",
+                RuntimeWarning, stacklevel=2)
+            self.FPP_degenerate = True
+        elif status == 'all_neginf':
+            warnings.warn(
+                "All scenario log-evidences are -inf: every MC draw was geometrically invalid. "
+                "FPP=1.0 reflects a failed computation, not a confident false positive. "
+                "Inspect self.lnZ for diagnostics.",
+                RuntimeWarning, stacklevel=2)
+            self.FPP_degenerate = True
+        else:
+            self.FPP_degenerate = False
+
+        self.probs = DataFrame({
+            "ID": targets, "scenario": scenarios, "M_s": best["M_s"], "R_s": best["R_s"],
+            "P_orb": best["P_orb"], "inc": best["inc"], "b": best["b"], "ecc": best["ecc"],
+            "w": best["argp"], "R_p": best["R_p"], "M_EB": best["M_EB"], "R_EB": best["R_EB"],
+            "prob": relative_probs})
+        self.lnZ = lnZ
+        self.star_num = star_num
+        self.u1 = best["u1"]
+        self.u2 = best["u2"]
+        self.fluxratio_EB = best["fluxratio_EB"]
+        self.fluxratio_comp = best["fluxratio_comp"]
+        prob = self.probs.prob
+        self.FPP = 1 - (prob[0] + prob[3] + prob[9])
+        self.NFPP = np.sum(prob[15:]) if len(prob) > 15 else 0.0
+        return
