@@ -1,0 +1,182 @@
+"""GPU parity against the golden vectors made from the imported reference
+(tests/golden/make_golden.py) and end-to-end against the CPU oracle.
+
+Tolerances (fp64): chi^2/2 relative 1e-9; lnZ absolute 1e-9; FPP / NFPP absolute 1e-9;
+probabilities absolute 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from helpers import GOLD, gold, install_cpu_device_fakes
+from oracle import oracle as O
+from triceratops_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+G = gold("lnz_cases.npz")
+CASES = [str(c) for c in G["cases"]]
+MODEL = {"lnL_TP_p": _lib.MODEL_TP, "lnL_EB_p": _lib.MODEL_EB, "lnL_EB_twin_p": _lib.MODEL_EB_TWIN}
+
+
+def test_kernels_on_the_reference_s_own_blocks():
+    t_d, f_d, sigma = _lib.dev(G["time"]), _lib.dev(G["flux"]), float(G["sigma"][0])
+    n = 0
+    for case in CASES:
+        i = 0
+        while "%s_call%d_name" % (case, i) in G.files:
+            block = G["%s_call%d_block" % (case, i)]
+            want = G["%s_call%d_out" % (case, i)]
+            name = str(G["%s_call%d_name" % (case, i)][0])
+            flags = _lib.FLAG_COMPANION_IS_HOST if bool(G["%s_call%d_is_host" % (case, i)][0]) else 0
+            i += 1
+            if block.shape[1] == 0:
+                continue
+            got = _lib.lnl_batch(MODEL[name], flags, t_d, f_d, sigma, _lib.dev(block), 0.00139, 20).cpu().numpy()
+            assert np.array_equal(np.isposinf(got), np.isposinf(want)), (case, i)
+            fin = np.isfinite(want)
+            assert np.allclose(got[fin], want[fin], rtol=1e-9, atol=0), (case, i)
+            n += int(fin.sum())
+    assert n > 2000
+
+
+def _call(ml, name, P, N, parallel, cc, filt):
+    s = dict(zip(("M_s", "R_s", "Teff", "Z", "plx", "Tmag", "Jmag", "Hmag", "Kmag"), (float(v) for v in G["star"])))
+    base = (G["time"], G["flux"], float(G["sigma"][0]), P, s["M_s"], s["R_s"], s["Teff"])
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    fn = getattr(ml, "lnZ_" + name)
+    if name in ("TTP", "TEB"):
+        return fn(*base, 0.0, N, parallel)
+    if name in ("PTP", "PEB", "STP", "SEB"):
+        return fn(*base, 0.0, s["plx"], cc, filt, N, parallel)
+    mags = (s["Tmag"], s["Jmag"], s["Hmag"], s["Kmag"])
+    if name in ("DTP", "DEB"):
+        return fn(*base, 0.0, *mags, tri, cc, filt, N, parallel)
+    return fn(*base, *mags, tri, cc, filt, N, parallel)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lnz_functions_end_to_end(case):
+    from triceratops_amd import marginal_likelihoods as ml
+    name, variant = case.split("_")
+    P = [2.5, 4.0] if variant == "range" else 3.3
+    cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
+    parallel = variant != "serial"
+    np.random.seed(int(G[case + "_seed"][0]))
+    res = _call(ml, name, P, int(G["N"][0]) if parallel else 300, parallel, cc, "J" if cc else "TESS")
+    dicts = res if isinstance(res, tuple) else (res,)
+    for i, d in enumerate(dicts):
+        want = G["%s_lnZ%d" % (case, i)][0]
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-9
+        n_fin = min(100, int(np.isfinite(G["%s_logw%d" % (case, i)]).sum()))
+        for k in ("P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB", "R_EB"):
+            assert np.allclose(d[k][:n_fin], G["%s_res%d_%s" % (case, i, k)][:n_fin], rtol=1e-12), (case, k)
+
+
+def test_toi1228_config1():
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("toi1228_ttp.npz")
+    M, R, Teff, Z = (float(v) for v in g["star"])
+    np.random.seed(int(g["seed"][0]))
+    res = ml.lnZ_TTP(g["time"], g["flux"], float(g["sigma"][0]), float(g["P_orb"][0]), M, R, Teff,
+                     Z, int(g["N"][0]), True)
+    assert abs(res["lnZ"] - g["lnZ"][0]) < 1e-9
+    assert np.allclose(res["R_p"], g["res_R_p"], rtol=1e-12)
+
+
+def test_numerics_module_on_device():
+    from triceratops_amd._numerics import _log_mean_exp
+    g = gold("numerics.npz")
+    for k in "abcdefg":
+        x, want = g["lme_in_" + k], g["lme_out_" + k][0]
+        got = _log_mean_exp(x, N_total=x.size)
+        assert (got == want) if not np.isfinite(want) else abs(got - want) < 1e-12
+        got = _log_mean_exp(_lib.dev(x), N_total=x.size)     # device tensor in, no host copy
+        assert (got == want) if not np.isfinite(want) else abs(got - want) < 1e-12
+    with pytest.raises(ValueError):
+        _log_mean_exp(np.zeros(5), N_total=4)
+
+
+def test_likelihood_module_vector_and_scalar_paths():
+    from triceratops_amd import likelihoods as lk
+    from triceratops_amd import synth
+    rng = np.random.default_rng(2)
+    t, f, sigma = G["time"], G["flux"], float(G["sigma"][0])
+    rows = synth.eb_rows(rng, 40, has_companion=True)
+    cols = [rows[i] for i in range(11)]
+    inc_before = cols[3].copy()
+    h = lk.lnL_EB_p(t, f, sigma, *cols[:10], cols[10], True)
+    assert np.array_equal(cols[3], inc_before)            # no in-place deg->rad conversion
+    want = O.lnl_batch(O.MODEL_EB, t, f, sigma, rows, companion_is_host=True)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isposinf(h), np.isposinf(want)) and np.allclose(h[fin], want[fin], rtol=1e-9)
+    grid, sec = lk.simulate_EB_transit_p(t, *cols[:10], cols[10], False)
+    wg, ws = O.flux_grid(O.MODEL_EB, t, rows)
+    assert grid.shape == (40, t.size) and sec.shape == (40, 1)
+    assert np.abs(grid - wg).max() < 5e-13 and np.abs(sec[:, 0] - ws).max() < 5e-13
+    ht = lk.lnL_EB_twin_p(t, f, sigma, *cols[:10], cols[10])
+    assert np.allclose(ht, O.lnl_batch(O.MODEL_EB_TWIN, t, f, sigma, rows), rtol=1e-9)
+    # scalar functions use the abs(k-1) rule and 1/k for the secondary
+    j = 3
+    one = [float(c[j]) for c in cols]
+    one[0] = one[5] * (1 + 2e-7)                            # R_EB within 1e-6 of R_s from above
+    v = lk.lnL_EB(t, f, sigma, *one[:10], one[10])
+    w = O.lnl_batch(O.MODEL_EB, t, f, sigma, np.array(one)[:, None], scalar_k=True)[0]
+    assert (v == w) if not np.isfinite(w) else abs(v / w - 1) < 1e-9
+    m, sd = lk.simulate_EB_transit(t, *one[:10], one[10])
+    wg, ws = O.flux_grid(O.MODEL_EB, t, np.array(one)[:, None], scalar_k=True)
+    assert np.abs(m - wg[0]).max() < 5e-13 and abs(sd - ws[0]) < 5e-13
+    tp = synth.tp_rows(rng, 5, True)
+    v = lk.lnL_TP(t, f, sigma, *[float(c[0]) for c in tp[:9]], float(tp[9][0]), True)
+    assert abs(v / O.lnl_batch(0, t, f, sigma, tp[:, :1], companion_is_host=True)[0] - 1) < 1e-9
+    assert lk.simulate_TP_transit(t, *[float(c[0]) for c in tp[:9]]).shape == t.shape
+
+
+def test_quadratic_model_seam():
+    """the pytransit.QuadraticModel call shapes the reference uses (likelihoods.py:24-25, 61-71,
+    348-349, 414-422)"""
+    from triceratops_amd.transit_model import QuadraticModel
+    tm = QuadraticModel(interpolate=False)
+    t = np.linspace(-0.2, 0.2, 91)
+    tm.set_data(t, exptimes=0.00139, nsamples=20)
+    f = tm.evaluate_ps(k=0.1, ldc=[0.4, 0.2], t0=0.0, p=3.0, a=9.0, i=1.55, e=0.1, w=0.7)
+    want = O.evaluate_pv(t, [[0.1, 0.0, 3.0, 9.0, 1.55, 0.1, 0.7]], [[0.4, 0.2]], 0.00139, 20)[0]
+    assert f.shape == t.shape and np.abs(f - want).max() < 5e-13
+    tm.set_data(np.linspace(-0.05, 0.05, 25))
+    pvp = np.array([[1.4, 0.0, 3.0, 9.0, 1.55, 0.1, 0.7 + np.pi], [0.3, 0.0, 5.0, 12.0, 1.56, 0.0, 0.1]])
+    ldc = np.array([[0.4, 0.2], [0.1, 0.3]])
+    g = tm.evaluate_pv(pvp, ldc)
+    assert g.shape == (2, 25) and np.abs(g - O.evaluate_pv(np.linspace(-0.05, 0.05, 25), pvp, ldc)).max() < 1e-11
+
+
+def test_calc_probs_matches_cpu_checker():
+    """full calc_probs (contrast curve, nearby star, all 18 scenarios) on the GPU vs the same
+    seeded run with the device calls replaced by the CPU oracle"""
+    import pandas as pd
+    from triceratops_amd.triceratops import target
+    stars = pd.DataFrame({
+        "ID": [111, 222], "Tmag": [10.4, 13.0], "Jmag": [9.5, 12.1], "Hmag": [9.1, 11.7],
+        "Kmag": [9.0, 11.6], "ra": [10.0, 10.01], "dec": [-5.0, -5.01], "mass": [0.82, 0.6],
+        "rad": [0.8, 0.58], "Teff": [5100.0, 4000.0], "plx": [14.2, 3.0],
+        "fluxratio": [0.95, 0.05], "tdepth": [0.0074, 0.14]})
+    kw = dict(P_orb=3.3, contrast_curve_file=os.path.join(GOLD, "contrast_curve_synth.csv"),
+              filt="J", N=3000, parallel=True, verbose=0)
+    tg = target(111, np.array([1]), stars=stars.copy(), trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"))
+    np.random.seed(99)
+    tg.calc_probs(G["time"], G["flux"], float(G["sigma"][0]), **kw)
+    mp = pytest.MonkeyPatch()
+    try:
+        install_cpu_device_fakes(mp)
+        ck = target(111, np.array([1]), stars=stars.copy(), trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"))
+        np.random.seed(99)
+        ck.calc_probs(G["time"], G["flux"], float(G["sigma"][0]), **kw)
+    finally:
+        mp.undo()
+    fin = np.isfinite(ck.lnZ)
+    assert np.array_equal(fin, np.isfinite(tg.lnZ)) and np.abs(tg.lnZ[fin] - ck.lnZ[fin]).max() < 1e-9
+    assert np.abs(tg.probs.prob.values - ck.probs.prob.values).max() < 1e-9
+    assert abs(tg.FPP - ck.FPP) < 1e-9 and abs(tg.NFPP - ck.NFPP) < 1e-9
+    assert list(tg.probs.scenario) == list(ck.probs.scenario)

@@ -1,0 +1,170 @@
+"""Multi-process path of calc_probs (triceratops_amd/sharding.py) on CPU: world_size 2, gloo.
+
+The work units here are cheap numpy thunks that draw from the global numpy stream, exactly like
+the lnZ_* functions do, so the test pins: the LPT schedule is identical on every rank, each unit
+runs on exactly one rank, the single all_gather reassembles the record table in unit order, and
+per-unit reseeding makes the result independent of the world size.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from triceratops_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_units(n_stars=3, drop=("PEB",)):
+    """the unit layout calc_probs builds: 10 target calls + 2 per nearby star"""
+    from triceratops_amd.triceratops import _TARGET_CALLS
+    units = []
+
+    def thunk(n_res, tag):
+        def run():
+            out = []
+            for r in range(n_res):
+                d = {c: np.random.rand(100) + tag for c in sharding.RECORD_COLS if c != "lnZ"}
+                d["lnZ"] = float(-50 * np.random.rand() - tag)
+                out.append(d)
+            return out[0] if n_res == 1 else tuple(out)
+        return run
+
+    for key, names, j0, snum in _TARGET_CALLS:
+        units.append((j0, names, snum, 111, None if key in drop else thunk(len(names), j0), key))
+    for i in range(1, n_stars):
+        j0 = 15 + 3 * (i - 1)
+        units.append((j0, ("NTP",), 1, 200 + i, thunk(1, j0), "NTP"))
+        units.append((j0 + 1, ("NEB", "NEBx2P"), 1, 200 + i, thunk(2, j0 + 1), "NEB"))
+    return units
+
+
+def _flatten(results):
+    rows = []
+    for r in results:
+        if r is None:
+            rows.append(None)
+        else:
+            rows.append(np.array([[d[c] for c in sharding.RECORD_COLS] for d in r]))
+    return rows
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    np.random.seed(4242)                      # same global state on every rank, like a user would
+    units = _fake_units()
+    res = sharding.run_units(units, verbose=0)
+    owners = sharding.schedule([sharding._COST.get(u[5], 1.0) for u in units if u[4] is not None], world)
+    q.put((rank, _flatten(res), owners))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_schedule_is_balanced_and_deterministic():
+    costs = [1.0, 1.7, 1.1, 1.8, 1.2, 1.9, 1.1, 1.8, 1.2, 1.9] + [1.0, 1.7] * 5
+    for world in (1, 2, 4, 8):
+        own = sharding.schedule(costs, world)
+        assert own == sharding.schedule(list(costs), world)
+        load = [sum(c for c, o in zip(costs, own) if o == r) for r in range(world)]
+        assert max(load) - min(load) <= max(costs) + 1e-12
+        assert set(own) == set(range(min(world, len(costs))))
+
+
+def test_world2_gloo_matches_single_process():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    (_, res0, own0), (_, res1, own1) = got
+    assert own0 == own1 and set(own0) == {0, 1}
+    # every rank ends with the same full table
+    for a, b in zip(res0, res1):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    # ... which equals a single-process run with per-unit seeding (partition independence)
+    np.random.seed(4242)
+    sharding.per_unit_seed = True
+    try:
+        single = _flatten(sharding.run_units(_fake_units(), verbose=0))
+    finally:
+        sharding.per_unit_seed = False
+    for a, b in zip(res0, single):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    assert res0[3] is None      # the dropped PEB unit stays empty
+
+
+def test_single_process_consumes_the_stream_sequentially():
+    """world == 1 without per-unit seeding: unit k sees the stream where unit k-1 left it, as in
+    the reference's sequential scenario loop"""
+    np.random.seed(7)
+    res = _flatten(sharding.run_units(_fake_units(n_stars=1, drop=()), verbose=0))
+    np.random.seed(7)
+    units = _fake_units(n_stars=1, drop=())
+    for u, r in zip(units, res):
+        want = sharding._record(u[4]())
+        assert np.array_equal(want, r)
+
+
+def test_calc_probs_end_to_end_on_host_fakes(monkeypatch):
+    """calc_probs table layout, scenario order, FPP/NFPP bookkeeping and drop_scenario handling
+    (triceratops.py:673-1485), device calls replaced by the CPU stand-in"""
+    import pandas as pd
+    from helpers import GOLD, gold, install_cpu_device_fakes
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd.triceratops import target
+    g = gold("lnz_cases.npz")
+    stars = pd.DataFrame({
+        "ID": [111, 222, 333], "Tmag": [10.4, 13.0, 15.5], "Jmag": [9.5, 12.1, 14.6],
+        "Hmag": [9.1, 11.7, 14.2], "Kmag": [9.0, 11.6, 14.1], "ra": [10.0, 10.01, 10.02],
+        "dec": [-5.0, -5.01, -5.02], "mass": [0.82, 0.6, np.nan], "rad": [0.8, 0.58, np.nan],
+        "Teff": [5100.0, 4000.0, np.nan], "plx": [14.2, 3.0, np.nan],
+        "fluxratio": [0.95, 0.04, 0.01], "tdepth": [0.0074, 0.17, 0.0]})
+    tg = target(111, np.array([1]), stars=stars, trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"))
+    np.random.seed(5)
+    with pytest.warns(None) if False else _nullcontext():
+        tg.calc_probs(g["time"], g["flux"], float(g["sigma"][0]), 3.3, N=400, parallel=True,
+                      drop_scenario=["SEB"], verbose=0)
+    assert list(tg.probs.scenario) == ["TP", "EB", "EBx2P", "PTP", "PEB", "PEBx2P", "STP", "SEB",
+                                      "SEBx2P", "DTP", "DEB", "DEBx2P", "BTP", "BEB", "BEBx2P",
+                                      "NTP", "NEB", "NEBx2P"]
+    assert len(tg.lnZ) == 3 * 2 + 12 and tg.lnZ[7] == -np.inf and tg.lnZ[8] == -np.inf
+    assert list(tg.star_num[:15]) == [1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 2, 2, 2]
+    assert list(tg.probs.ID[15:]) == [222, 222, 222]
+    assert abs(tg.probs.prob.sum() - 1) < 1e-12
+    assert abs(tg.FPP - (1 - tg.probs.prob[[0, 3, 9]].sum())) < 1e-15
+    assert abs(tg.NFPP - tg.probs.prob[15:].sum()) < 1e-15
+    assert tg.FPP_degenerate is False
+    # same seed, sequential stream -> identical to calling the lnZ_* in the reference's order
+    from triceratops_amd import marginal_likelihoods as ml
+    from triceratops_amd.funcs import renorm_flux
+    np.random.seed(5)
+    fl, fe = renorm_flux(g["flux"], float(g["sigma"][0]), 0.95)
+    r = ml.lnZ_TTP(g["time"], fl, fe, 3.3, 0.82, 0.8, 5100.0, 0.0, 400, True, "TESS", False, 0.00139, 20)
+    assert r["lnZ"] == tg.lnZ[0] and r["R_p"][0] == tg.probs.R_p[0]
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -110,10 +110,10 @@ def run_units(units, verbose=0):
     if dist:
         import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        mine = torch.as_tensor(table).to(dev)
-        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        mine = torch.as_tensor(table).to(dev).reshape(-1)
+        gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=dev)
         dist.all_gather_into_tensor(gathered, mine)          # the single data-path collective
-        g = gathered.cpu().numpy()
+        g = gathered.cpu().numpy().reshape((world,) + table.shape)
         for k in live:
             table[offs[k]:offs[k] + rows[k]] = g[owner[k], offs[k]:offs[k] + rows[k]]
 
