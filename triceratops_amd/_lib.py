@@ -11,7 +11,7 @@ import numpy as np
 import torch  # noqa: F401  (imported first so libtrx binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrx.so")
+LIB_PATH = os.environ.get("TRX_LIB") or os.path.join(_HERE, "libtrx.so")   # TRX_LIB: A/B builds
 
 MODEL_TP, MODEL_EB, MODEL_EB_TWIN, MODEL_RAW = 0, 1, 2, 3
 FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K = 1, 2

@@ -6,9 +6,13 @@
 //   * Kepler's equation is solved once per light-curve point; the S sub-exposures of that
 //     point are reached by Newton steps on dE using Taylor kernels for sin(dE), cos(dE)-1
 //     (|dE| ~ 1e-4 rad), so no trig range reduction runs inside the supersample loop.
-//   * the two Bulirsch `cel` integrals of a Mandel-Agol evaluation share one AGM loop.
+//   * the two Bulirsch `cel` integrals of a Mandel-Agol evaluation share one AGM loop and
+//     one reciprocal per iteration.
 //   * a per-row mean-anomaly window (analytic bound of |X| < 1+k around inferior
 //     conjunction) lets out-of-transit points return exactly 1.0 without touching the orbit.
+//   * reciprocal / square root / sincos are short fp64 sequences seeded by v_rcp_f64 /
+//     v_rsq_f64 (about 1 ulp, not correctly rounded): the IEEE div/sqrt expansions and the
+//     Payne-Hanek path of the library sincos cost registers and issue slots this kernel needs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -34,16 +38,79 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------
-// cel(kc,1,a1,b1) + cel(kc,p2,g,g) (Bulirsch 1969) with the kc/em recurrence shared.
+// short fp64 sequences (finite, normal-range arguments; ~1 ulp)
+__device__ __forceinline__ double rcp_fast(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);      // v_rcp_f64: ~2^-23 relative
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
+// sqrt(x) and 1/sqrt(x) for x > 0 (Goldschmidt from v_rsq_f64); x == 0 gives (0, inf)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    s = (x == 0.0) ? 0.0 : g;
+    rs = (x == 0.0) ? INFINITY : 2.0 * h;
+}
+
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+    double s, rs;
+    sqrt_rsqrt(x, s, rs);
+    return s;
+}
+
+// sin and cos for |x| up to ~1e5 (orbit angles): Cody-Waite reduction by pi/2 with a
+// two-word pi/2 under fma, fdlibm kernel polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void sincos_red(double x, double& s, double& c)
+{
+    const double n = rint(x * 0.63661977236758134308);   // 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10,
+                      -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                      -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                      -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11,
+                      2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                      2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                      4.16666666666666019037e-02);
+    const double sr = fma(z * r, ps, r);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)n & 3;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// ---------------------------------------------------------------------------------------
+// cel(kc,1,a1,b1) + cel(kc,p2,g2,g2) (Bulirsch 1969): the kc/em recurrence is shared and the
+// two p-sequences use one reciprocal per iteration.  Returns the sum of the two integrals.
 __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, double p2, double g2)
 {
     double e = kc, em = 1.0, q = kc;
     double p1 = 1.0;
-    double pp = sqrt(p2);
-    double a2 = g2, b2 = g2 / pp;
+    double pp, rp;
+    sqrt_rsqrt(p2, pp, rp);
+    double a2 = g2, b2 = g2 * rp;
 #pragma unroll 1
     for (int it = 0; it < 40; ++it) {
-        const double r1 = 1.0 / p1, r2 = 1.0 / pp;
+        const double r = rcp_fast(p1 * pp);
+        const double r1 = r * pp, r2 = r * p1;
         double f = a1, g = e * r1;
         a1 = fma(b1, r1, a1);
         b1 = fma(f, g, b1);
@@ -58,10 +125,12 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
         g = em;
         em += q;
         if (fabs(g - q) <= g * 1e-8) break;
-        q = 2.0 * sqrt(e);
+        q = 2.0 * sqrt_fast(e);
         e = q * em;
     }
-    return kHalfPi * ((b1 + a1 * em) / (em * (em + p1)) + (b2 + a2 * em) / (em * (em + pp)));
+    const double d1 = em * (em + p1), d2 = em * (em + pp);
+    const double num = fma(fma(a1, em, b1), d2, fma(a2, em, b2) * d1);
+    return kHalfPi * num * rcp_fast(d1 * d2);
 }
 
 // Limb-darkening weights of one row: F = 1 - (cle*le + cld*ld + ced*ed)
@@ -82,7 +151,8 @@ __device__ __forceinline__ Limb limb_weights(double u1, double u2)
 
 // Mandel & Agol (2002) quadratic-law flux for 0 <= z < 1+p, p > 0 (callers handle the
 // unocculted side).  Case analysis and factored contact-triangle form: DESIGN.md section 4.
-__device__ double ma_flux(double z, double p, const Limb& L)
+// Both regions (disk inside the limb / crossing it) feed ONE cel_pair call.
+__device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
 {
     if (p >= 1.0 && z <= p - 1.0) return 0.0;
     const double z2 = z * z, p2 = p * p;
@@ -94,89 +164,107 @@ __device__ double ma_flux(double z, double p, const Limb& L)
     const double eta2 = 0.5 * p2 * (p2 + 2.0 * z2);
     const double theta = (z < p) ? (2.0 / 3.0) : ((z == p) ? (1.0 / 3.0) : 0.0);
     const double t7 = z2 + 7.0 * p2 - 4.0;
-    // the term -3 q / a * Pi(...) vanishes in the limit z -> p (a == 0): drop it there
-    const double ga = (a > 0.0) ? (-3.0 * q / a) : 0.0;
-    double le, ld, ed;
-    if (p < 1.0 && z <= omp) {
+    const bool inside = (p < 1.0 && z <= omp);
+    const double ra = (a > 0.0) ? rcp_fast(a) : 0.0;
+    // the term -3 q / a * Pi(...) vanishes in the limit z -> p (a == 0): dropped there
+    const double ga = -3.0 * q * ra;
+    const double b = (z + p) * (z + p);
+    double le, ed, kc2, al, be, P, scale;
+    bool contact = false;
+    if (inside) {
         le = p2;
         ed = eta2;
         const double g1 = omp - z;
-        if (g1 == 0.0) {
-            ld = (2.0 / (3.0 * kPi)) * acos(1.0 - 2.0 * p)
-               - (4.0 / (9.0 * kPi)) * (3.0 + 2.0 * p - 8.0 * p2) * sqrt(p * omp);
-        } else {
-            const double oma = f2 * f3;
-            const double kc2 = g1 * f4 / oma;
-            const double al = 1.0 - 5.0 * z2 + p2 + q * q;
-            const double be = oma * t7;
-            const double P = (a > 0.0) ? ((z + p) * (z + p) / a) : 1.0;
-            const double s = cel_pair(sqrt(kc2), al + be, fma(be, kc2, al), P, ga);
-            ld = 2.0 / (9.0 * kPi * sqrt(oma)) * s + theta;
-        }
+        contact = (g1 == 0.0);
+        const double oma = f2 * f3;
+        double so, rso;
+        sqrt_rsqrt(oma, so, rso);
+        kc2 = g1 * f4 * rso * rso;
+        al = 1.0 - 5.0 * z2 + p2 + q * q;
+        be = oma * t7;
+        P = (a > 0.0) ? b * ra : 1.0;
+        scale = (2.0 / (9.0 * kPi)) * rso;
     } else {
         const double f1 = (p < 1.0) ? (z - omp) : (z + (p - 1.0));
-        const double s14 = sqrt(f1 * f4), s23 = sqrt(f2 * f3);
+        const double s14 = sqrt_fast(f1 * f4), s23 = sqrt_fast(f2 * f3);
         const double kap0 = 2.0 * atan2(s23, s14);
-        const double kap1 = 2.0 * atan2(sqrt(f1 * f2), sqrt(f3 * f4));
+        const double kap1 = 2.0 * atan2(sqrt_fast(f1 * f2), sqrt_fast(f3 * f4));
         const double area4 = s14 * s23;
         le = (p2 * kap0 + kap1 - 0.5 * area4) * (1.0 / kPi);
         ed = (kap1 + 2.0 * eta2 * kap0 - 0.25 * (1.0 + 5.0 * p2 + z2) * area4) * (1.0 / kTwoPi);
         const double fzp = 4.0 * z * p;
-        const double kc2 = f1 * f4 / fzp;
-        const double b = (z + p) * (z + p);
-        const double al = (1.0 - b) * (2.0 * b + a - 3.0) - 3.0 * q * (b - 2.0);
-        const double be = fzp * t7;
-        const double P = (a > 0.0) ? (1.0 / a) : 1.0;
-        const double s = cel_pair(sqrt(kc2), al + be, fma(be, kc2, al), P, ga);
-        ld = s / (9.0 * kPi * sqrt(p * z)) + theta;
+        double sz, rsz;
+        sqrt_rsqrt(fzp, sz, rsz);
+        kc2 = f1 * f4 * rsz * rsz;
+        al = (1.0 - b) * (2.0 * b + a - 3.0) - 3.0 * q * (b - 2.0);
+        be = fzp * t7;
+        P = (a > 0.0) ? ra : 1.0;
+        scale = (2.0 / (9.0 * kPi)) * rsz;   // 1/(9 pi sqrt(p z))
+    }
+    double ld;
+    if (contact) {
+        ld = (2.0 / (3.0 * kPi)) * acos(1.0 - 2.0 * p)
+           - (4.0 / (9.0 * kPi)) * (3.0 + 2.0 * p - 8.0 * p2) * sqrt(p * omp);
+    } else {
+        const double s = cel_pair(sqrt_fast(kc2), al + be, fma(be, kc2, al), P, ga);
+        ld = fma(scale, s, theta);
     }
     return 1.0 - (L.cle * le + L.cld * ld + L.ced * ed);
 }
 
 // ---------------------------------------------------------------------------------------
 // Kepler's equation, full solve: bracket-safeguarded Halley on m = |M| in [0, pi].
-// Returns E and (sin E, cos E).
-__device__ __forceinline__ void kepler_full(double M, double e, double& E, double& sE, double& cE)
+// Returns (sin E, cos E).  The iteration stops one step early: a Halley step below 1e-6
+// leaves an error ~ step^3, and (sin, cos) follow by a third-order update.
+__device__ __forceinline__ void kepler_full(double M, double e, double& sE, double& cE)
 {
     M = remainder(M, kTwoPi);
     const double sgn = (M < 0.0) ? -1.0 : 1.0;
     const double m = fabs(M);
     double lo = m, hi = fmin(m + e, kPi);
-    double sm, cm;
-    sincos(m, &sm, &cm);
-    double x = m + e * sm * rsqrt(fma(e, e - 2.0 * cm, 1.0));
-    if (!(x >= lo && x <= hi)) x = 0.5 * (lo + hi);
-    double s = sm, c = cm;
+    double s, c;
+    sincos_red(m, s, c);
+    double x = m;
     bool done = (e == 0.0);
-    if (done) x = m;
-#pragma unroll 1
-    for (int it = 0; it < 24; ++it) {
-        if (__all(done)) break;
-        sincos(x, &s, &c);
-        const double f = x - e * s - m;
-        if (f > 0.0) hi = x; else lo = x;
-        const double fp = 1.0 - e * c;
-        double dx = -f / (fp + 0.5 * (-f / fp) * e * s);
-        double xn = x + dx;
-        if (!(xn >= lo && xn <= hi)) { xn = 0.5 * (lo + hi); dx = xn - x; }
-        if (!done) x = xn;
-        done = done || (fabs(dx) <= 2.3e-16 * (1.0 + fabs(x))) || !(dx == dx);
+    {
+        const double x0 = m + e * s * __builtin_amdgcn_rsq(fma(e, e - 2.0 * c, 1.0));
+        if (!done) x = (x0 >= lo && x0 <= hi) ? x0 : 0.5 * (lo + hi);
     }
-    sincos(x, &s, &c);
-    E = sgn * x;
+#pragma unroll 1
+    for (int it = 0; it < 30; ++it) {
+        if (__all(done)) break;
+        double sx, cx;
+        sincos_red(x, sx, cx);
+        const double f = x - e * sx - m;
+        if (f > 0.0) hi = x; else lo = x;
+        const double fp = 1.0 - e * cx;
+        const double rfp = rcp_fast(fp);
+        double dx = -f * rcp_fast(fma(-0.5 * f * rfp, e * sx, fp));
+        double xn = x + dx;
+        const bool safe = (xn >= lo && xn <= hi);
+        if (!safe) { xn = 0.5 * (lo + hi); dx = xn - x; }
+        if (!done) {
+            x = xn;
+            // (sin, cos) at x + dx from those at x
+            const double h = dx * dx;
+            s = fma(dx, fma(-h, 1.0 / 6.0, 1.0) * cx, fma(-0.5 * h, sx, sx));
+            c = fma(-dx, fma(-h, 1.0 / 6.0, 1.0) * sx, fma(-0.5 * h, cx, cx));
+        }
+        done = done || (safe && fabs(dx) < 1e-6) || !(dx == dx);
+    }
     sE = sgn * s;
     cE = c;
 }
 
-// Advance the solution (E, sinE, cosE) of E - e sinE = M to M + dM for small dM:
-// Newton on g(d) = d - e (sinE (cos d - 1) + cosE sin d) - dM with Taylor kernels.
-// Returns false when |d| is too large for the series (caller falls back to kepler_full).
-__device__ __forceinline__ bool kepler_step(double dM, double e, double& E, double& sE, double& cE)
+// Advance (sinE, cosE) of E - e sinE = M to M + dM for small dM: Newton on
+// g(d) = d - e (sinE (cos d - 1) + cosE sin d) - dM with Taylor kernels and a running
+// reciprocal of g' (no division).  Returns false when |d| is too large for the series.
+__device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, double& cE)
 {
-    const double rho = 1.0 / (1.0 - e * cE);
+    double rho = rcp_fast(fma(-e, cE, 1.0));
     double d = dM * rho;
     if (!(fabs(d) < 0.08)) return false;
-    double ds = 0.0, dc = 0.0;
+    double ds = 0.0, dc = 0.0, step = 0.0;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const double d2 = d * d;
@@ -186,15 +274,18 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& E, doub
                                                      -1.0 / 720.0), 1.0 / 24.0), -0.5);
         ds = fma(sE, c1, cE * sd);   // sin(E+d) - sin E
         dc = fma(cE, c1, -sE * sd);  // cos(E+d) - cos E
-        const double g = d - e * ds - dM;
-        const double gp = 1.0 - e * (cE + dc);
-        const double step = g / gp;
+        const double g = fma(-e, ds, d) - dM;
+        const double gp = fma(-e, cE + dc, 1.0);
+        rho = rho * fma(-gp, rho, 2.0);          // one Newton step on 1/gp
+        step = g * rho;
         d -= step;
-        if (__all(fabs(step) <= 1e-17 + 1.2e-16 * fabs(d))) break;
+        // a step below 1e-9 leaves an error ~ step^2: done after applying it
+        if (__all(fabs(step) < 1e-9)) break;
     }
-    E += d;
-    sE += ds;
-    cE += dc;
+    // (ds, dc) were evaluated one step back: first-order correction
+    const double s1 = sE + ds, c1 = cE + dc;
+    sE = fma(-step, c1, s1);
+    cE = fma(step, s1, c1);
     return true;
 }
 
@@ -210,19 +301,19 @@ struct RowC {
 };
 constexpr int kRowDoubles = sizeof(RowC) / sizeof(double);
 
-// Orbit constants from pytransit-shaped (k, t0, p, a, i, e, w).
+// Orbit constants from pytransit-shaped (k, t0, p, a, i, e, w).  Runs once per row.
 __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double per, double a,
                                            double inc, double e, double w, double exptime)
 {
     const double ftr = kHalfPi - w;
     const double rt = sqrt(1.0 - e * e);
     double sf, cf;
-    sincos(ftr, &sf, &cf);
+    sincos_red(ftr, sf, cf);
     const double Etr = atan2(rt * sf, e + cf);
     double sEt, cEt;
-    sincos(Etr, &sEt, &cEt);
+    sincos_red(Etr, sEt, cEt);
     double sw, cw;
-    sincos(w, &sw, &cw);
+    sincos_red(w, sw, cw);
     c.k = k;
     c.t0 = t0;
     c.nmot = kTwoPi / per;
@@ -232,7 +323,8 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
     c.bx = -a * rt * sw;
     c.ay = a * sw;
     c.by = a * rt * cw;
-    c.cosi = cos(inc);
+    double si;
+    sincos_red(inc, si, c.cosi);
     // Window: X(E) = ax (cosE - e) + bx sinE = A cos(E - phi) - ax e; transit needs |X| < 1+k.
     const double R = (1.0 + k) * (1.0 + 1e-9) + 1e-12;
     const double A = sqrt(c.ax * c.ax + c.bx * c.bx);
@@ -241,57 +333,56 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
     const double psi = remainder(Etr - phi, kTwoPi);
     double plo, phi2;  // arc [plo, phi2] of psi = E - phi containing psi
     const bool open_hi = !(chi < 1.0), open_lo = !(clo > -1.0);
+    const double xlo = acos(fmin(fmax(clo, -1.0), 1.0)), xhi = acos(fmin(fmax(chi, -1.0), 1.0));
     if (open_hi && open_lo) {
         plo = psi - kTwoPi;
         phi2 = psi + kTwoPi;
     } else if (open_hi) {
-        const double x = acos(clo);
-        plo = -x;
-        phi2 = x;
+        plo = -xlo;
+        phi2 = xlo;
     } else if (open_lo) {
-        const double x = acos(chi);
-        if (psi >= 0.0) { plo = x; phi2 = kTwoPi - x; } else { plo = x - kTwoPi; phi2 = -x; }
+        if (psi >= 0.0) { plo = xhi; phi2 = kTwoPi - xhi; } else { plo = xhi - kTwoPi; phi2 = -xhi; }
     } else {
-        const double x0 = acos(chi), x1 = acos(clo);
-        if (psi >= 0.0) { plo = x0; phi2 = x1; } else { plo = -x1; phi2 = -x0; }
+        if (psi >= 0.0) { plo = xhi; phi2 = xlo; } else { plo = -xlo; phi2 = -xhi; }
     }
     const double Elo = Etr + (plo - psi), Ehi = Etr + (phi2 - psi);
+    double sl, cl, sh, ch;
+    sincos_red(Elo, sl, cl);
+    sincos_red(Ehi, sh, ch);
     const double mg = 0.5 * fabs(c.nmot * exptime) * (1.0 + 1e-9) + 1e-11;
-    c.wlo = (Elo - Etr) - e * (sin(Elo) - sEt) - mg;
-    c.whi = (Ehi - Etr) - e * (sin(Ehi) - sEt) + mg;
-    // NaN anywhere (invalid draw) => comparisons below are false => the point is evaluated
-    // and the NaN propagates to the result exactly as in the plain restatement.
+    c.wlo = (Elo - Etr) - e * (sl - sEt) - mg;
+    c.whi = (Ehi - Etr) - e * (sh - sEt) + mg;
+    // NaN anywhere (invalid draw) => the comparisons in in_window are false => the cell is
+    // evaluated and the NaN propagates to the result exactly as in the plain algorithm.
 }
 
-__device__ __forceinline__ bool in_window(const RowC& c, double dMc)
+__device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 {
     // dMc in [-pi, pi]: mean anomaly of the exposure centre relative to conjunction
-    const bool out = ((dMc < c.wlo) && !(dMc + kTwoPi <= c.whi)) ||
-                     ((dMc > c.whi) && !(dMc - kTwoPi >= c.wlo));
+    const bool out = ((dMc < wlo) && !(dMc + kTwoPi <= whi)) ||
+                     ((dMc > whi) && !(dMc - kTwoPi >= wlo));
     return !out;
 }
 
 // Mean model flux of one exposure (centre t), S sub-exposures: the body of
 // pytransit's evaluate_pv for one (row, time) cell.
-template <bool STEP>
 __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
-                                                double exptime, int S)
+                                                double exptime, int S, bool stepping)
 {
-    const double tc = t - c.t0;
-    const double dMc = remainder(c.nmot * tc, kTwoPi);
-    if (!in_window(c, dMc)) return 1.0;
+    const double dMc = remainder(c.nmot * (t - c.t0), kTwoPi);
+    if (!in_window(c.wlo, c.whi, dMc)) return 1.0;
     const double opp = 1.0 + c.k;
     const double opp2 = opp * opp;
     const double dS = (double)S;
     double acc = 0.0;
-    double E = 0.0, sE = 0.0, cE = 1.0, Mprev = 0.0;
+    double sE = 0.0, cE = 1.0, Mprev = 0.0;
 #pragma unroll 1
     for (int s = 1; s <= S; ++s) {
         const double off = exptime * (((double)s - 0.5) / dS - 0.5);
         const double M = c.nmot * ((t + off) - c.t0) + c.Mtr;
-        bool stepped = false;
-        if (STEP && s > 1) stepped = kepler_step(M - Mprev, c.e, E, sE, cE);
-        if (!stepped) kepler_full(M, c.e, E, sE, cE);
+        bool have = false;
+        if (stepping && s > 1) have = kepler_step(M - Mprev, c.e, sE, cE);
+        if (!have) kepler_full(M, c.e, sE, cE);
         Mprev = M;
         const double ce = cE - c.e;
         const double X = fma(c.ax, ce, c.bx * sE);
@@ -299,7 +390,7 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
         const double yc = Y * c.cosi;
         const double z2 = fma(X, X, yc * yc);
         double f = 1.0;
-        if (Y >= 0.0 && z2 < opp2) f = ma_flux(sqrt(z2), c.k, L);
+        if (Y >= 0.0 && z2 < opp2) f = ma_flux(sqrt_fast(z2), c.k, L);
         else if (z2 != z2) f = z2;
         acc += f;
     }

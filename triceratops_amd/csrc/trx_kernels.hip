@@ -68,8 +68,14 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
     return k;
 }
 
+// register budget: 3 waves/SIMD (168 VGPRs) measured best on MI355X (profiles/r01_ab_waves.txt);
+// the few spills land in the once-per-row prologue
+#ifndef TRX_WAVES_PER_EU
+#define TRX_WAVES_PER_EU 3
+#endif
+
 template <int MODE, bool STEP>
-__global__ __launch_bounds__(64) void rows_kernel(RowsArgs a)
+__global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 {
     extern __shared__ double lds[];
     const int B = a.B;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a)
                 // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
                 double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
                 if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux<false>(sc, L, ts, 0.0, 1);
+                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, false);
             }
             __syncthreads();
             if (lane < nb) {
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(64) void rows_kernel(RowsArgs a)
             const Limb L{c.cle, c.cld, c.ced};
             double acc = 0.0;
             for (int j = lane; j < a.n_time; j += 64) {
-                double m = exposure_flux<STEP>(c, L, a.time[j], a.exptime, a.S);
+                double m = exposure_flux(c, L, a.time[j], a.exptime, a.S, STEP);
                 if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                 if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
                 if (MODE == MODE_GRID) {
