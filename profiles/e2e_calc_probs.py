@@ -1,0 +1,47 @@
+"""End-to-end calc_probs() wall-clock on one GPU (BASELINE metric, second half).
+
+Shape of BASELINE config 3: a 100-point binned light curve + contrast curve, one target and
+`--nearby` contaminating stars (3 scenarios each), N draws per scenario, parallel=True.
+Inputs are synthetic (the reference's TIC/TRILEGAL tables come from the network); the contrast
+curve and TRILEGAL table are the committed test fixtures.
+"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, pandas as pd, torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--N", type=int, default=1_000_000)
+ap.add_argument("--nearby", type=int, default=20)
+ap.add_argument("--n-time", type=int, default=100)
+args = ap.parse_args()
+
+from triceratops_amd import _lib, synth
+from triceratops_amd.triceratops import target
+
+G = os.path.join(ROOT, "tests", "golden")
+rng = np.random.default_rng(3)
+t = np.linspace(-0.2, 0.2, args.n_time)
+ref = synth.reference_tp_row()
+curve, _ = _lib.flux_grid(0, 0, _lib.dev(t), _lib.dev(ref), synth.EXPTIME, 20, False)
+flux = synth.noisy_light_curve(rng, curve[0].cpu().numpy())
+n = 1 + args.nearby
+stars = pd.DataFrame({
+    "ID": np.arange(100, 100 + n), "Tmag": np.r_[10.4, rng.uniform(12, 16, n - 1)],
+    "Jmag": np.r_[9.5, rng.uniform(11, 15, n - 1)], "Hmag": np.r_[9.1, rng.uniform(11, 15, n - 1)],
+    "Kmag": np.r_[9.0, rng.uniform(11, 15, n - 1)], "ra": 10.0, "dec": -5.0,
+    "mass": np.r_[0.82, rng.uniform(0.3, 1.2, n - 1)], "rad": np.r_[0.8, rng.uniform(0.3, 1.2, n - 1)],
+    "Teff": np.r_[5100.0, rng.uniform(3500, 6500, n - 1)], "plx": np.r_[14.2, rng.uniform(1, 5, n - 1)],
+    "fluxratio": np.r_[0.9, np.full(n - 1, 0.1 / max(n - 1, 1))], "tdepth": np.r_[0.008, np.full(n - 1, 0.3)]})
+tg = target(100, np.array([1]), stars=stars, trilegal_fname=os.path.join(G, "trilegal_synth.csv"))
+np.random.seed(1)
+kw = dict(P_orb=3.0, contrast_curve_file=os.path.join(G, "contrast_curve_synth.csv"), filt="J",
+          N=args.N, parallel=True, verbose=0)
+tg.calc_probs(t, flux, synth.SIGMA, **dict(kw, N=2000))      # warm-up (library load, LDC tables)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+tg.calc_probs(t, flux, synth.SIGMA, **kw)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("calc_probs: N=%d, %d points, %d scenarios: %.2f s   FPP=%.4g NFPP=%.4g" % (
+    args.N, args.n_time, len(tg.lnZ), dt, tg.FPP, tg.NFPP))

@@ -100,13 +100,12 @@ __device__ __forceinline__ void sincos_red(double x, double& s, double& c)
 // ---------------------------------------------------------------------------------------
 // cel(kc,1,a1,b1) + cel(kc,p2,g2,g2) (Bulirsch 1969): the kc/em recurrence is shared and the
 // two p-sequences use one reciprocal per iteration.  Returns the sum of the two integrals.
-__device__ __forceinline__ double cel_pair(double kc, double a1, double b1, double p2, double g2)
+// The second integral is passed pre-scaled: pp = sqrt(p2), a2 = g2, b2 = g2 / sqrt(p2).
+__device__ __forceinline__ double cel_pair(double kc, double a1, double b1, double pp, double a2,
+                                           double b2)
 {
     double e = kc, em = 1.0, q = kc;
     double p1 = 1.0;
-    double pp, rp;
-    sqrt_rsqrt(p2, pp, rp);
-    double a2 = g2, b2 = g2 * rp;
 #pragma unroll 1
     for (int it = 0; it < 40; ++it) {
         const double r = rcp_fast(p1 * pp);
@@ -165,11 +164,16 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
     const double theta = (z < p) ? (2.0 / 3.0) : ((z == p) ? (1.0 / 3.0) : 0.0);
     const double t7 = z2 + 7.0 * p2 - 4.0;
     const bool inside = (p < 1.0 && z <= omp);
-    const double ra = (a > 0.0) ? rcp_fast(a) : 0.0;
-    // the term -3 q / a * Pi(...) vanishes in the limit z -> p (a == 0): dropped there
-    const double ga = -3.0 * q * ra;
-    const double b = (z + p) * (z + p);
-    double le, ed, kc2, al, be, P, scale;
+    // second integral: gamma * Pi(n) with gamma = -3 q / a, a = (z-p)^2.  With r = 1/|z-p|:
+    // sqrt(1+n) and gamma/sqrt(1+n) have closed forms (no sqrt, one reciprocal); the term
+    // vanishes in the limit z -> p and is dropped there.
+    const double zpp = z + p;
+    const double azmp = fabs(zmp);
+    const bool nz = azmp > 0.0;
+    const double r = nz ? rcp_fast(azmp) : 0.0;
+    const double m3 = nz ? ((p > z) ? -3.0 : 3.0) : 0.0;      // -3 sign(p - z)
+    const double b = zpp * zpp;
+    double le, ed, kc2, al, be, pp, a2, b2, scale;
     bool contact = false;
     if (inside) {
         le = p2;
@@ -182,7 +186,9 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         kc2 = g1 * f4 * rso * rso;
         al = 1.0 - 5.0 * z2 + p2 + q * q;
         be = oma * t7;
-        P = (a > 0.0) ? b * ra : 1.0;
+        pp = nz ? zpp * r : 1.0;                 // sqrt(b / a)
+        a2 = m3 * pp;                             // -3 q / a
+        b2 = m3;                                  // a2 / pp
         scale = (2.0 / (9.0 * kPi)) * rso;
     } else {
         const double f1 = (p < 1.0) ? (z - omp) : (z + (p - 1.0));
@@ -198,7 +204,9 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         kc2 = f1 * f4 * rsz * rsz;
         al = (1.0 - b) * (2.0 * b + a - 3.0) - 3.0 * q * (b - 2.0);
         be = fzp * t7;
-        P = (a > 0.0) ? ra : 1.0;
+        pp = nz ? r : 1.0;                        // sqrt(1 / a)
+        b2 = m3 * zpp;                            // a2 / pp
+        a2 = b2 * r;                              // -3 q / a
         scale = (2.0 / (9.0 * kPi)) * rsz;   // 1/(9 pi sqrt(p z))
     }
     double ld;
@@ -206,7 +214,7 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         ld = (2.0 / (3.0 * kPi)) * acos(1.0 - 2.0 * p)
            - (4.0 / (9.0 * kPi)) * (3.0 + 2.0 * p - 8.0 * p2) * sqrt(p * omp);
     } else {
-        const double s = cel_pair(sqrt_fast(kc2), al + be, fma(be, kc2, al), P, ga);
+        const double s = cel_pair(sqrt_fast(kc2), al + be, fma(be, kc2, al), pp, a2, b2);
         ld = fma(scale, s, theta);
     }
     return 1.0 - (L.cle * le + L.cld * ld + L.ced * ed);
@@ -264,6 +272,7 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
     double rho = rcp_fast(fma(-e, cE, 1.0));
     double d = dM * rho;
     if (!(fabs(d) < 0.08)) return false;
+    d = fma(-0.5 * e * sE * rho * d, d, d);     // second-order start: one Newton step then suffices
     double ds = 0.0, dc = 0.0, step = 0.0;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
@@ -374,11 +383,13 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
     const double opp = 1.0 + c.k;
     const double opp2 = opp * opp;
     const double dS = (double)S;
+    const double rS = 1.0 / dS;
     double acc = 0.0;
     double sE = 0.0, cE = 1.0, Mprev = 0.0;
 #pragma unroll 1
     for (int s = 1; s <= S; ++s) {
-        const double off = exptime * (((double)s - 0.5) / dS - 0.5);
+        // exptime*((s-0.5)/S - 0.5) up to an ulp of the offset (~1e-20 d)
+        const double off = exptime * fma((double)s - 0.5, rS, -0.5);
         const double M = c.nmot * ((t + off) - c.t0) + c.Mtr;
         bool have = false;
         if (stepping && s > 1) have = kepler_step(M - Mprev, c.e, sE, cE);

@@ -21,6 +21,7 @@ run on the GPU, there is no Python loop over draws here.
 from pathlib import Path
 
 import numpy as np
+import torch
 from pandas import read_csv
 
 from . import _lib
@@ -72,13 +73,15 @@ class _LdcTable:
         rt = np.round(Teffs / 250) * 250
         rt[rt < 3500] = 3500
         rt[rt > teff_cap] = teff_cap
-        pairs, inv = np.unique(np.stack([rt, rg]), axis=1, return_inverse=True)
-        c1, c2 = np.empty(pairs.shape[1]), np.empty(pairs.shape[1])
-        for j in range(pairs.shape[1]):
-            sel = (tz == pairs[0, j]) & (gz == pairs[1, j])
-            c1[j], c2[j] = a1[sel].item(), a2[sel].item()
-        inv = np.ravel(inv)
-        return c1[inv], c2[inv]
+        # the rounded values live on a 250 K x 0.5 dex lattice: code them as integers and look
+        # each distinct cell up once (an absent cell raises like the reference's .item())
+        code = np.rint((rt - 3500) / 250).astype(np.int64) * 8 + np.rint((rg - 3.5) / 0.5).astype(np.int64)
+        cells = np.unique(code)
+        lut1, lut2 = np.full(cells.max() + 1, np.nan), np.full(cells.max() + 1, np.nan)
+        for cidx in cells:
+            sel = (tz == 3500 + 250 * (cidx // 8)) & (gz == 3.5 + 0.5 * (cidx % 8))
+            lut1[cidx], lut2[cidx] = a1[sel].item(), a2[sel].item()
+        return lut1[code], lut2[code]
 
     def field_stars(self, Teffs, loggs, Zs):
         """per-background-star coefficients: nearest Teff and logg, then the nearest Z among the
@@ -125,8 +128,10 @@ def _logg(M, R):
 
 
 def _flux_share(masses, M_s, filt="TESS"):
-    return flux_relation(masses, filt) / (flux_relation(masses, filt)
-                                          + flux_relation(np.array([M_s]), filt))
+    """F(m) / (F(m) + F(M_s)) in band `filt` (the spline is evaluated once, the reference
+    evaluates the same expression twice)"""
+    f = flux_relation(masses, filt)
+    return f / (f + flux_relation(np.array([M_s]), filt))
 
 
 def _e_corr(eccs, argps):
@@ -228,7 +233,7 @@ class _Field:
 def _evidence(model, is_host, parallel, time, flux, sigma, cols, mask, lnprior, N, exptime,
               nsamples):
     """GPU part of a scenario branch: chi^2/2 of the masked draws and log-mean-exp over N.
-    Returns (lnL over all N draws, lnZ)."""
+    Returns (indices of the N_BEST best draws by decreasing lnL, lnZ)."""
     lnsigma = np.log(sigma)
     idx = np.flatnonzero(mask)
     block = np.empty((len(cols), idx.size), dtype=np.float64)
@@ -238,14 +243,25 @@ def _evidence(model, is_host, parallel, time, flux, sigma, cols, mask, lnprior, 
     lp = None if lnprior is None else _lib.dev(lnprior[idx])
     h, lnz = _lib.lnz_scenario(model, flags, _lib.dev(time), _lib.dev(flux), sigma,
                                _lib.dev(block), exptime, nsamples, lp, N, lnsigma)
-    lnL = np.full(N, -np.inf)
-    lnL[idx] = -0.5 * ln2pi - lnsigma - h.cpu().numpy()
-    return lnL, float(lnz.cpu()[0])
+    # best draws = smallest chi^2/2.  With >= N_BEST finite values only their order matters and a
+    # device top-k gives it; otherwise fall back to the reference's full argsort so that the
+    # (arbitrary) order of the -inf ties is the reference's too.
+    # (Equal chi^2 values do occur -- every draw whose model is flat over the data window has
+    # the same one -- and their order is the sort algorithm's: any tie sends us to the fallback.)
+    best = None
+    if idx.size > N_BEST:
+        hv, hi = torch.topk(h, N_BEST + 1, largest=False, sorted=True)
+        if bool(torch.isfinite(hv[-1])) and bool((hv[1:] > hv[:-1]).all()):
+            best = idx[hi[:N_BEST].cpu().numpy()]
+    if best is None:
+        lnL = np.full(N, -np.inf)
+        lnL[idx] = -0.5 * ln2pi - lnsigma - h.cpu().numpy()
+        best = (-lnL).argsort()[:N_BEST]
+    return best, float(lnz.cpu()[0])
 
 
-def _table(lnL, lnZ, **cols):
+def _table(idx, lnZ, **cols):
     """best-N_BEST table, by decreasing lnL (marginal_likelihoods.py:152-171)"""
-    idx = (-lnL).argsort()[:N_BEST]
     res = {}
     for key in ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
                 "R_EB", "fluxratio_EB", "fluxratio_comp"):
@@ -271,9 +287,9 @@ def _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps
     a_col = a if isinstance(a, np.ndarray) else np.full(N, a)
     cols = (rps, P_orb, incs, a_col, R_host, u1, u2, eccs, argps,
             0.0 if fr_comp is None else fr_comp)
-    lnL, lnZ = _evidence(MODEL_TP, is_host, parallel, time, flux, sigma, cols, mask, lnprior, N,
+    best, lnZ = _evidence(MODEL_TP, is_host, parallel, time, flux, sigma, cols, mask, lnprior, N,
                          exptime, nsamples)
-    return _table(lnL, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=P_orb, inc=incs, b=b,
+    return _table(best, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=P_orb, inc=incs, b=b,
                   R_p=rps, ecc=eccs, argp=argps, M_EB=None, R_EB=None, fluxratio_EB=None,
                   fluxratio_comp=fr_comp)
 
@@ -306,9 +322,9 @@ def _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, q
     for model, m, per, sma, bb in ((MODEL_EB, mask, P_orb, a, b),
                                    (MODEL_EB_TWIN, mask_twin, 2 * P_orb, a_twin, b_twin)):
         cols = (radii, fluxratios, per, incs, sma, R_host, u1, u2, eccs, argps, frc)
-        lnL, lnZ = _evidence(model, is_host, parallel, time, flux, sigma, cols, m, lnprior, N,
+        best, lnZ = _evidence(model, is_host, parallel, time, flux, sigma, cols, m, lnprior, N,
                              exptime, nsamples)
-        out.append(_table(lnL, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=per, inc=incs,
+        out.append(_table(best, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=per, inc=incs,
                           b=bb, R_p=None, ecc=eccs, argp=argps, M_EB=masses, R_EB=radii,
                           fluxratio_EB=fluxratios, fluxratio_comp=fr_comp))
     return out[0], out[1]
