@@ -276,6 +276,50 @@ def main():
     gold["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "lnz_cases.npz"), **gold)
 
+    # ---- (3b) the four lnZ_* that calc_probs never calls (API surface) --------
+    extra = {"time": t, "flux": f, "sigma": np.array([sigma])}
+    ex_cases = []
+    ex_plan = [
+        ("NTPu_par", lambda: rml.lnZ_NTP_unknown(*b, 3.3, 14.0, tri_path, N, True)),
+        ("NTPu_serial", lambda: rml.lnZ_NTP_unknown(*b, 3.3, 14.0, tri_path, 300, False)),
+        ("NTPu_empty", lambda: rml.lnZ_NTP_unknown(*b, 3.3, 30.0, tri_path, N, True)),
+        ("NEBu_par", lambda: rml.lnZ_NEB_unknown(*b, 3.3, 14.0, tri_path, N, True)),
+        ("NEBu_serial", lambda: rml.lnZ_NEB_unknown(*b, 3.3, 14.0, tri_path, 300, False)),
+        ("NEBu_empty", lambda: rml.lnZ_NEB_unknown(*b, 3.3, 30.0, tri_path, N, True)),
+        ("NTPe_par", lambda: rml.lnZ_NTP_evolved(*b, 3.3, 3.2, 4900.0, 0.0, N, True)),
+        ("NTPe_serial", lambda: rml.lnZ_NTP_evolved(*b, 3.3, 3.2, 4900.0, 0.0, 300, False)),
+        ("NEBe_par", lambda: rml.lnZ_NEB_evolved(*b, [3.0, 3.6], 3.2, 4900.0, 0.0, N, True)),
+        ("NEBe_serial", lambda: rml.lnZ_NEB_evolved(*b, 3.3, 3.2, 4900.0, 0.0, 300, False)),
+    ]
+    seed = 5000
+    for case, fn in ex_plan:
+        seed += 1
+        np.random.seed(seed)
+        del captured[:], logws[:]
+        res = fn()
+        ex_cases.append(case)
+        dicts = res if isinstance(res, tuple) else (res,)
+        extra[case + "_seed"] = np.array([seed])
+        extra[case + "_nres"] = np.array([len(dicts)])
+        for i, d in enumerate(dicts):
+            extra["%s_lnZ%d" % (case, i)] = np.array([d["lnZ"]])
+            extra["%s_keys%d" % (case, i)] = np.array(sorted(d.keys()))
+            for k, v in d.items():
+                if k != "lnZ":
+                    extra["%s_res%d_%s" % (case, i, k)] = np.atleast_1d(np.asarray(v, dtype=float))
+        for i, lw in enumerate(logws):
+            extra["%s_logw%d" % (case, i)] = lw
+        if case.endswith("_par"):
+            for i, (cname, args, kw_, outv) in enumerate(captured):
+                shape = max((np.shape(a) for a in args), key=len)
+                extra["%s_call%d_name" % (case, i)] = np.array([cname])
+                extra["%s_call%d_block" % (case, i)] = np.stack(
+                    [np.broadcast_to(a, shape) for a in args]
+                    + [np.broadcast_to(kw_["companion_fluxratio"], shape)])
+                extra["%s_call%d_out" % (case, i)] = outv
+    extra["cases"] = np.array(ex_cases)
+    np.savez_compressed(os.path.join(HERE, "lnz_extra.npz"), **extra)
+
     # ---- (4) BASELINE config 1: TOI-1228, TP scenario, N = 1e4 -------------------------------
     tb, fb, sg = binned_toi1228()
     np.random.seed(20260424 % (2 ** 32))

@@ -57,3 +57,38 @@ def install_cpu_device_fakes(monkeypatch):
     monkeypatch.setattr(_lib, "flux_grid", flux_grid)
     monkeypatch.setattr(_lib, "log_mean_exp", log_mean_exp)
     monkeypatch.setattr(_lib, "require_gpu", lambda: None)
+
+
+def call_extra(ml, case, g):
+    """invoke one of the four lnZ_* that calc_probs never calls, as make_golden.py did"""
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    b = (g["time"], g["flux"], float(g["sigma"][0]))
+    name, variant = case.split("_")
+    par = variant != "serial"
+    N = 2000 if par else 300
+    if name == "NTPu":
+        return ml.lnZ_NTP_unknown(*b, 3.3, 30.0 if variant == "empty" else 14.0, tri, N, par)
+    if name == "NEBu":
+        return ml.lnZ_NEB_unknown(*b, 3.3, 30.0 if variant == "empty" else 14.0, tri, N, par)
+    if name == "NTPe":
+        return ml.lnZ_NTP_evolved(*b, 3.3, 3.2, 4900.0, 0.0, N, par)
+    return ml.lnZ_NEB_evolved(*b, [3.0, 3.6] if par else 3.3, 3.2, 4900.0, 0.0, N, par)
+
+
+def check_extra(res, case, g, lnz_tol):
+    dicts = res if isinstance(res, tuple) else (res,)
+    assert len(dicts) == int(g[case + "_nres"][0])
+    for i, d in enumerate(dicts):
+        assert sorted(d.keys()) == [str(k) for k in g["%s_keys%d" % (case, i)]], (case, i)
+        want = g["%s_lnZ%d" % (case, i)][0]
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < lnz_tol
+        key = "%s_logw%d" % (case, i)
+        n_fin = min(100, int(np.isfinite(g[key]).sum())) if key in g.files else 1
+        for k in d:
+            if k == "lnZ":
+                continue
+            w = g["%s_res%d_%s" % (case, i, k)]
+            v = np.atleast_1d(np.asarray(d[k], dtype=float))
+            assert v.shape == w.shape
+            top = n_fin if v.size > 1 else 1
+            assert np.allclose(v[:top], w[:top], rtol=1e-12, atol=0), (case, i, k)

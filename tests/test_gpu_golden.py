@@ -180,3 +180,15 @@ def test_calc_probs_matches_cpu_checker():
     assert np.abs(tg.probs.prob.values - ck.probs.prob.values).max() < 1e-9
     assert abs(tg.FPP - ck.FPP) < 1e-9 and abs(tg.NFPP - ck.NFPP) < 1e-9
     assert list(tg.probs.scenario) == list(ck.probs.scenario)
+
+
+EXTRA = [str(c) for c in gold("lnz_extra.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", EXTRA)
+def test_unused_lnz_functions_end_to_end(case):
+    from helpers import call_extra, check_extra
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("lnz_extra.npz")
+    np.random.seed(int(g[case + "_seed"][0]))
+    check_extra(call_extra(ml, case, g), case, g, 1e-9)

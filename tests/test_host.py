@@ -193,3 +193,18 @@ def test_missing_ldc_combination_raises_like_the_reference(monkeypatch):
     assert u1.shape == (2,)
     with pytest.raises(ValueError):
         tab.companions(0.0, np.array([12400.0]), np.array([4.0]), 13000)
+
+
+EXTRA = [str(c) for c in gold("lnz_extra.npz")["cases"]]
+
+
+@pytest.mark.parametrize("case", EXTRA)
+def test_unused_lnz_functions_match_reference(case, monkeypatch):
+    """lnZ_NTP/NEB_unknown and _evolved: exported by the reference, never called by calc_probs
+    (SURVEY 8 row a9); quirks kept (one dict for an empty population, no u1/u2 keys, twin = host copy)"""
+    from helpers import call_extra, check_extra
+    install_cpu_device_fakes(monkeypatch)
+    from triceratops_amd import marginal_likelihoods as ml
+    g = gold("lnz_extra.npz")
+    np.random.seed(int(g[case + "_seed"][0]))
+    check_extra(call_extra(ml, case, g), case, g, 1e-10)

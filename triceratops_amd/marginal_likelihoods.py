@@ -4,7 +4,9 @@ Same entry points, positional signatures and return conventions as the reference
 triceratops/marginal_likelihoods.py for the ten functions calc_probs calls:
   lnZ_TTP (39-172), lnZ_TEB (175-383), lnZ_PTP (386-586), lnZ_PEB (589-866), lnZ_STP (869-1077),
   lnZ_SEB (1080-1376), lnZ_DTP (1379-1568), lnZ_DEB (1571-1837), lnZ_BTP (1840-2035),
-  lnZ_BEB (2038-2362).
+  lnZ_BEB (2038-2362),
+and for the four it only exports: lnZ_NTP_unknown (2365), lnZ_NEB_unknown (2554),
+lnZ_NTP_evolved (2832), lnZ_NEB_evolved (2969).
 TP family -> one dict, EB family -> (res, res_twin); every dict holds the 14 best-fit columns
 (100 draws, by decreasing lnL) and 'lnZ' (Python float, may be -inf).
 
@@ -296,14 +298,17 @@ def _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps
 
 def _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs, eccs,
                      argps, masses, radii, fluxratios, M_host, R_host, u1, u2, fr_comp, is_host,
-                     extra, lnprior):
-    """common tail of the five *EB scenarios: q < 0.95 at P_orb and q >= 0.95 at 2 P_orb"""
+                     extra, lnprior, twin_is_host_copy=False):
+    """common tail of the *EB scenarios: q < 0.95 at P_orb and q >= 0.95 at 2 P_orb.
+    twin_is_host_copy: lnZ_NEB_evolved treats the twin as a copy of the host (2 R_host in its
+    transit probability, R_host as its radius; marginal_likelihoods.py:3052, 3100)."""
     e_corr = _e_corr(eccs, argps)
     a = _sma(M_host + masses, P_orb)
     size = radii * Rsun + R_host * Rsun
     Ptra = size / a * e_corr
     a_twin = _sma(M_host + masses, 2 * P_orb)
-    Ptra_twin = size / a_twin * e_corr
+    size_twin = (R_host * Rsun + R_host * Rsun) if twin_is_host_copy else size
+    Ptra_twin = size_twin / a_twin * e_corr
     b = _impact(a, eccs, argps, incs, R_host)
     b_twin = _impact(a_twin, eccs, argps, incs, R_host)
     coll = size > a * (1 - eccs)
@@ -319,13 +324,14 @@ def _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, q
         mask, mask_twin = mask & extra, mask_twin & extra
     frc = 0.0 if fr_comp is None else fr_comp
     out = []
-    for model, m, per, sma, bb in ((MODEL_EB, mask, P_orb, a, b),
-                                   (MODEL_EB_TWIN, mask_twin, 2 * P_orb, a_twin, b_twin)):
-        cols = (radii, fluxratios, per, incs, sma, R_host, u1, u2, eccs, argps, frc)
+    r_twin = R_host if twin_is_host_copy else radii
+    for model, m, per, sma, bb, r_eb in ((MODEL_EB, mask, P_orb, a, b, radii),
+                                         (MODEL_EB_TWIN, mask_twin, 2 * P_orb, a_twin, b_twin, r_twin)):
+        cols = (r_eb, fluxratios, per, incs, sma, R_host, u1, u2, eccs, argps, frc)
         best, lnZ = _evidence(model, is_host, parallel, time, flux, sigma, cols, m, lnprior, N,
                              exptime, nsamples)
         out.append(_table(best, lnZ, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=per, inc=incs,
-                          b=bb, R_p=None, ecc=eccs, argp=argps, M_EB=masses, R_EB=radii,
+                          b=bb, R_p=None, ecc=eccs, argp=argps, M_EB=masses, R_EB=r_eb,
                           fluxratio_EB=fluxratios, fluxratio_comp=fr_comp))
     return out[0], out[1]
 
@@ -563,3 +569,114 @@ def lnZ_BEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, tr
     return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
                             eccs, argps, masses, radii, fluxratios, M_host, R_host, u1f[idxs],
                             u2f[idxs], fr_comp, True, extra, lnprior)
+
+
+# ---------------------------------------------------------------------------------------
+# exported by the reference but never called by calc_probs
+def _similar_field_stars(trilegal_fname, Tmag, mission):
+    """TRILEGAL stars within one magnitude of Tmag: the possible identities of a nearby star
+    of unknown properties (marginal_likelihoods.py:2402-2446)"""
+    Tmags, masses, loggs, Teffs, Zs, _, _, _ = trilegal_results(trilegal_fname, Tmag)
+    near = (Tmag - 1 < Tmags) & (Tmags < Tmag + 1)
+    masses, loggs, Teffs, Zs = masses[near], loggs[near], Teffs[near], Zs[near]
+    radii = np.sqrt(G * masses * Msun / 10 ** loggs) / Rsun
+    u1s, u2s = (_ldc(mission).field_stars(Teffs, loggs, Zs) if masses.size
+                else (np.zeros(0), np.zeros(0)))
+    return masses, radii, loggs, Teffs, u1s, u2s
+
+
+_EMPTY_KEYS = ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "R_p", "ecc", "argp", "M_EB", "R_EB",
+               "fluxratio_EB", "fluxratio_comp")
+
+
+def _empty_result(with_b):
+    """what the reference returns when no similar field star exists: scalar zeros and
+    lnZ = -inf; lnZ_NTP_unknown's dict has no 'b' entry, lnZ_NEB_unknown's has
+    (marginal_likelihoods.py:2450-2468, 2645-2665)"""
+    res = {k: 0 for k in _EMPTY_KEYS}
+    if with_b:
+        res["b"] = 0
+    res["lnZ"] = -np.inf
+    return res
+
+
+def lnZ_NTP_unknown(time, flux, sigma, P_orb, Tmag, trilegal_fname, N: int = 1000000,
+                    parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+                    exptime: float = 0.00139, nsamples: int = 20):
+    """Planet on a nearby star of unknown properties (marginal_likelihoods.py:2365-2551)."""
+    P_orb = _periods(P_orb, N)
+    masses_f, radii_f, loggs_f, Teffs_f, u1f, u2f = _similar_field_stars(trilegal_fname, Tmag, mission)
+    if masses_f.size == 0:
+        return _empty_result(with_b=False)
+    idxs = np.random.randint(0, masses_f.size, N)
+    M_host, R_host = masses_f[idxs], radii_f[idxs]
+    rps, incs, eccs, argps = _draw_planet(N, M_host, P_orb, flatpriors)
+    a = _sma(M_host, P_orb)
+    extra = (loggs_f[idxs] >= 3.5) & (Teffs_f[idxs] <= 10000)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_host, R_host, u1f[idxs], u2f[idxs], None, False, extra,
+                          None)
+
+
+def lnZ_NEB_unknown(time, flux, sigma, P_orb, Tmag, trilegal_fname, N: int = 1000000,
+                    parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+                    exptime: float = 0.00139, nsamples: int = 20):
+    """EB on a nearby star of unknown properties (marginal_likelihoods.py:2554-2829).  Like the
+    reference, an empty field population returns ONE dict although the normal return is two."""
+    P_orb = _periods(P_orb, N)
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), 1.0)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    masses_f, radii_f, loggs_f, Teffs_f, u1f, u2f = _similar_field_stars(trilegal_fname, Tmag, mission)
+    if masses_f.size == 0:
+        return _empty_result(with_b=True)
+    idxs = np.random.randint(0, masses_f.size, N)
+    M_host, R_host = masses_f[idxs], radii_f[idxs]
+    masses = qs * M_host
+    radii, _ = stellar_relations(masses, R_host, Teffs_f[idxs])
+    f_eb = flux_relation(masses)
+    fluxratios = f_eb / (f_eb + flux_relation(M_host))
+    extra = (loggs_f[idxs] >= 3.5) & (Teffs_f[idxs] <= 10000)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_host, R_host, u1f[idxs],
+                            u2f[idxs], None, False, extra, None)
+
+
+def _evolved_host(R_s, Teff, Z, mission):
+    """a subgiant of log g = 3.0 and radius R_s (marginal_likelihoods.py:2868-2891)"""
+    logg = 3.0
+    M_s = (10 ** logg) * (R_s * Rsun) ** 2 / G / Msun
+    u1, u2 = _ldc(mission).star(Z, Teff, logg)
+    return M_s, u1, u2
+
+
+def lnZ_NTP_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
+                    parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+                    exptime: float = 0.00139, nsamples: int = 20):
+    """Planet on an evolved nearby star (marginal_likelihoods.py:2832-2966)."""
+    P_orb = _periods(P_orb, N)
+    M_s, u1, u2 = _evolved_host(R_s, Teff, Z, mission)
+    rps, incs, eccs, argps = _draw_planet(N, np.full(N, M_s), P_orb, flatpriors)
+    a = _sma(M_s, P_orb)
+    return _planet_branch(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, rps, incs,
+                          eccs, argps, a, M_s, R_s, u1, u2, None, False, None, None)
+
+
+def lnZ_NEB_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
+                    parallel: bool = False, mission: str = "TESS", flatpriors: bool = False,
+                    exptime: float = 0.00139, nsamples: int = 20):
+    """EB on an evolved nearby star (marginal_likelihoods.py:2969-3178).  Reference quirk kept:
+    the twin is a copy of the host (2 R_s in Ptra_twin, R_s as its radius)."""
+    P_orb = _periods(P_orb, N)
+    M_s, u1, u2 = _evolved_host(R_s, Teff, Z, mission)
+    incs = sample_inc(np.random.rand(N))
+    qs = sample_q(np.random.rand(N), 1.0)
+    eccs = sample_ecc(np.random.rand(N), planet=False, P_orb=np.mean(P_orb))
+    argps = sample_w(np.random.rand(N))
+    masses = qs * M_s
+    radii, _ = stellar_relations(masses, np.full(N, R_s), np.full(N, Teff))
+    fluxratios = _flux_share(masses, M_s)
+    return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
+                            eccs, argps, masses, radii, fluxratios, M_s, R_s, u1, u2, None, False,
+                            None, None, twin_is_host_copy=True)
