@@ -333,7 +333,86 @@ def main():
                         logw=logws[0], block=np.stack(captured[0][1] + [np.zeros_like(captured[0][1][0])]),
                         out=captured[0][3],
                         **{"res_" + k: np.asarray(v, dtype=float) for k, v in res.items() if k != "lnZ"})
+    # ---- (5) the reference's own target.calc_depths / calc_probs -------------------------------
+    # triceratops/triceratops.py imports the catalogue / plotting stack at module level; stub it.
+    # The object is created without running __init__ (which queries MAST/TessCut/TRILEGAL).
+    for name in ("lightkurve", "astroquery", "astroquery.mast", "astroquery.vizier",
+                 "astropy.coordinates", "astropy.wcs", "astropy.wcs.utils", "astropy.units"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["astroquery.mast"].Catalogs = object
+    sys.modules["astroquery.mast"].Tesscut = object
+    sys.modules["astroquery.vizier"].Vizier = object
+    sys.modules["astropy.coordinates"].SkyCoord = object
+    sys.modules["astropy.wcs"].WCS = object
+    sys.modules["astropy.wcs.utils"].pixel_to_skycoord = object
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    import triceratops.triceratops as rtr
+    # the lnZ_* were star-imported into rtr at import time, before the capture wrappers existed
+    write_molusc(os.path.join(HERE, "molusc_synth.csv"), np.random.default_rng(5))
+
+    def stars_table():
+        return pd.DataFrame({
+            "ID": [111, 222, 333, 444], "Tmag": [10.4, 13.0, 15.5, 12.2],
+            "Jmag": [9.5, 12.1, 14.6, 11.5], "Hmag": [9.1, 11.7, 14.2, 11.1],
+            "Kmag": [9.0, 11.6, 14.1, 11.0], "ra": [10.0, 10.004, 10.01, 9.99],
+            "dec": [-5.0, -5.003, -5.01, -4.995], "mass": [0.82, 0.6, np.nan, 1.1],
+            "rad": [0.8, 0.58, np.nan, 1.3], "Teff": [5100.0, 4000.0, np.nan, 6000.0],
+            "plx": [14.2, 3.0, np.nan, 2.0]})
+
+    def ref_target(stars):
+        tg = object.__new__(rtr.target)
+        tg.ID, tg.mission, tg.sectors, tg.search_radius, tg.N_pix = 111, "TESS", np.array([1]), 10, 22
+        tg.stars, tg.trilegal_fname, tg.trilegal_url = stars, tri_path, None
+        tg.pix_coords = [np.array([[10.2, 10.7], [11.9, 11.3], [14.0, 7.5], [8.4, 12.6]]),
+                         np.array([[10.6, 10.1], [12.2, 10.9], [14.5, 7.0], [8.9, 12.0]])]
+        return tg
+
+    cp = {}
+    tg = ref_target(stars_table())
+    aps = [np.array([[x, y] for x in range(9, 12) for y in range(10, 13)]),
+           np.array([[x, y] for x in range(9, 13) for y in range(9, 12)])]
+    tg.calc_depths(0.007, aps)
+    cp["depths_fluxratio"], cp["depths_tdepth"] = tg.stars["fluxratio"].values, tg.stars["tdepth"].values
+    for i, a_ in enumerate(aps):
+        cp["aperture%d" % i] = a_
+    tg5 = ref_target(stars_table())
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        tg5.calc_depths(0.007)                        # default 5x5 apertures
+    cp["depths5_fluxratio"], cp["depths5_tdepth"] = tg5.stars["fluxratio"].values, tg5.stars["tdepth"].values
+    runs = {
+        "cc": dict(contrast_curve_file=cc_path, filt="J", drop_scenario=[]),
+        "molusc": dict(contrast_curve_file=None, filt="TESS", drop_scenario=["DEB", "BTP"],
+                       molusc_file=os.path.join(HERE, "molusc_synth.csv")),
+    }
+    for rname, kw in runs.items():
+        np.random.seed(777)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tg.calc_probs(t, f, sigma, 3.3, N=1500, parallel=True, verbose=0, **kw)
+        pr = tg.probs
+        cp[rname + "_lnZ"], cp[rname + "_prob"] = np.array(tg.lnZ), pr["prob"].values
+        cp[rname + "_FPP"], cp[rname + "_NFPP"] = np.array([tg.FPP]), np.array([tg.NFPP])
+        cp[rname + "_scenario"] = np.array(list(pr["scenario"]))
+        cp[rname + "_ID"], cp[rname + "_star_num"] = pr["ID"].values, np.array(tg.star_num)
+        for col in ("M_s", "R_s", "P_orb", "inc", "b", "ecc", "w", "R_p", "M_EB", "R_EB"):
+            cp[rname + "_" + col] = pr[col].values
+        cp[rname + "_u1"], cp[rname + "_u2"] = np.array(tg.u1), np.array(tg.u2)
+        cp[rname + "_fluxratio_EB"], cp[rname + "_fluxratio_comp"] = (np.array(tg.fluxratio_EB),
+                                                                      np.array(tg.fluxratio_comp))
+    cp["time"], cp["flux"], cp["sigma"] = t, f, np.array([sigma])
+    np.savez_compressed(os.path.join(HERE, "calc_probs.npz"), **cp)
     print("wrote", sorted(os.listdir(HERE)))
+
+
+def write_molusc(path, rng, n=900):
+    """synthetic MOLUSC output with the three columns marginal_likelihoods.py:458-462 reads"""
+    import pandas as pd
+    pd.DataFrame({"semi-major axis(AU)": 10 ** rng.uniform(0, 3, n),
+                  "eccentricity": rng.uniform(0, 0.9, n),
+                  "mass ratio": rng.uniform(0.02, 1.0, n)}).to_csv(path, index=False)
 
 
 def _with_N(plan, name, rml, b, s, tri_path, n, P, kw):

@@ -1,0 +1,113 @@
+"""target.calc_depths / target.calc_probs against the reference's OWN class methods
+(triceratops.py:559-671, 673-1485), run in the build container by tests/golden/make_golden.py
+section 5 on an object created without the network constructor.
+
+CPU variant: device calls replaced by the oracle stand-in (checks the driver logic end to end:
+unit order on the random stream, renormalisation per star, NaN -> solar defaults, drop_scenario,
+MOLUSC path, probability table, FPP / NFPP).  GPU variant: the real kernels, same goldens.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import GOLD, gold, install_cpu_device_fakes
+
+G = gold("calc_probs.npz")
+
+
+def _stars():
+    return pd.DataFrame({
+        "ID": [111, 222, 333, 444], "Tmag": [10.4, 13.0, 15.5, 12.2],
+        "Jmag": [9.5, 12.1, 14.6, 11.5], "Hmag": [9.1, 11.7, 14.2, 11.1],
+        "Kmag": [9.0, 11.6, 14.1, 11.0], "ra": [10.0, 10.004, 10.01, 9.99],
+        "dec": [-5.0, -5.003, -5.01, -4.995], "mass": [0.82, 0.6, np.nan, 1.1],
+        "rad": [0.8, 0.58, np.nan, 1.3], "Teff": [5100.0, 4000.0, np.nan, 6000.0],
+        "plx": [14.2, 3.0, np.nan, 2.0]})
+
+
+def _target():
+    from triceratops_amd.triceratops import target
+    pix = [np.array([[10.2, 10.7], [11.9, 11.3], [14.0, 7.5], [8.4, 12.6]]),
+           np.array([[10.6, 10.1], [12.2, 10.9], [14.5, 7.0], [8.9, 12.0]])]
+    return target(111, np.array([1]), stars=_stars(), pix_coords=pix,
+                  trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"))
+
+
+def test_calc_depths_matches_reference(capsys):
+    tg = _target()
+    tg.calc_depths(0.007, [G["aperture0"], G["aperture1"]])
+    assert np.allclose(tg.stars["fluxratio"].values, G["depths_fluxratio"], rtol=1e-13, atol=0)
+    assert np.allclose(tg.stars["tdepth"].values, G["depths_tdepth"], rtol=1e-12, atol=0)
+    t5 = _target()
+    t5.calc_depths(0.007)                       # default: 5x5 pixels centred on the target
+    assert "No apertures provided" in capsys.readouterr().out
+    assert np.allclose(t5.stars["fluxratio"].values, G["depths5_fluxratio"], rtol=1e-13, atol=0)
+    assert np.allclose(t5.stars["tdepth"].values, G["depths5_tdepth"], rtol=1e-12, atol=0)
+    # analytic PSF integral = Phi differences (reference tests/test_analytic_psf.py): a star
+    # centred in a huge aperture contributes all of its flux
+    from scipy.special import ndtr
+    assert abs((ndtr(50 / 0.75) - ndtr(-50 / 0.75)) - 1.0) < 1e-15
+
+
+RUNS = {
+    "cc": dict(contrast_curve_file=os.path.join(GOLD, "contrast_curve_synth.csv"), filt="J",
+               drop_scenario=[]),
+    "molusc": dict(contrast_curve_file=None, filt="TESS", drop_scenario=["DEB", "BTP"],
+                   molusc_file=os.path.join(GOLD, "molusc_synth.csv")),
+}
+
+
+def _run_and_check(rname, tol):
+    tg = _target()
+    tg.calc_depths(0.007, [G["aperture0"], G["aperture1"]])
+    np.random.seed(777)
+    tg.calc_probs(G["time"], G["flux"], float(G["sigma"][0]), 3.3, N=1500, parallel=True,
+                  verbose=0, **RUNS[rname])
+    want_lnz = G[rname + "_lnZ"]
+    fin = np.isfinite(want_lnz)
+    assert np.array_equal(fin, np.isfinite(tg.lnZ))
+    assert np.array_equal(np.isneginf(want_lnz), np.isneginf(tg.lnZ))
+    assert np.abs(tg.lnZ[fin] - want_lnz[fin]).max() < tol
+    assert list(tg.probs.scenario) == [str(s) for s in G[rname + "_scenario"]]
+    assert np.array_equal(tg.probs.ID.values, G[rname + "_ID"])
+    assert np.array_equal(tg.star_num, G[rname + "_star_num"])
+    assert np.abs(tg.probs.prob.values - G[rname + "_prob"]).max() < tol
+    assert abs(tg.FPP - G[rname + "_FPP"][0]) < tol and abs(tg.NFPP - G[rname + "_NFPP"][0]) < tol
+    for col in ("M_s", "R_s", "P_orb", "inc", "b", "ecc", "w", "R_p", "M_EB", "R_EB"):
+        assert np.allclose(tg.probs[col].values, G[rname + "_" + col], rtol=1e-12, atol=0), col
+    for attr in ("u1", "u2", "fluxratio_EB", "fluxratio_comp"):
+        assert np.allclose(getattr(tg, attr), G[rname + "_" + attr], rtol=1e-12, atol=0), attr
+    assert tg.FPP_degenerate is False
+    return tg
+
+
+@pytest.mark.parametrize("rname", sorted(RUNS))
+def test_calc_probs_matches_reference_host_logic(rname, monkeypatch):
+    install_cpu_device_fakes(monkeypatch)
+    tg = _run_and_check(rname, 1e-10)
+    if rname == "molusc":
+        for j in (10, 11, 12):                       # dropped DEB, DEBx2P, BTP
+            assert tg.lnZ[j] == -np.inf and tg.probs.prob[j] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rname", sorted(RUNS))
+def test_calc_probs_matches_reference_on_gpu(rname):
+    _run_and_check(rname, 1e-9)
+
+
+def test_degenerate_evidence_warnings(monkeypatch):
+    """all scenarios dropped / impossible -> RuntimeWarning + FPP_degenerate (triceratops.py:1431-1452)"""
+    install_cpu_device_fakes(monkeypatch)
+    tg = _target()
+    tg.stars["fluxratio"] = [1.0, 0.0, 0.0, 0.0]
+    tg.stars["tdepth"] = [0.007, 0.0, 0.0, 0.0]
+    with pytest.warns(RuntimeWarning, match="All scenario log-evidences are -inf"):
+        tg.calc_probs(G["time"], G["flux"], float(G["sigma"][0]), 3.3, N=50, parallel=True, verbose=0,
+                      drop_scenario=["TP", "EB", "PTP", "PEB", "STP", "SEB", "DTP", "DEB", "BTP", "BEB"])
+    assert tg.FPP_degenerate is True and tg.FPP == 1.0 and tg.NFPP == 0.0
+    with pytest.raises(ValueError, match="trilegal_fname"):
+        tg.trilegal_fname = None
+        tg.calc_probs(G["time"], G["flux"], float(G["sigma"][0]), 3.3, N=50, verbose=0)
