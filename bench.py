@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--n-time", type=int, default=N_TIME)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
+    # with every rank on cuda:0 and a gloo process group (RCCL refuses two ranks on one device)
+    ap.add_argument("--debug-single-device", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -58,14 +61,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    debug_one = args.debug_single_device
+    if world > 1 and not debug_one:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     _lib.require_gpu()
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
+
+    def gather(dst, src):
+        if debug_one:                      # gloo moves host tensors
+            buf = torch.empty(dst.numel(), dtype=dst.dtype)
+            dist.all_gather_into_tensor(buf, src.cpu())
+            dst.copy_(buf)
+        else:
+            dist.all_gather_into_tensor(dst, src)
 
     n_time, n_rows = args.n_time, args.n_samples
     fams = synth.FAMILIES
@@ -101,7 +117,7 @@ def main():
             lnz.append(_lib.lnz_from_halfchi2(h_d[i], lnprior_d[i], n_total, lnsigma))
         mine = torch.cat(lnz)
         if world > 1:
-            dist.all_gather_into_tensor(lnz_all, mine)
+            gather(lnz_all, mine)          # the single data-path collective (RCCL over xGMI)
         else:
             lnz_all.copy_(mine)
         return lnz_all
@@ -121,7 +137,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if debug_one else device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
 

@@ -72,6 +72,36 @@ __device__ __forceinline__ double sqrt_fast(double x)
     return s;
 }
 
+// the same for arguments known to be > 0 (no zero guard)
+__device__ __forceinline__ void sqrt_rsqrt_pos(double x, double& s, double& rs)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    s = fma(d, h, g);
+    rs = 2.0 * h;
+}
+
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    double s, rs;
+    sqrt_rsqrt_pos(x, s, rs);
+    return s;
+}
+
+// x reduced to [-pi, pi] (two-word 2 pi under fma; error ~1e-16 |x| for |x| < ~1e9)
+__device__ __forceinline__ double reduce_2pi(double x)
+{
+    const double n = rint(x * 0.15915494309189533577);   // 1/(2 pi)
+    return fma(-n, 2.44929359829470641435e-16, fma(-n, 6.28318530717958623200e+00, x));
+}
+
 // sin and cos for |x| up to ~1e5 (orbit angles): Cody-Waite reduction by pi/2 with a
 // two-word pi/2 under fma, fdlibm kernel polynomials on [-pi/4, pi/4].
 __device__ __forceinline__ void sincos_red(double x, double& s, double& c)
@@ -95,6 +125,31 @@ __device__ __forceinline__ void sincos_red(double x, double& s, double& c)
     const double c0 = (q & 1) ? sr : cr;
     s = (q & 2) ? -s0 : s0;
     c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// atan(x) for x >= 0 (x = +inf allowed): the four-breakpoint argument reduction and the
+// degree-10 odd minimax polynomial of fdlibm's s_atan.c, selected without branches; one
+// reciprocal.
+__device__ __forceinline__ double atan_pos(double x)
+{
+    const bool r0 = x < 0.4375, r1 = x < 0.6875, r2 = x < 1.1875, r3 = x < 2.4375;
+    // t = num / den
+    const double num = r0 ? x : (r1 ? fma(2.0, x, -1.0) : (r2 ? x - 1.0 : (r3 ? x - 1.5 : -1.0)));
+    const double den = r0 ? 1.0 : (r1 ? 2.0 + x : (r2 ? x + 1.0 : (r3 ? fma(1.5, x, 1.0) : x)));
+    const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01
+                         : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
+    const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17
+                         : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
+    const double t = (den > 1.7e308) ? 0.0 : num * rcp_fast(den);
+    const double z = t * t, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02,
+                      4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                      9.09088713343650656196e-02), 1.42857142725034663711e-01),
+                      3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02,
+                      -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                      -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    return hi - ((t * (s1 + s2) - lo) - t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -124,7 +179,7 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
         g = em;
         em += q;
         if (fabs(g - q) <= g * 1e-8) break;
-        q = 2.0 * sqrt_fast(e);
+        q = 2.0 * sqrt_pos(e);
         e = q * em;
     }
     const double d1 = em * (em + p1), d2 = em * (em + pp);
@@ -182,7 +237,7 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         contact = (g1 == 0.0);
         const double oma = f2 * f3;
         double so, rso;
-        sqrt_rsqrt(oma, so, rso);
+        sqrt_rsqrt_pos(oma, so, rso);
         kc2 = g1 * f4 * rso * rso;
         al = 1.0 - 5.0 * z2 + p2 + q * q;
         be = oma * t7;
@@ -192,15 +247,17 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         scale = (2.0 / (9.0 * kPi)) * rso;
     } else {
         const double f1 = (p < 1.0) ? (z - omp) : (z + (p - 1.0));
-        const double s14 = sqrt_fast(f1 * f4), s23 = sqrt_fast(f2 * f3);
-        const double kap0 = 2.0 * atan2(s23, s14);
-        const double kap1 = 2.0 * atan2(sqrt_fast(f1 * f2), sqrt_fast(f3 * f4));
-        const double area4 = s14 * s23;
+        // contact triangle (sides 1, p, z): one square root, area4 = 4 x area; the half-angle
+        // tangents are sqrt(f2 f3 / (f1 f4)) = area4/(f1 f4) and sqrt(f1 f2 / (f3 f4)) = area4/(f3 f4)
+        const double f14 = f1 * f4, f34 = f3 * f4;
+        const double area4 = sqrt_fast(f14 * (f2 * f3));
+        const double kap0 = 2.0 * atan_pos((f14 > 0.0) ? area4 * rcp_fast(f14) : INFINITY);
+        const double kap1 = 2.0 * atan_pos(area4 * rcp_fast(f34));
         le = (p2 * kap0 + kap1 - 0.5 * area4) * (1.0 / kPi);
         ed = (kap1 + 2.0 * eta2 * kap0 - 0.25 * (1.0 + 5.0 * p2 + z2) * area4) * (1.0 / kTwoPi);
         const double fzp = 4.0 * z * p;
         double sz, rsz;
-        sqrt_rsqrt(fzp, sz, rsz);
+        sqrt_rsqrt_pos(fzp, sz, rsz);
         kc2 = f1 * f4 * rsz * rsz;
         al = (1.0 - b) * (2.0 * b + a - 3.0) - 3.0 * q * (b - 2.0);
         be = fzp * t7;
@@ -226,7 +283,7 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
 // leaves an error ~ step^3, and (sin, cos) follow by a third-order update.
 __device__ __forceinline__ void kepler_full(double M, double e, double& sE, double& cE)
 {
-    M = remainder(M, kTwoPi);
+    M = reduce_2pi(M);
     const double sgn = (M < 0.0) ? -1.0 : 1.0;
     const double m = fabs(M);
     double lo = m, hi = fmin(m + e, kPi);
@@ -378,8 +435,11 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
                                                 double exptime, int S, bool stepping)
 {
-    const double dMc = remainder(c.nmot * (t - c.t0), kTwoPi);
-    if (!in_window(c.wlo, c.whi, dMc)) return 1.0;
+    const double phase = c.nmot * (t - c.t0);
+    const double dMc = reduce_2pi(phase);
+    // the reduction is good to ~1e-16 |phase|: widen the window by that much
+    const double slack = 1e-15 * fabs(phase);
+    if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return 1.0;
     const double opp = 1.0 + c.k;
     const double opp2 = opp * opp;
     const double dS = (double)S;
