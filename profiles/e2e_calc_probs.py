@@ -14,8 +14,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=1_000_000)
 ap.add_argument("--nearby", type=int, default=20)
 ap.add_argument("--n-time", type=int, default=100)
+ap.add_argument("--sampling", default="numpy", choices=["numpy", "device"])
 args = ap.parse_args()
 
+import triceratops_amd
 from triceratops_amd import _lib, synth
 from triceratops_amd.triceratops import target
 
@@ -34,7 +36,9 @@ stars = pd.DataFrame({
     "Teff": np.r_[5100.0, rng.uniform(3500, 6500, n - 1)], "plx": np.r_[14.2, rng.uniform(1, 5, n - 1)],
     "fluxratio": np.r_[0.9, np.full(n - 1, 0.1 / max(n - 1, 1))], "tdepth": np.r_[0.008, np.full(n - 1, 0.3)]})
 tg = target(100, np.array([1]), stars=stars, trilegal_fname=os.path.join(G, "trilegal_synth.csv"))
+triceratops_amd.set_sampling(args.sampling)
 np.random.seed(1)
+torch.manual_seed(1)
 kw = dict(P_orb=3.0, contrast_curve_file=os.path.join(G, "contrast_curve_synth.csv"), filt="J",
           N=args.N, parallel=True, verbose=0)
 tg.calc_probs(t, flux, synth.SIGMA, **dict(kw, N=2000))      # warm-up (library load, LDC tables)
@@ -43,5 +47,5 @@ t0 = time.perf_counter()
 tg.calc_probs(t, flux, synth.SIGMA, **kw)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("calc_probs: N=%d, %d points, %d scenarios: %.2f s   FPP=%.4g NFPP=%.4g" % (
-    args.N, args.n_time, len(tg.lnZ), dt, tg.FPP, tg.NFPP))
+print("calc_probs[%s sampling]: N=%d, %d points, %d scenarios: %.2f s   FPP=%.4g NFPP=%.4g" % (
+    args.sampling, args.N, args.n_time, len(tg.lnZ), dt, tg.FPP, tg.NFPP))

@@ -5,3 +5,10 @@ Mirrors the reference's module layout for this path only:
 Compute runs in hand-written HIP kernels behind the C ABI of include/trx.h (libtrx.so).
 """
 __version__ = "0.1.0"
+
+
+def set_sampling(mode):
+    """'numpy' (default): priors sampled on the host from numpy's global stream, draw-for-draw
+    reproducible against the reference; 'device': the whole scenario on the GPU."""
+    from .marginal_likelihoods import set_sampling as _set
+    _set(mode)

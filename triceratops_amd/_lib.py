@@ -98,6 +98,12 @@ def require_gpu():
                        "CPU fallback")
 
 
+def compute_device():
+    """the current GPU as a torch.device (raises without one)"""
+    require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 # ---------------------------------------------------------------------------------------
 # device helpers
 def dev(x, device=None):

@@ -680,3 +680,32 @@ def lnZ_NEB_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
     return _binary_branches(time, flux, sigma, N, parallel, exptime, nsamples, P_orb, qs, incs,
                             eccs, argps, masses, radii, fluxratios, M_s, R_s, u1, u2, None, False,
                             None, None, twin_is_host_copy=True)
+
+
+# ---------------------------------------------------------------------------------------
+# where the priors are sampled: "numpy" (host, reproduces the reference's random stream draw for
+# draw) or "device" (whole scenario on the GPU, triceratops_amd/device_pipeline.py)
+_sampling = {"mode": "numpy"}
+
+
+def set_sampling(mode):
+    if mode not in ("numpy", "device"):
+        raise ValueError("sampling mode must be 'numpy' or 'device'")
+    _sampling["mode"] = mode
+
+
+def _dispatch(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if _sampling["mode"] == "device":
+            from . import device_pipeline
+            return getattr(device_pipeline, fn.__name__)(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+for _name in ("lnZ_TTP", "lnZ_TEB", "lnZ_PTP", "lnZ_PEB", "lnZ_STP", "lnZ_SEB", "lnZ_DTP", "lnZ_DEB",
+              "lnZ_BTP", "lnZ_BEB"):
+    globals()[_name] = _dispatch(globals()[_name])

@@ -104,7 +104,10 @@ def run_units(units, verbose=0):
                   + ("y" if len(names) == 1 else "ies") + " for " + str(ID)
                   + (" [rank %d]" % rank if dist else "") + ".")
         if base is not None:
-            np.random.seed((base + 7919 * (k + 1)) % (2 ** 32))
+            unit_seed = (base + 7919 * (k + 1)) % (2 ** 32)
+            np.random.seed(unit_seed)
+            import torch
+            torch.manual_seed(unit_seed)             # device-side sampling (set_sampling("device"))
         table[offs[k]:offs[k] + rows[k]] = _record(fn())
 
     if dist:
