@@ -404,6 +404,24 @@ def main():
                                                                       np.array(tg.fluxratio_comp))
     cp["time"], cp["flux"], cp["sigma"] = t, f, np.array([sigma])
     np.savez_compressed(os.path.join(HERE, "calc_probs.npz"), **cp)
+
+    # ---- (6) TOI-1228 (BASELINE north-star case): the reference's calc_probs on the tutorial's
+    # light curve, contrast curve and star table (examples/TSCIII_tutorial.ipynb cells 5, 7, 18, 20;
+    # the TRILEGAL table is synthetic and there is no MOLUSC file: neither is in the tree)
+    tb, fb, sg = binned_toi1228()
+    t1228 = object.__new__(rtr.target)
+    t1228.ID, t1228.mission, t1228.sectors = 300038935, "TESS", np.array([1])
+    t1228.search_radius, t1228.N_pix, t1228.trilegal_fname, t1228.trilegal_url = 10, 22, tri_path, None
+    t1228.stars = toi1228_stars()
+    np.random.seed(1228)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t1228.calc_probs(tb, fb, sg, 29.04992, contrast_curve_file=os.path.join(HERE, "toi1228_cc.csv"),
+                         filt="TESS", N=4000, parallel=True, verbose=0)
+    np.savez_compressed(os.path.join(HERE, "toi1228_calc_probs.npz"), time=tb, flux=fb,
+                        sigma=np.array([sg]), lnZ=np.array(t1228.lnZ), prob=t1228.probs["prob"].values,
+                        FPP=np.array([t1228.FPP]), NFPP=np.array([t1228.NFPP]),
+                        scenario=np.array(list(t1228.probs["scenario"])), N=np.array([4000]),
+                        seed=np.array([1228]))
     print("wrote", sorted(os.listdir(HERE)))
 
 
@@ -430,6 +448,27 @@ def _with_N(plan, name, rml, b, s, tri_path, n, P, kw):
         "BTP": lambda: rml.lnZ_BTP(*base, *mags), "BEB": lambda: rml.lnZ_BEB(*base, *mags),
     }
     return table[name]()
+
+
+
+
+def toi1228_stars():
+    """the six stars with tdepth > 0 of examples/TSCIII_tutorial.ipynb cell 18 (notebook output)"""
+    import pandas as pd
+    return pd.DataFrame({
+        "ID": [300038935, 300038933, 300038940, 300038932, 300038925, 300038947],
+        "Tmag": [9.0963, 14.2544, 14.8737, 17.0169, 14.2296, 12.4406],
+        "Jmag": [8.887, 13.082, 13.832, 16.356, 13.282, 11.452],
+        "Hmag": [8.854, 12.418, 13.213, 15.803, 12.879, 10.912],
+        "Kmag": [8.823, 12.225, 13.137, 15.684, 12.705, 10.810],
+        "ra": [107.843696, 107.852043, 107.848770, 107.860272, 107.852177, 107.874142],
+        "dec": [-68.833491, -68.832404, -68.839563, -68.829404, -68.817218, -68.852895],
+        "mass": [2.13, 0.58456, 0.75, 0.96, 0.88, np.nan],
+        "rad": [1.79626, 0.595692, 0.641739, 0.580447, 0.863853, 3.22447],
+        "Teff": [8557.0, 3922.0, 4690.0, 5484.0, 5192.0, 4986.0],
+        "plx": [3.64491, 3.70654, 1.93455, 0.565248, 1.5691, 1.04073],
+        "fluxratio": [0.979954, 0.008361, 0.004675, 0.000589, 0.001471, 0.003010],
+        "tdepth": [0.000415, 0.048680, 0.087064, 0.690429, 0.276603, 0.135210]})
 
 
 if __name__ == "__main__":
