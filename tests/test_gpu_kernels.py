@@ -218,3 +218,54 @@ def test_full_size_properties():
     c = curve.cpu().numpy()
     assert np.abs(c - c[::-1]).max() < 1e-13
     assert c.min() < 1 - 0.07 ** 2 and c.max() == 1.0
+
+
+def test_entry_points_capture_into_a_hip_graph_and_replay():
+    """include/trx.h promises: no allocation, no sync, stream-ordered -> capturable"""
+    rng, t, flux = _lc(300)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    rows_d = _lib.dev(synth.tp_rows(rng, 2000, True))
+    prior_d = _lib.dev(rng.uniform(-5, 0, 2000))
+    h_d = torch.empty(2000, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, out=h_d)     # warm-up
+        _lib.lnz_from_halfchi2(h_d, prior_d, 20000, np.log(synth.SIGMA))
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, out=h_d)
+        lnz_d = _lib.lnz_from_halfchi2(h_d, prior_d, 20000, np.log(synth.SIGMA))
+    for rep in range(2):
+        rows = synth.tp_rows(rng, 2000, True)
+        rows_d.copy_(_lib.dev(rows))              # new inputs in the captured buffers
+        h_d.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        want_h = O.lnl_batch(0, t, flux, synth.SIGMA, rows)
+        _cmp_h(h_d.cpu().numpy(), want_h)
+        lnL = np.full(20000, -np.inf)
+        lnL[:2000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h + prior_d.cpu().numpy()
+        assert abs(float(lnz_d.cpu()[0]) - O.log_mean_exp(lnL, 20000)) < 1e-9
+
+
+def test_concurrent_streams_do_not_interfere():
+    rng, t, flux = _lc(256)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    blocks = [synth.eb_rows(rng, 3000, has_companion=True) for _ in range(4)]
+    devs = [_lib.dev(b) for b in blocks]
+    streams = [torch.cuda.Stream() for _ in blocks]
+    outs = []
+    torch.cuda.synchronize()
+    for st, d in zip(streams, devs):
+        with torch.cuda.stream(st):
+            outs.append(_lib.lnz_scenario(1, 0, t_d, f_d, synth.SIGMA, d, synth.EXPTIME, 20, None,
+                                          30000, np.log(synth.SIGMA)))
+    torch.cuda.synchronize()
+    for (h, lnz), b in zip(outs, blocks):
+        want_h = O.lnl_batch(1, t, flux, synth.SIGMA, b)
+        _cmp_h(h.cpu().numpy(), want_h)
+        lnL = np.full(30000, -np.inf)
+        lnL[:3000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h
+        assert abs(float(lnz.cpu()[0]) - O.log_mean_exp(lnL, 30000)) < 1e-9

@@ -123,7 +123,8 @@ _ws = {}
 
 
 def workspace(device):
-    key = (device.type, device.index)
+    """LME scratch, one per (device, stream): calls on different streams may overlap"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _ws:
         nbytes = lib().trx_workspace_bytes()
         _ws[key] = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=device)
