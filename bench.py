@@ -49,6 +49,9 @@ def parse():
     # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
     # with every rank on cuda:0 and a gloo process group (RCCL refuses two ranks on one device)
     ap.add_argument("--debug-single-device", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fp32-model", action="store_true",
+                    help="BASELINE config 5: fp32 Mandel-Agol arithmetic, fp64 orbit/chi^2/log-mean-exp "
+                         "(flux within 1e-6, chi^2/2 within 2e-4 relative of the fp64 path)")
     return ap.parse_args()
 
 
@@ -107,7 +110,7 @@ def main():
     def step(events=None):
         lnz = []
         for i, (name, model, is_host, has_comp) in enumerate(fams):
-            flags = _lib.FLAG_COMPANION_IS_HOST if is_host else 0
+            flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0)
             if events is not None:
                 events[i][0].record()
             _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME,
@@ -202,7 +205,7 @@ def main():
             "metric": "light-curve-point x sample evals/sec", "value": value,
             "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: synthetic %d-point light curve, 18 "
                                    "scenario families x %d transiting rows, nsamples=%d supersampling, "
                                    "fused lnL + log-mean-exp" % (n_time, n_rows, synth.NSAMPLES),

@@ -45,6 +45,10 @@ extern "C" {
                                         secondary (likelihoods.py:121-123, 137) instead of the vector
                                         path's `(k-1)<1e-6` on both (likelihoods.py:406, 418) */
 
+#define TRX_FLAG_FP32_MODEL         4 /* mixed precision (BASELINE config 5): fp64 orbit and geometric
+                                        differences, fp32 Mandel-Agol arithmetic, fp64 chi^2 and
+                                        log-mean-exp accumulation; ~1e-7 absolute in flux */
+
 /* parameter-block rows, SoA [n_param][n] contiguous fp64 (reference argument order):
  *   TP  (10): R_p[R_earth] P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio
  *   EB  (11): R_EB[R_sun] EB_fluxratio P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio

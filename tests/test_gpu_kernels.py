@@ -250,6 +250,32 @@ def test_entry_points_capture_into_a_hip_graph_and_replay():
         assert abs(float(lnz_d.cpu()[0]) - O.log_mean_exp(lnL, 20000)) < 1e-9
 
 
+@pytest.mark.parametrize("n_time", [200, 2000])
+def test_mixed_precision_model_tolerance(n_time):
+    """TRX_FLAG_FP32_MODEL (BASELINE config 5): fp64 orbit and geometric differences, fp32
+    Mandel-Agol arithmetic, fp64 chi^2 / log-mean-exp.  Stated tolerance vs the fp64 path:
+    flux 1e-6 absolute, chi^2/2 2e-4 relative, identical exclusion pattern."""
+    rng, t, flux = _lc(n_time, seed=3)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    for model, rows in ((0, synth.tp_rows(rng, 3000, True)), (1, synth.eb_rows(rng, 3000, False, True)),
+                        (2, synth.eb_rows(rng, 3000, True))):
+        r_d = _lib.dev(rows)
+        g64, s64 = _lib.flux_grid(model, 0, t_d, r_d[:, :500].contiguous(), synth.EXPTIME, 20)
+        g32, s32 = _lib.flux_grid(model, _lib.FLAG_FP32_MODEL, t_d, r_d[:, :500].contiguous(), synth.EXPTIME, 20)
+        assert float((g32 - g64).abs().max()) < 1e-6
+        h64 = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20)
+        h32 = _lib.lnl_batch(model, _lib.FLAG_FP32_MODEL, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20)
+        fin = torch.isfinite(h64)
+        assert bool((torch.isfinite(h32) == fin).all())
+        assert float(((h32 - h64)[fin].abs() / h64[fin]).max()) < 2e-4
+        # evidence level: the same rows reduced with log-mean-exp
+        c0 = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA)
+        z64 = float(_lib.lnz_from_halfchi2(h64, None, 30000, np.log(synth.SIGMA)).cpu()[0])
+        z32 = float(_lib.lnz_from_halfchi2(h32, None, 30000, np.log(synth.SIGMA)).cpu()[0])
+        if np.isfinite(z64):
+            assert abs(z32 - z64) < 0.25, (model, z32, z64, c0)
+
+
 def test_concurrent_streams_do_not_interfere():
     rng, t, flux = _lc(256)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)

@@ -278,6 +278,121 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
 }
 
 // ---------------------------------------------------------------------------------------
+// Mixed-precision variant (BASELINE config 5): the orbit and the geometric differences
+// (z-p, 1-p-z, 1+p-z ...) stay fp64 -- they carry the cancellations -- and everything after
+// them (products, square roots, the cel loop, atan, the case combination) runs in fp32 on the
+// full-rate hardware reciprocal / rsqrt / sqrt.  The result is a flux deficit of relative
+// accuracy ~1e-6, i.e. ~1e-7 absolute in flux for the reference's depths.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsqf_(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sqrtf_(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+__device__ __forceinline__ float atan_pos_f(float x)
+{
+    const bool r0 = x < 0.4375f, r1 = x < 0.6875f, r2 = x < 1.1875f, r3 = x < 2.4375f;
+    const float num = r0 ? x : (r1 ? fmaf(2.0f, x, -1.0f) : (r2 ? x - 1.0f : (r3 ? x - 1.5f : -1.0f)));
+    const float den = r0 ? 1.0f : (r1 ? 2.0f + x : (r2 ? x + 1.0f : (r3 ? fmaf(1.5f, x, 1.0f) : x)));
+    const float hi = r0 ? 0.0f : (r1 ? 4.6364760900e-01f : (r2 ? 7.8539816340e-01f
+                        : (r3 ? 9.8279372325e-01f : 1.5707963268e+00f)));
+    const float t = (den > 3.0e38f) ? 0.0f : num * rcpf_(den);
+    const float z = t * t;
+    // atan(t) = t + t z q(z), z = t^2 <= 0.4375^2: degree-4 Chebyshev fit of q, |error| < 2e-9
+    const float q = fmaf(z, fmaf(z, fmaf(z, fmaf(z, -0.062244711499f, 0.10671716232f),
+                                         -0.14256975819f), 0.19999330138f), -0.33333330811f);
+    return hi + fmaf(t * z, q, t);
+}
+
+__device__ __forceinline__ float cel_pair_f(float kc, float a1, float b1, float pp, float a2, float b2)
+{
+    float e = kc, em = 1.0f, q = kc, p1 = 1.0f;
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
+        const float r = rcpf_(p1 * pp);
+        const float r1 = r * pp, r2 = r * p1;
+        float f = a1, g = e * r1;
+        a1 = fmaf(b1, r1, a1);
+        b1 = fmaf(f, g, b1);
+        b1 += b1;
+        p1 += g;
+        f = a2;
+        g = e * r2;
+        a2 = fmaf(b2, r2, a2);
+        b2 = fmaf(f, g, b2);
+        b2 += b2;
+        pp += g;
+        g = em;
+        em += q;
+        if (fabsf(g - q) <= g * 3.5e-4f) break;
+        q = 2.0f * sqrtf_(e);
+        e = q * em;
+    }
+    const float d1 = em * (em + p1), d2 = em * (em + pp);
+    return 1.57079632679f * fmaf(fmaf(a1, em, b1), d2, fmaf(a2, em, b2) * d1) * rcpf_(d1 * d2);
+}
+
+__device__ __forceinline__ double ma_flux_f32(double z, double p, const Limb& L)
+{
+    if (p >= 1.0 && z <= p - 1.0) return 0.0;
+    // fp64: the differences
+    const double omp = 1.0 - p, opp = 1.0 + p, zmp_d = z - p;
+    const bool inside = (p < 1.0 && z <= omp);
+    const double d1_d = inside ? (omp - z) : ((p < 1.0) ? (z - omp) : (z + (p - 1.0)));   // g1 or f1
+    if (inside && d1_d == 0.0) {
+        const double p2 = p * p;
+        const double ld = (2.0 / (3.0 * kPi)) * acos(1.0 - 2.0 * p)
+                        - (4.0 / (9.0 * kPi)) * (3.0 + 2.0 * p - 8.0 * p2) * sqrt(p * omp);
+        return 1.0 - (L.cle * p2 + L.cld * ld + L.ced * (0.5 * p2 * (p2 + 2.0 * z * z)));
+    }
+    // fp32 from here
+    const float zf = (float)z, pf = (float)p, zmp = (float)zmp_d, d1 = (float)d1_d;
+    const float f2 = (float)(opp - z), f3 = (float)(1.0 + zmp_d), f4 = (float)(opp + z);
+    const float z2 = zf * zf, p2 = pf * pf, a = zmp * zmp, zpp = zf + pf;
+    const float q = -zmp * zpp;
+    const float eta2 = 0.5f * p2 * (p2 + 2.0f * z2);
+    const float theta = (zmp_d < 0.0) ? (2.0f / 3.0f) : ((zmp_d == 0.0) ? (1.0f / 3.0f) : 0.0f);
+    const float t7 = z2 + 7.0f * p2 - 4.0f;
+    const float azmp = fabsf(zmp);
+    const bool nz = azmp > 0.0f;
+    const float r = nz ? rcpf_(azmp) : 0.0f;
+    const float m3 = nz ? ((zmp_d < 0.0) ? -3.0f : 3.0f) : 0.0f;
+    const float b = zpp * zpp;
+    float le, ed, kc2, al, be, pp, a2, b2, scale;
+    if (inside) {
+        le = p2;
+        ed = eta2;
+        const float oma = f2 * f3;
+        const float rso = rsqf_(oma);
+        kc2 = d1 * f4 * rso * rso;
+        al = 1.0f - 5.0f * z2 + p2 + q * q;
+        be = oma * t7;
+        pp = nz ? zpp * r : 1.0f;
+        a2 = m3 * pp;
+        b2 = m3;
+        scale = (float)(2.0 / (9.0 * kPi)) * rso;
+    } else {
+        const float f14 = d1 * f4, f34 = f3 * f4;
+        const float area4 = sqrtf_(f14 * (f2 * f3));
+        const float kap0 = 2.0f * atan_pos_f((f14 > 0.0f) ? area4 * rcpf_(f14) : INFINITY);
+        const float kap1 = 2.0f * atan_pos_f(area4 * rcpf_(f34));
+        le = (p2 * kap0 + kap1 - 0.5f * area4) * (float)(1.0 / kPi);
+        ed = (kap1 + 2.0f * eta2 * kap0 - 0.25f * (1.0f + 5.0f * p2 + z2) * area4) * (float)(1.0 / kTwoPi);
+        const float fzp = 4.0f * zf * pf;
+        const float rsz = rsqf_(fzp);
+        kc2 = d1 * f4 * rsz * rsz;
+        al = (1.0f - b) * (2.0f * b + a - 3.0f) - 3.0f * q * (b - 2.0f);
+        be = fzp * t7;
+        pp = nz ? r : 1.0f;
+        b2 = m3 * zpp;
+        a2 = b2 * r;
+        scale = (float)(2.0 / (9.0 * kPi)) * rsz;
+    }
+    const float s = cel_pair_f(sqrtf_(kc2), al + be, fmaf(be, kc2, al), pp, a2, b2);
+    const float ld = fmaf(scale, s, theta);
+    const float deficit = (float)L.cle * le + (float)L.cld * ld + (float)L.ced * ed;
+    return 1.0 - (double)deficit;
+}
+
+// ---------------------------------------------------------------------------------------
 // Kepler's equation, full solve: bracket-safeguarded Halley on m = |M| in [0, pi].
 // Returns (sin E, cos E).  The iteration stops one step early: a Halley step below 1e-6
 // leaves an error ~ step^3, and (sin, cos) follow by a third-order update.
@@ -432,6 +547,7 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 
 // Mean model flux of one exposure (centre t), S sub-exposures: the body of
 // pytransit's evaluate_pv for one (row, time) cell.
+template <bool FP32 = false>
 __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
                                                 double exptime, int S, bool stepping)
 {
@@ -461,7 +577,7 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
         const double yc = Y * c.cosi;
         const double z2 = fma(X, X, yc * yc);
         double f = 1.0;
-        if (Y >= 0.0 && z2 < opp2) f = ma_flux(sqrt_fast(z2), c.k, L);
+        if (Y >= 0.0 && z2 < opp2) f = FP32 ? ma_flux_f32(sqrt_fast(z2), c.k, L) : ma_flux(sqrt_fast(z2), c.k, L);
         else if (z2 != z2) f = z2;
         acc += f;
     }

@@ -74,7 +74,7 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 #define TRX_WAVES_PER_EU 3
 #endif
 
-template <int MODE, bool STEP>
+template <int MODE, bool STEP, bool FP32>
 __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 {
     extern __shared__ double lds[];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
             const Limb L{c.cle, c.cld, c.ced};
             double acc = 0.0;
             for (int j = lane; j < a.n_time; j += 64) {
-                double m = exposure_flux(c, L, a.time[j], a.exptime, a.S, STEP);
+                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, STEP);
                 if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                 if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
                 if (MODE == MODE_GRID) {
@@ -424,8 +424,10 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     const long max_grid = 1L << 20;
     const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
     const size_t lds = (size_t)a.B * (2 * kRowDoubles + kSecPoints) * sizeof(double);
-    if (g_step) hipLaunchKernelGGL((rows_kernel<MODE, true>), dim3(grid), dim3(64), lds, st, a);
-    else        hipLaunchKernelGGL((rows_kernel<MODE, false>), dim3(grid), dim3(64), lds, st, a);
+    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
+    if (!g_step)    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
+    else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
+    else            hipLaunchKernelGGL((rows_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
     TRX_HIP(hipGetLastError());
     return TRX_OK;
 }
