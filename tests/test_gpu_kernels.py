@@ -276,6 +276,25 @@ def test_mixed_precision_model_tolerance(n_time):
             assert abs(z32 - z64) < 0.25, (model, z32, z64, c0)
 
 
+def test_large_batches_spot_checked():
+    """3e6 rows x 48 points (grid-stride over > 2^20 workgroups is not reached, B = 16 rows per
+    wave is) and 200 rows x 20000 points: random rows against the oracle, and bitwise equality
+    between the batched launch and the same rows launched alone (no cross-row state)."""
+    rng, t, flux = _lc(48, seed=9)
+    rows = synth.tp_rows(rng, 3_000_000, True)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    h = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
+    pick = rng.choice(rows.shape[1], 300, replace=False)
+    _cmp_h(h[pick], O.lnl_batch(0, t, flux, synth.SIGMA, rows[:, pick]))
+    alone = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
+    assert np.array_equal(alone, h[pick])
+    assert np.isfinite(h).all()
+    rng, t, flux = _lc(20000, seed=10)
+    rows = synth.eb_rows(rng, 200, True, True)
+    h = _lib.lnl_batch(2, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
+    _cmp_h(h[:6], O.lnl_batch(2, t, flux, synth.SIGMA, rows[:, :6]))
+
+
 def test_concurrent_streams_do_not_interfere():
     rng, t, flux = _lc(256)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)

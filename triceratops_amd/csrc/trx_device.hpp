@@ -549,7 +549,7 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 // pytransit's evaluate_pv for one (row, time) cell.
 template <bool FP32 = false>
 __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
-                                                double exptime, int S, bool stepping)
+                                                double exptime, int S, double dS, double rS, bool stepping)
 {
     const double phase = c.nmot * (t - c.t0);
     const double dMc = reduce_2pi(phase);
@@ -558,8 +558,6 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
     if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return 1.0;
     const double opp = 1.0 + c.k;
     const double opp2 = opp * opp;
-    const double dS = (double)S;
-    const double rS = 1.0 / dS;
     double acc = 0.0;
     double sE = 0.0, cE = 1.0, Mprev = 0.0;
 #pragma unroll 1

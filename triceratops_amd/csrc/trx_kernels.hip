@@ -58,6 +58,9 @@ struct RowsArgs {
     double* out_sec;   // MODE_GRID: [n] or null
     int B;
     long nbatch;
+    // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
+    // computing them in the kernel parks them in long-lived vector registers
+    double s2, dS, rS;
 };
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
     const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
     const long n = a.n;
-    const double s2 = a.sigma * a.sigma;
+    const double s2 = a.s2;
 
     for (long batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
         const long base = batch * B;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
                 double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
                 if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, false);
+                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false);
             }
             __syncthreads();
             if (lane < nb) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
             const Limb L{c.cle, c.cld, c.ced};
             double acc = 0.0;
             for (int j = lane; j < a.n_time; j += 64) {
-                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, STEP);
+                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, a.dS, a.rS, STEP);
                 if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                 if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
                 if (MODE == MODE_GRID) {
@@ -420,6 +423,9 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
 {
     RowsArgs a = a0;
     a.B = pick_rows_per_wave(a.n_time, a.n);
+    a.s2 = a.sigma * a.sigma;
+    a.dS = (double)a.S;
+    a.rS = 1.0 / a.dS;
     a.nbatch = (a.n + a.B - 1) / a.B;
     const long max_grid = 1L << 20;
     const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
@@ -473,7 +479,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0};
+               out_halfchi2, nullptr, 0, 0, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -485,7 +491,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0};
+               out_flux, out_secdepth, 0, 0, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
