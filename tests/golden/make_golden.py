@@ -240,16 +240,13 @@ def main():
             variants.append(("ccJ", 3.3, True, {"cc": cc_path, "filt": "J"}))
         variants.append(("serial", 3.3, False, {}))
         for vname, P, par, kw in variants:
-            if not par:
-                rml_N = 300   # the serial path is a Python loop over draws in the reference
             seed += 1
             np.random.seed(seed)
             del captured[:], logws[:]
             if par:
                 res = fn(P, par, **kw)
             else:
-                # smaller N for the per-draw loop
-                old = N
+                # the serial path is a Python loop over draws in the reference: smaller N
                 res = _with_N(plan, name, rml, b, s, tri_path, 300, P, kw)
             case = "%s_%s" % (name, vname)
             cases.append(case)
