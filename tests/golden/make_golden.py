@@ -419,6 +419,53 @@ def main():
                         FPP=np.array([t1228.FPP]), NFPP=np.array([t1228.NFPP]),
                         scenario=np.array(list(t1228.probs["scenario"])), N=np.array([4000]),
                         seed=np.array([1228]))
+
+    # ---- (7) caller-side helpers of target: star-table edits and the best-fit curves of plot_fits
+    # (the reference keeps star IDs as strings; plot_fits matches on str(ID))
+    ops = {}
+    st = stars_table()
+    st["ID"] = st["ID"].astype(str)
+    tg = ref_target(st)
+    tg.calc_depths(0.007, aps)
+    np.random.seed(99)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tg.calc_probs(t, f, sigma, 3.3, N=1500, parallel=True, verbose=0, contrast_curve_file=cc_path,
+                      drop_scenario=["PEB"])
+    import matplotlib.pyplot as plt
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        tg.plot_fits(t, f, sigma, save=True, fname=os.path.join(tmp, "fits"))
+    panels = plt.gcf().axes
+    ops["fit_model"] = np.array([[ln for ln in p.lines if ln.get_linewidth() == 3][0].get_ydata()
+                                 for p in panels])
+    ops["fit_model_time"] = np.asarray([ln for ln in panels[0].lines if ln.get_linewidth() == 3][0].get_xdata())
+    ops["fit_data"] = np.array([[ln for ln in p.lines if ln.get_linewidth() != 3][0].get_ydata()
+                                for p in panels])
+    ops["fit_labels"] = np.array([[a.get_text() for a in p.texts] for p in panels])
+    plt.close("all")
+    ops["fit_seed"] = np.array([99])
+    tg.add_star(555, 14.5, True)
+    tg.add_star(666, 16.0, False)
+    ops["add_ID"], ops["add_Tmag"], ops["add_plx"] = (np.array(list(tg.stars["ID"])),
+                                                      tg.stars["Tmag"].values.copy(),
+                                                      tg.stars["plx"].values.copy())
+    ops["add_mass"] = tg.stars["mass"].values.copy()      # update_star below writes in place
+    ops["add_pix0"], ops["add_pix1"] = tg.pix_coords
+    tg.update_star(666, "mass", 0.4)
+    tg.update_star(222, "Teff", 4100.0)
+    ops["upd_mass"], ops["upd_Teff"] = tg.stars["mass"].values.copy(), tg.stars["Teff"].values.copy()
+    tg.remove_star(np.array([333, 555]))
+    ops["rm_ID"], ops["rm_index"] = np.array(list(tg.stars["ID"])), tg.stars.index.values
+    tg.remove_star(444)
+    ops["rm2_ID"] = np.array(list(tg.stars["ID"]))
+    # the two caller-less helpers of funcs.py
+    vk = np.array([[12.0, 10.5], [9.3, 8.8], [15.0, 9.5], [14.0, 8.0], [11.0, 5.9]])
+    ops["cteff_in"], ops["cteff_out"] = vk, np.array([rfuncs.color_Teff_relations(v, k) for v, k in vk])
+    gx, gy = np.linspace(3, 7, 9), np.linspace(2, 6.5, 7)
+    ops["gauss_x"], ops["gauss_y"] = gx, gy
+    ops["gauss_grid"] = rfuncs.Gauss2D(gx, gy, 5.3, 4.7, 0.75, 2.5)
+    ops["gauss_scalar"] = np.array([rfuncs.Gauss2D(4.9, 5.2, 5.3, 4.7, 0.75, 2.5)])
+    np.savez_compressed(os.path.join(HERE, "target_ops.npz"), **ops)
     print("wrote", sorted(os.listdir(HERE)))
 
 

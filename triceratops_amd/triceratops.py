@@ -6,8 +6,12 @@ Mirrors the compute half of triceratops/triceratops.py `class target`:
 with the same argument lists and the same result attributes (.probs .lnZ .FPP .NFPP
 .FPP_degenerate .star_num .u1 .u2 .fluxratio_EB .fluxratio_comp).
 
+and the caller-side helpers around it:
+  add_star / remove_star / update_star (triceratops.py:265-335)   edits of the .stars table
+  fit_curves, plot_fits (triceratops.py:1487-1638)   best-fit model light curve per scenario
+
 Out of scope: the catalogue / cut-out / TRILEGAL web queries of
-__init__ and the matplotlib plots.  A `target` here is built from a ready star table (and, for
+__init__ and plot_field.  A `target` here is built from a ready star table (and, for
 calc_depths, pixel coordinates); the TRILEGAL population is a local csv (`trilegal_fname`).
 
 With torch.distributed initialised (one process per GPU, RCCL) calc_probs shards the
@@ -17,10 +21,12 @@ results; see triceratops_amd/sharding.py.
 import warnings
 
 import numpy as np
-from pandas import DataFrame
+from pandas import DataFrame, concat
 from scipy.special import ndtr
 
+from . import _lib
 from ._numerics import _normalize_probabilities
+from .constants import G, Msun, pi
 from .funcs import renorm_flux
 from .marginal_likelihoods import *  # noqa: F401,F403  (reference re-exports the lnZ_* names)
 from .marginal_likelihoods import (lnZ_BEB, lnZ_BTP, lnZ_DEB, lnZ_DTP, lnZ_PEB, lnZ_PTP, lnZ_SEB,
@@ -65,6 +71,34 @@ class target:
         self.trilegal_url = None
         self.stars = stars.reset_index(drop=True)
         self.pix_coords = pix_coords
+
+    # -----------------------------------------------------------------------------------
+    def add_star(self, ID: int, Tmag: float, bound: bool):
+        """Append a star found by follow-up (e.g. an unresolved companion) to .stars.  A bound
+        star inherits the target's parallax; every other column is NaN.  Its pixel position in
+        each sector is the target's."""
+        row = {"ID": str(ID), "Tmag": Tmag}
+        if bound:
+            row["plx"] = self.stars["plx"].values[0]
+        self.stars = concat([self.stars, DataFrame([row])]).reset_index(drop=True)
+        if self.pix_coords is not None:
+            self.pix_coords = [np.vstack([np.asarray(c), np.asarray(c)[:1]])
+                               for c in self.pix_coords]
+        return
+
+    def remove_star(self, drop_stars):
+        """Drop stars (scalar ID or sequence of IDs) that were ruled out as NTP/NEB hosts.  Like
+        the reference this keeps the surviving rows' index labels and does not touch pix_coords."""
+        ids = [drop_stars] if np.isscalar(drop_stars) else list(drop_stars)
+        gone = self.stars["ID"].astype(str).isin([str(s) for s in ids])
+        self.stars = self.stars[~gone]
+        return
+
+    def update_star(self, ID: int, param: str, value: float):
+        """Set column `param` of star `ID` to `value`."""
+        hit = self.stars["ID"].astype(str) == str(ID)
+        self.stars.loc[hit, [param]] = value
+        return
 
     # -----------------------------------------------------------------------------------
     def calc_depths(self, tdepth: float, all_ap_pixels=None):
@@ -235,3 +269,81 @@ class target:
         self.FPP = 1 - (prob[0] + prob[3] + prob[9])
         self.NFPP = np.sum(prob[15:]) if len(prob) > 15 else 0.0
         return
+
+    # -----------------------------------------------------------------------------------
+    def fit_curves(self, time, flux_0, flux_err_0: float, n_model: int = 100,
+                   exptime: float = 0.00139, nsamples: int = 20):
+        """Best-fit model light curve of every scenario of the last calc_probs: the data half of
+        the reference's plot_fits (triceratops.py:1502-1597).
+
+        Returns (model_time, curves): model_time = linspace(min(time), max(time), n_model) and one
+        dict per row of .probs {ID, scenario, flux, flux_err, model}; flux/flux_err are the data
+        renormalised to that scenario's host star, model is all ones for a skipped scenario.  All
+        rows of one kind (TP / EB, companion-is-host or not) go to the GPU as one parameter block,
+        with the reference's scalar-path radius-ratio rule (likelihoods.py:63-66, 122-131)."""
+        time = np.asarray(time, dtype=np.float64)
+        flux_0 = np.asarray(flux_0, dtype=np.float64)
+        live = (self.probs["ID"] != 0).values       # rows calc_probs never reached keep ID 0
+        df = self.probs[live]
+        star_num, u1, u2 = self.star_num[live], self.u1[live], self.u2[live]
+        fr_EB, fr_comp = self.fluxratio_EB[live], self.fluxratio_comp[live]
+        model_time = np.linspace(np.min(time), np.max(time), n_model)
+        star_ids = self.stars["ID"].astype(str).values
+        models = np.ones((len(df), n_model))
+        groups = {}
+        for k in range(len(df)):
+            if df["M_s"].values[k] == 0.0:
+                continue
+            groups.setdefault((k % 3 == 0, bool(star_num[k] != 1)), []).append(k)
+        t_d = _lib.dev(model_time)
+        for (is_tp, comp), rows in groups.items():
+            r = np.array(rows)
+            M = df["M_s"].values[r] + (0.0 if is_tp else df["M_EB"].values[r])
+            P = df["P_orb"].values[r]
+            a = ((G * M * Msun) / (4 * pi ** 2) * (P * 86400) ** 2) ** (1 / 3)
+            common = (P, df["inc"].values[r], a, df["R_s"].values[r], u1[r], u2[r],
+                      df["ecc"].values[r], df["w"].values[r], fr_comp[r])
+            if is_tp:
+                model, cols = _lib.MODEL_TP, (df["R_p"].values[r],) + common
+            else:
+                model, cols = _lib.MODEL_EB, (df["R_EB"].values[r], fr_EB[r]) + common
+            flags = _lib.FLAG_SCALAR_K | (_lib.FLAG_COMPANION_IS_HOST if comp else 0)
+            grid, _ = _lib.flux_grid(model, flags, t_d, _lib.dev(_lib.pack_params(model, cols, len(r))),
+                                     exptime, nsamples, want_secdepth=False)
+            models[r] = grid.cpu().numpy()
+        curves = []
+        for k in range(len(df)):
+            idx = np.argwhere(star_ids == str(df["ID"].values[k]))[0, 0]
+            flux, flux_err = renorm_flux(flux_0, flux_err_0, self.stars["fluxratio"].values[idx])
+            curves.append({"ID": df["ID"].values[k], "scenario": df["scenario"].values[k],
+                           "flux": flux, "flux_err": flux_err, "model": models[k]})
+        return model_time, curves
+
+    def plot_fits(self, time, flux_0, flux_err_0: float, save: bool = False, fname: str = None):
+        """One panel per scenario (rows of three: TP, EB, EBx2P of a star) with the renormalised
+        data and the best-fit model of fit_curves.  save=False shows the figure; save=True writes
+        `fname`.pdf, or TIC<target>_fits.pdf without a name (as the reference)."""
+        import matplotlib.pyplot as plt
+        from matplotlib import ticker
+        model_time, curves = self.fit_curves(time, flux_0, flux_err_0)
+        n_rows = len(curves) // 3
+        f, ax = plt.subplots(n_rows, 3, figsize=(12, n_rows * 4), sharex=True, squeeze=False)
+        for k, c in enumerate(curves[:3 * n_rows]):
+            p = ax[k // 3, k % 3]
+            p.yaxis.set_major_formatter(ticker.ScalarFormatter(useOffset=False))
+            p.errorbar(time, c["flux"], c["flux_err"], fmt=".", color="blue", alpha=0.25, zorder=0,
+                       rasterized=True)
+            p.plot(model_time, c["model"], "k-", lw=3, zorder=2)
+            p.set_ylabel("normalized flux", fontsize=12)
+            p.annotate(str(c["ID"]), xy=(0.05, 0.92), xycoords="axes fraction", fontsize=12)
+            p.annotate(str(c["scenario"]), xy=(0.05, 0.05), xycoords="axes fraction", fontsize=12)
+        for j in range(3):
+            ax[n_rows - 1, j].set_xlabel("days from transit center", fontsize=12)
+        plt.tight_layout()
+        if save is False:
+            plt.show()
+        elif fname is None:
+            plt.savefig("TIC" + str(self.stars.ID.values[0]) + "_fits.pdf")
+        else:
+            plt.savefig(fname + ".pdf")
+        return f
