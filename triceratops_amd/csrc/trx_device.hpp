@@ -38,64 +38,73 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---------------------------------------------------------------------------------------
-// short fp64 sequences (finite, normal-range arguments; ~1 ulp)
+// short fp64 sequences (finite, normal-range arguments; a few ulp).
+// Measured on gfx950 (profiles/micro/): v_rcp_f64 / v_rsq_f64 cost 16 cycles per wave, an fp64
+// fma/mul/add 4, and the seeds are good to 2^-24.2.  One third-order step (e + e^2, resp.
+// r + 1.5 r^2) therefore reaches 2^-72 in one op less than two Newton steps.
 __device__ __forceinline__ double rcp_fast(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);      // v_rcp_f64: ~2^-23 relative
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 
-// sqrt(x) and 1/sqrt(x) for x > 0 (Goldschmidt from v_rsq_f64); x == 0 gives (0, inf)
-__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs)
+// one Newton step only (2^-48): for callers that iterate on the result anyway
+__device__ __forceinline__ double rcp_nr1(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    s = (x == 0.0) ? 0.0 : g;
-    rs = (x == 0.0) ? INFINITY : 2.0 * h;
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
 }
 
-__device__ __forceinline__ double sqrt_fast(double x)
-{
-    double s, rs;
-    sqrt_rsqrt(x, s, rs);
-    return s;
-}
-
-// the same for arguments known to be > 0 (no zero guard)
+// sqrt(x) and 1/sqrt(x) for x > 0 (Goldschmidt from v_rsq_f64, third order)
 __device__ __forceinline__ void sqrt_rsqrt_pos(double x, double& s, double& rs)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    s = fma(d, h, g);
-    rs = 2.0 * h;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-g, h, 0.5);
+    const double t = fma(1.5 * r, r, r);
+    s = fma(g, t, g);
+    rs = 2.0 * fma(h, t, h);
 }
 
 __device__ __forceinline__ double sqrt_pos(double x)
 {
-    double s, rs;
-    sqrt_rsqrt_pos(x, s, rs);
-    return s;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-g, h, 0.5);
+    return fma(g, fma(1.5 * r, r, r), g);
+}
+
+// the same with x == 0 allowed: (0, inf)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs)
+{
+    double g, h;
+    sqrt_rsqrt_pos(x, g, h);
+    s = (x == 0.0) ? 0.0 : g;
+    rs = (x == 0.0) ? INFINITY : h;
+}
+
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+    const double g = sqrt_pos(x);
+    return (x == 0.0) ? 0.0 : g;
 }
 
 // x reduced to [-pi, pi] (two-word 2 pi under fma; error ~1e-16 |x| for |x| < ~1e9)
+// x*y + C for a literal C, with C held in a scalar register pair.  Left to itself the compiler
+// forms v_fmac_f64 for a Horner step and first copies C into the accumulator VGPR pair: two
+// extra VALU issues per step on a VALU-issue-bound kernel.  The s_mov pair is free (scalar unit).
+__device__ __forceinline__ double fma_k(double x, double y, double C)
+{
+#ifdef TRX_NO_SGPR_CONSTS
+    return fma(x, y, C);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(C));
+    return r;
+#endif
+}
+
 __device__ __forceinline__ double reduce_2pi(double x)
 {
     const double n = rint(x * 0.15915494309189533577);   // 1/(2 pi)
@@ -110,11 +119,11 @@ __device__ __forceinline__ void sincos_red(double x, double& s, double& c)
     double r = fma(-n, 1.57079632679489655800e+00, x);
     r = fma(-n, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10,
+    const double ps = fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, 1.58969099521155010221e-10,
                       -2.50507602534068634195e-08), 2.75573137070700676789e-06),
                       -1.98412698298579493134e-04), 8.33333333332248946124e-03),
                       -1.66666666666666324348e-01);
-    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11,
+    const double pc = fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, -1.13596475577881948265e-11,
                       2.08757232129817482790e-09), -2.75573143513906633035e-07),
                       2.48015872894767294178e-05), -1.38888888888741095749e-03),
                       4.16666666666666019037e-02);
@@ -142,11 +151,11 @@ __device__ __forceinline__ double atan_pos(double x)
                          : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
     const double t = (den > 1.7e308) ? 0.0 : num * rcp_fast(den);
     const double z = t * t, w = z * z;
-    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02,
+    const double s1 = z * fma_k(w, fma_k(w, fma_k(w, fma_k(w, fma_k(w, 1.62858201153657823623e-02,
                       4.97687799461593236017e-02), 6.66107313738753120669e-02),
                       9.09088713343650656196e-02), 1.42857142725034663711e-01),
                       3.33333333333329318027e-01);
-    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02,
+    const double s2 = w * fma_k(w, fma_k(w, fma_k(w, fma_k(w, -3.65315727442169155270e-02,
                       -5.83357013379057348645e-02), -7.69187620504482999495e-02),
                       -1.11111104054623557880e-01), -1.99999999998764832476e-01);
     return hi - ((t * (s1 + s2) - lo) - t);
@@ -161,26 +170,33 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
 {
     double e = kc, em = 1.0, q = kc;
     double p1 = 1.0;
-#pragma unroll 1
-    for (int it = 0; it < 40; ++it) {
+    // one Bulirsch step; true when the kc/em recurrence has converged
+    auto step = [&]() -> bool {
         const double r = rcp_fast(p1 * pp);
         const double r1 = r * pp, r2 = r * p1;
-        double f = a1, g = e * r1;
+        const double g1 = e * r1, g2 = e * r2;
+        const double t1 = fma(a1, g1, b1), t2 = fma(a2, g2, b2);
         a1 = fma(b1, r1, a1);
-        b1 = fma(f, g, b1);
-        b1 += b1;
-        p1 += g;
-        f = a2;
-        g = e * r2;
         a2 = fma(b2, r2, a2);
-        b2 = fma(f, g, b2);
-        b2 += b2;
-        pp += g;
-        g = em;
+        b1 = t1 + t1;
+        b2 = t2 + t2;
+        p1 += g1;
+        pp += g2;
+        const double g = em;
         em += q;
-        if (fabs(g - q) <= g * 1e-8) break;
+        // the gap squares every step: stopping at a relative gap of 2e-6 leaves ~5e-13 relative
+        // on the integrals, i.e. < 1e-13 on the flux (Bulirsch's sqrt(eps) costs one more step)
+        if (fabs(g - q) <= g * 2e-6) return true;
         q = 2.0 * sqrt_pos(e);
         e = q * em;
+        return false;
+    };
+    // two steps per trip: the a/b pairs swap registers every step, so a single-step loop pays
+    // four v_mov_b64 per iteration (4 cycles each, as much as an fp64 fma) to rotate them back
+#pragma unroll 1
+    for (int it = 0; it < 20; ++it) {
+        if (step()) break;
+        if (step()) break;
     }
     const double d1 = em * (em + p1), d2 = em * (em + pp);
     const double num = fma(fma(a1, em, b1), d2, fma(a2, em, b2) * d1);
@@ -418,8 +434,8 @@ __device__ __forceinline__ void kepler_full(double M, double e, double& sE, doub
         const double f = x - e * sx - m;
         if (f > 0.0) hi = x; else lo = x;
         const double fp = 1.0 - e * cx;
-        const double rfp = rcp_fast(fp);
-        double dx = -f * rcp_fast(fma(-0.5 * f * rfp, e * sx, fp));
+        const double rfp = rcp_nr1(fp);
+        double dx = -f * rcp_nr1(fma(-0.5 * f * rfp, e * sx, fp));
         double xn = x + dx;
         const bool safe = (xn >= lo && xn <= hi);
         if (!safe) { xn = 0.5 * (lo + hi); dx = xn - x; }
@@ -441,7 +457,7 @@ __device__ __forceinline__ void kepler_full(double M, double e, double& sE, doub
 // reciprocal of g' (no division).  Returns false when |d| is too large for the series.
 __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, double& cE)
 {
-    double rho = rcp_fast(fma(-e, cE, 1.0));
+    double rho = rcp_nr1(fma(-e, cE, 1.0));
     double d = dM * rho;
     if (!(fabs(d) < 0.08)) return false;
     d = fma(-0.5 * e * sE * rho * d, d, d);     // second-order start: one Newton step then suffices
@@ -449,9 +465,9 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const double d2 = d * d;
-        const double sd = d * fma(d2, fma(d2, fma(d2, fma(d2, 1.0 / 362880.0, -1.0 / 5040.0),
+        const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 362880.0, -1.0 / 5040.0),
                                                     1.0 / 120.0), -1.0 / 6.0), 1.0);
-        const double c1 = d2 * fma(d2, fma(d2, fma(d2, fma(d2, -1.0 / 3628800.0, 1.0 / 40320.0),
+        const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 3628800.0, 1.0 / 40320.0),
                                                      -1.0 / 720.0), 1.0 / 24.0), -0.5);
         ds = fma(sE, c1, cE * sd);   // sin(E+d) - sin E
         dc = fma(cE, c1, -sE * sd);  // cos(E+d) - cos E
