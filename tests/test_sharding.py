@@ -160,3 +160,119 @@ def test_calc_probs_end_to_end_on_host_fakes(monkeypatch):
     r = ml.lnZ_TTP(g["time"], fl, fe, 3.3, 0.82, 0.8, 5100.0, 0.0, 400, True, "TESS", False, 0.00139, 20)
     assert r["lnZ"] == tg.lnZ[0] and r["R_p"][0] == tg.probs.R_p[0]
 
+
+
+# ---------------------------------------------------------------------------------------
+# calc_probs_many: several targets, one unit list, one all_gather
+def _two_jobs():
+    import pandas as pd
+    from helpers import GOLD, gold
+    from triceratops_amd.triceratops import target
+    g = gold("lnz_cases.npz")
+
+    def stars(ids, fr):
+        n = len(ids)
+        return pd.DataFrame({
+            "ID": ids, "Tmag": [10.4, 13.0, 15.5][:n], "Jmag": [9.5, 12.1, 14.6][:n],
+            "Hmag": [9.1, 11.7, 14.2][:n], "Kmag": [9.0, 11.6, 14.1][:n], "ra": [10.0, 10.01, 10.02][:n],
+            "dec": [-5.0, -5.01, -5.02][:n], "mass": [0.82, 0.6, np.nan][:n], "rad": [0.8, 0.58, np.nan][:n],
+            "Teff": [5100.0, 4000.0, np.nan][:n], "plx": [14.2, 3.0, np.nan][:n],
+            "fluxratio": fr, "tdepth": [0.0074, 0.17, 0.3][:n]})
+
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    a = target(111, np.array([1]), stars=stars([111, 222, 333], [0.95, 0.04, 0.01]), trilegal_fname=tri)
+    b = target(777, np.array([2]), stars=stars([777, 888], [0.9, 0.1]), trilegal_fname=tri)
+    sig = float(g["sigma"][0])
+    jobs = [(a, dict(time=g["time"], flux_0=g["flux"], flux_err_0=sig, P_orb=3.3, N=300, parallel=True,
+                     drop_scenario=["SEB"])),
+            (b, dict(time=g["time"][::2], flux_0=g["flux"][::2], flux_err_0=sig, P_orb=[3.0, 3.6], N=200,
+                     parallel=True, drop_scenario=["DTP", "DEB", "BTP", "BEB"]))]
+    return jobs
+
+
+def _tables(jobs):
+    return [np.concatenate([tg.lnZ, tg.probs.prob.values, [tg.FPP, tg.NFPP], tg.probs.R_p.values])
+            for tg, _ in jobs]
+
+
+def test_calc_probs_many_equals_sequential_calls_on_one_stream(monkeypatch):
+    from helpers import install_cpu_device_fakes
+    from triceratops_amd.triceratops import calc_probs_many
+    install_cpu_device_fakes(monkeypatch)
+    jobs = _two_jobs()
+    np.random.seed(31)
+    out = calc_probs_many(jobs)
+    assert out[0] is jobs[0][0] and len(jobs[0][0].lnZ) == 21 and len(jobs[1][0].lnZ) == 18
+    many = _tables(jobs)
+    seq = _two_jobs()
+    np.random.seed(31)
+    for tg, kw in seq:
+        tg.calc_probs(verbose=0, **kw)
+    for m, s in zip(many, _tables(seq)):
+        assert np.array_equal(m, s, equal_nan=True)
+    assert np.isfinite(many[0][0]) and np.isfinite(many[1][0]) and jobs[1][0].lnZ[9] == -np.inf
+
+
+def _many_worker(rank, world, port, q):
+    import pytest as _pytest
+    from helpers import install_cpu_device_fakes
+    from triceratops_amd.triceratops import calc_probs_many
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mp_ = _pytest.MonkeyPatch()
+    install_cpu_device_fakes(mp_)
+    jobs = _two_jobs()
+    np.random.seed(77)
+    calc_probs_many(jobs)
+    units = [u for tg, kw in _two_jobs() for u in tg._prepare(**{k: v for k, v in kw.items()})[0]]
+    live = [u for u in units if u[4] is not None]
+    owners = sharding.schedule([sharding._COST.get(u[5], 1.0) * u[6] for u in live], world)
+    q.put((rank, _tables(jobs), owners))
+    dist.barrier()
+    dist.destroy_process_group()
+    mp_.undo()
+
+
+def test_calc_probs_many_world2_gloo_matches_single_process(monkeypatch):
+    from helpers import install_cpu_device_fakes
+    from triceratops_amd.triceratops import calc_probs_many
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_many_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, own0), (_, t1, own1) = got
+    assert own0 == own1 and set(own0) == {0, 1}
+    # the larger job's units weigh more: the two ranks' loads are balanced by weight, not by count
+    for a, b in zip(t0, t1):
+        assert np.array_equal(a, b, equal_nan=True)
+    install_cpu_device_fakes(monkeypatch)
+    jobs = _two_jobs()
+    np.random.seed(77)
+    sharding.per_unit_seed = True
+    try:
+        calc_probs_many(jobs)
+    finally:
+        sharding.per_unit_seed = False
+    for a, b in zip(t0, _tables(jobs)):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_calc_probs_many_on_gpu_equals_sequential_calls():
+    from triceratops_amd.triceratops import calc_probs_many
+    jobs = _two_jobs()
+    np.random.seed(31)
+    calc_probs_many(jobs)
+    seq = _two_jobs()
+    np.random.seed(31)
+    for tg, kw in seq:
+        tg.calc_probs(verbose=0, **kw)
+    for m, s in zip(_tables(jobs), _tables(seq)):
+        assert np.array_equal(m, s, equal_nan=True)

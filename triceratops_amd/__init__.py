@@ -12,3 +12,9 @@ def set_sampling(mode):
     reproducible against the reference; 'device': the whole scenario on the GPU."""
     from .marginal_likelihoods import set_sampling as _set
     _set(mode)
+
+
+def calc_probs_many(jobs, verbose: int = 0):
+    """calc_probs for several targets in one sharded pass (see triceratops.calc_probs_many)."""
+    from .triceratops import calc_probs_many as _many
+    return _many(jobs, verbose=verbose)

@@ -68,8 +68,10 @@ def _as_dicts(rec):
 def run_units(units, verbose=0):
     """Evaluate the work units of one calc_probs.
 
-    units: list of (first_row, names, star_num, ID, thunk_or_None, key).  Returns, per unit, None
-    (dropped scenario) or a tuple of per-scenario dicts {column: best value, 'lnZ': float}."""
+    units: list of (first_row, names, star_num, ID, thunk_or_None, key[, weight]); weight scales the
+    scenario cost of `key` in the schedule (units of differently sized jobs, calc_probs_many).
+    Returns, per unit, None (dropped scenario) or a tuple of per-scenario dicts
+    {column: best value, 'lnZ': float}."""
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
@@ -84,7 +86,8 @@ def run_units(units, verbose=0):
             b[0] = int(np.random.randint(0, 2 ** 31 - 1))
         dist.broadcast(b, src=0)
         base = int(b[0])
-        own = schedule([_COST.get(units[k][5], 1.0) for k in live], world)
+        own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
+                        for k in live], world)
         owner = {k: own[i] for i, k in enumerate(live)}
     elif per_unit_seed:
         base = int(np.random.randint(0, 2 ** 31 - 1))
@@ -98,7 +101,7 @@ def run_units(units, verbose=0):
     for k in live:
         if owner[k] != rank:
             continue
-        j0, names, snum, ID, fn, key = units[k]
+        j0, names, snum, ID, fn, key = units[k][:6]
         if verbose == 1:
             print("Calculating " + ", ".join(names) + " scenario probabilit"
                   + ("y" if len(names) == 1 else "ies") + " for " + str(ID)

@@ -204,28 +204,44 @@ class target:
 
         `parallel` selects the reference's vector-path or per-draw-loop semantics (App. C of
         SURVEY.md); both run on the GPU."""
+        units, book = self._prepare(time, flux_0, flux_err_0, P_orb, contrast_curve_file, filt, N,
+                                    parallel, drop_scenario, flatpriors, exptime, nsamples,
+                                    molusc_file)
+        self._finish(units, sharding.run_units(units, verbose=verbose), book)
+        return
+
+    def _prepare(self, time, flux_0, flux_err_0, P_orb, contrast_curve_file=None, filt="TESS",
+                 N=1000000, parallel=False, drop_scenario=[], flatpriors=False, exptime=0.00139,
+                 nsamples=20, molusc_file=None):
+        """Work units of one calc_probs (triceratops.py:673-735: NaN filter, star filter, table
+        sizes) and the number of table rows."""
         time = np.asarray(time, dtype=np.float64)
         flux_0 = np.asarray(flux_0, dtype=np.float64)
         keep = ~np.isnan(time) & ~np.isnan(flux_0)
         time, flux_0 = time[keep], flux_0[keep]
         filtered = self.stars[self.stars["tdepth"] > 0]
         n_scen = 3 * len(filtered) + 12
-        targets = np.zeros(n_scen, dtype=np.dtype("i8"))
-        star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
-        scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
-        best = {c: np.zeros(n_scen) for c in _COLS}
-        lnZ = np.zeros(n_scen)
         needs_field = not all(k in drop_scenario for k in ("DTP", "DEB", "BTP", "BEB"))
         if self.trilegal_fname is None and needs_field:
             raise ValueError("trilegal_fname is required for the D and B scenarios (the TRILEGAL "
                              "web query is outside the accelerated path); pass it to target(...) "
                              "or drop DTP, DEB, BTP and BEB")
-
         units, _ok = self._units(filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file,
                                  filt, N, parallel, drop_scenario, flatpriors, exptime, nsamples,
                                  molusc_file)
-        results = sharding.run_units(units, verbose=verbose)
-        for (j0, names, snum, ID, fn, key), res in zip(units, results):
+        # relative size of this job's units for the multi-GPU schedule
+        weight = float(N) * max(1, time.size)
+        return [u + (weight,) for u in units], n_scen
+
+    def _finish(self, units, results, n_scen):
+        """Scenario table, normalised probabilities, FPP and NFPP from the per-unit results
+        (triceratops.py:1430-1485)."""
+        targets = np.zeros(n_scen, dtype=np.dtype("i8"))
+        star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
+        scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
+        best = {c: np.zeros(n_scen) for c in _COLS}
+        lnZ = np.zeros(n_scen)
+        for (j0, names, snum, ID, fn, key, _w), res in zip(units, results):
             for off, name in enumerate(names):
                 j = j0 + off
                 targets[j], star_num[j], scenarios[j] = ID, snum, name
@@ -242,14 +258,14 @@ class target:
             warnings.warn(
                 "Unexpected NaN or +inf in scenario log-evidences. This indicates a numerical "
                 "anomaly unrelated to geometric exclusions. Inspect self.lnZ for diagnostics.",
-                RuntimeWarning, stacklevel=2)
+                RuntimeWarning, stacklevel=3)
             self.FPP_degenerate = True
         elif status == 'all_neginf':
             warnings.warn(
                 "All scenario log-evidences are -inf: every MC draw was geometrically invalid. "
                 "FPP=1.0 reflects a failed computation, not a confident false positive. "
                 "Inspect self.lnZ for diagnostics.",
-                RuntimeWarning, stacklevel=2)
+                RuntimeWarning, stacklevel=3)
             self.FPP_degenerate = True
         else:
             self.FPP_degenerate = False
@@ -347,3 +363,26 @@ class target:
         else:
             plt.savefig(fname + ".pdf")
         return f
+
+
+def calc_probs_many(jobs, verbose: int = 0):
+    """calc_probs for several targets at once (BASELINE config 4: many TOIs over the GPUs of a node).
+
+    jobs: sequence of (target, kwargs) with kwargs the calc_probs arguments of that target
+    (time, flux_0, flux_err_0, P_orb, ...).  The (TOI, star, lnZ_* call) units of ALL jobs form one
+    list, dealt to the ranks by size (N x n_time x scenario cost) and finished with the same single
+    all_gather as one calc_probs; every target then gets its own table, FPP and NFPP.  On one GPU
+    without per-unit seeding this is the jobs' calc_probs calls one after the other on one random
+    stream."""
+    prepared = []
+    for tg, kw in jobs:
+        kw = dict(kw)
+        kw.pop("verbose", None)
+        prepared.append((tg,) + tg._prepare(**kw))
+    flat = [u for _, units, _ in prepared for u in units]
+    results = sharding.run_units(flat, verbose=verbose)
+    at = 0
+    for tg, units, n_scen in prepared:
+        tg._finish(units, results[at:at + len(units)], n_scen)
+        at += len(units)
+    return [tg for tg, _ in jobs]
