@@ -49,6 +49,9 @@ def parse():
     # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
     # with every rank on cuda:0 and a gloo process group (RCCL refuses two ranks on one device)
     ap.add_argument("--debug-single-device", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--all-subexposures", action="store_true",
+                    help="switch the reduced-node exposure average off: every cell evaluates all nsamples "
+                         "sub-exposures (the plain algorithm's instruction stream; profiles/r01_*_all_sub*.json)")
     ap.add_argument("--fp32-model", action="store_true",
                     help="BASELINE config 5: fp32 Mandel-Agol arithmetic, fp64 orbit/chi^2/log-mean-exp "
                          "(flux within 1e-6, chi^2/2 within 2e-4 relative of the fp64 path)")
@@ -76,6 +79,8 @@ def main():
     else:
         torch.cuda.set_device(0)
     _lib.require_gpu()
+    if args.all_subexposures:
+        _lib.lib().trx_set_supersample_tiers(0)
     device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
 
     def gather(dst, src):
@@ -167,6 +172,7 @@ def main():
         alg_bytes_per_launch = (8.0 * n_par + 8.0) * n_rows + 16.0 * n_time
         kernels = {"rows_kernel<lnl>": {
             "bound": "fp64_valu", "mean_launch_ms": mean_launch_s * 1e3,
+            "all_subexposures": bool(args.all_subexposures),
             "evals_per_launch": evals_per_launch, "p_in": p_in, "flop_per_eval": flop_per_eval,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "hbm_GBps": alg_bytes_per_launch / mean_launch_s / 1e9}}
@@ -213,10 +219,16 @@ def main():
                        "evals_per_step_per_gpu": evals_per_step_per_gpu,
                        "parallelism": "scenario-sharded x%d, one all_gather of lnZ" % world},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TF,
+                         "frac_all_subexposures": all_sub_frac(n_time, n_rows, args),
                          "unit": "TFLOP/s", "frac": achieved_tf / FP64_VALU_PEAK_TF,
                          "traffic": pmc_traffic(n_time, n_rows),
                          "note": "dominant kernel rows_kernel<lnl> is fp64-VALU bound (no MFMA shape, "
-                                 "~0.05 B/eval of HBM traffic); HBM-bound reductions under 'kernels'"},
+                                 "~0.05 B/eval of HBM traffic); HBM-bound reductions under 'kernels'. "
+                                 "achieved = algorithmic flops of the plain S-sub-exposure algorithm / "
+                                 "launch time; the kernel reaches the same averages (to 1e-13) from fewer "
+                                 "Chebyshev nodes where the exposure is far from the limb contacts, so "
+                                 "frac_all_subexposures (shortcut off, every sub-exposure evaluated) is "
+                                 "the figure for the instruction stream itself"},
             "kernels": kernels,
             "cpu_baseline": cpu,
             "lnZ_checksum": float(np.nansum(lnz_host[np.isfinite(lnz_host)])),
@@ -225,6 +237,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def all_sub_frac(n_time, n_rows, args):
+    """roofline fraction of the same workload with every sub-exposure evaluated (this run when
+    --all-subexposures is given, else the committed run of that mode, profiles/all_subexposures.json)"""
+    if args.fp32_model:
+        return None
+    path = os.path.join(ROOT, "profiles", "all_subexposures.json")
+    if args.all_subexposures or not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("n_time") == n_time and rec.get("n_samples") == n_rows:
+        return rec["frac"]
+    return None
 
 
 def pmc_traffic(n_time, n_rows):

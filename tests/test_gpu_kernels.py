@@ -46,22 +46,71 @@ def test_lnl_batch_matches_oracle(fam, n_time):
     _cmp_h(got, want)
 
 
-@pytest.mark.parametrize("stepping", [0, 1])
+@pytest.mark.parametrize("stepping,tiers", [(0, 1), (1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("rows_per_wave", [0, 1, 4, 16])
-def test_launch_knobs_do_not_change_results(stepping, rows_per_wave):
+def test_launch_knobs_do_not_change_results(stepping, tiers, rows_per_wave):
     rng, t, flux = _lc(150)
     rows = synth.eb_rows(rng, 333, has_companion=True)
     L = _lib.lib()
     try:
         L.trx_set_kepler_stepping(stepping)
+        L.trx_set_supersample_tiers(tiers)
         L.trx_set_rows_per_wave(rows_per_wave)
         got = _lib.lnl_batch(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA,
                              _lib.dev(rows), synth.EXPTIME, synth.NSAMPLES).cpu().numpy()
     finally:
         L.trx_set_kepler_stepping(1)
+        L.trx_set_supersample_tiers(1)
         L.trx_set_rows_per_wave(0)
     want = O.lnl_batch(O.MODEL_EB, t, flux, synth.SIGMA, rows)
     _cmp_h(got, want)
+
+
+def _raw_stress_rows(rng, n):
+    """pytransit-shaped rows far outside the bench's ranges: deep and grazing geometries, k up to
+    1.5, e up to 0.95, periods from 0.3 to 100 d, orbits down to 1.5 stellar radii"""
+    k = np.where(rng.random(n) < 0.7, rng.uniform(0.01, 0.3, n), rng.uniform(0.3, 1.5, n))
+    a = 10 ** rng.uniform(np.log10(1.5), np.log10(60), n)
+    e = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(0, 0.95, n))
+    w = rng.uniform(0, 2 * np.pi, n)
+    b = rng.uniform(0, 1 + k)
+    inc = np.arccos(np.clip(b / (a * (1 - e * e) / (1 + e * np.sin(w))), 0, 1))
+    per = 10 ** rng.uniform(np.log10(0.3), 2, n)
+    rows = np.stack([k, rng.uniform(-0.02, 0.02, n), per, a, inc, e, w, rng.uniform(0.1, 0.6, n),
+                     rng.uniform(0.05, 0.4, n)])
+    return np.ascontiguousarray(rows[:, a * (1 - e) > 1 + k])
+
+
+@pytest.mark.parametrize("exptime,S,unfolded", [(0.00139, 20, False), (0.0204, 20, False), (0.0204, 50, False),
+                                                (0.00139, 12, False), (0.00139, 20, True), (0.00139, 8, False)])
+def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfolded):
+    """The kernel averages the model over fewer Chebyshev nodes where the exposure is far from the
+    limb contacts (trx_device.hpp TierTable).  Against the same kernel evaluating all S
+    sub-exposures: flux within 2e-13 everywhere, bit-identical where no tier applies (S < 9) and
+    exactly 1 out of transit; and against the oracle within the usual 5e-13."""
+    rng = np.random.default_rng(100 + S)
+    rows = _raw_stress_rows(rng, 1500)
+    t = np.sort(rng.uniform(-3.0, 3.0, 1200)) if unfolded else np.linspace(-0.45, 0.45, 900)
+    L = _lib.lib()
+    g = {}
+    try:
+        for on in (1, 0):
+            L.trx_set_supersample_tiers(on)
+            g[on] = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), exptime, S,
+                                   want_secdepth=False)[0].cpu().numpy()
+    finally:
+        L.trx_set_supersample_tiers(1)
+    d = np.abs(g[1] - g[0])
+    assert np.nanmax(d) < 2e-13, np.nanmax(d)
+    assert np.array_equal(np.isnan(g[1]), np.isnan(g[0]))
+    assert np.array_equal(g[1] == 1.0, g[0] == 1.0)                # out of transit stays exactly 1
+    if S < 9:
+        assert np.array_equal(g[1], g[0], equal_nan=True)
+    else:
+        assert (d > 0).mean() > 0.02                               # the reduced sets are in use
+    k1 = rows[0] <= 1.0
+    want = O.evaluate_pv(t, rows[:7, k1][:, :300].T, rows[7:, k1][:, :300].T, exptime, S)
+    assert np.abs(g[1][k1][:300] - want).max() < ATOL_FLUX
 
 
 @pytest.mark.parametrize("model,is_host", [(0, False), (0, True), (1, False), (1, True), (2, False)])

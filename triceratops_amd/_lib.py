@@ -73,6 +73,8 @@ def lib():
     L.trx_set_rows_per_wave.argtypes = [c_int]
     L.trx_set_kepler_stepping.restype = c_int
     L.trx_set_kepler_stepping.argtypes = [c_int]
+    L.trx_set_supersample_tiers.restype = c_int
+    L.trx_set_supersample_tiers.argtypes = [c_int]
     L.trx_version.restype = ctypes.c_char_p
     L.trx_last_error.restype = ctypes.c_char_p
     L.trx_device_count.restype = c_int

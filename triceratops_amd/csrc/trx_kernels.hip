@@ -58,6 +58,8 @@ struct RowsArgs {
     double* out_sec;   // MODE_GRID: [n] or null
     int B;
     long nbatch;
+    int use_tiers;
+    TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
     double s2, dS, rS;
@@ -85,6 +87,15 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     RowC* rows = reinterpret_cast<RowC*>(lds);
     RowC* srows = rows + B;                                           // secondary-eclipse orbits
     double* sec = lds + 2 * (size_t)B * kRowDoubles;                  // [B][25]
+    double* tier_xw = sec + (size_t)B * kSecPoints;                   // [x | w] of the tier table
+    if (a.use_tiers && threadIdx.x == 0) {
+        // constant indices only: a dynamically indexed by-value kernel argument is copied to scratch
+#pragma unroll
+        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
+            tier_xw[i] = a.tiers.x[i];
+            tier_xw[kTiers * kTierMaxNodes + i] = a.tiers.w[i];
+        }
+    }
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
                 double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
                 if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false);
+                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers, nullptr);
             }
             __syncthreads();
             if (lane < nb) {
@@ -191,7 +202,8 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
             const Limb L{c.cle, c.cld, c.ced};
             double acc = 0.0;
             for (int j = lane; j < a.n_time; j += 64) {
-                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, a.dS, a.rS, STEP);
+                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, a.dS, a.rS, STEP,
+                                               a.tiers, a.use_tiers ? tier_xw : nullptr);
                 if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                 if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
                 if (MODE == MODE_GRID) {
@@ -407,6 +419,45 @@ int n_params(int model)
     }
 }
 
+// Chebyshev node sets and the weights that reproduce the S-point average of their interpolant:
+// w_j = mean over the S sample points of the j-th Lagrange basis polynomial (see TierTable).
+// Radii from the measured error decay (profiles/r01_j_tier_error.txt): <= ~2e-14 per tier.
+int g_tiers = 1;
+bool fill_tiers(TierTable& T, int S)
+{
+    static const int nn[kTiers] = {5, 7, 10, 12};
+    static const double rad[kTiers] = {36.0, 11.0, 5.5, 3.25};
+    bool any = false;
+    for (int q = 0; q < kTiers; ++q) {
+        const int n = nn[q];
+        T.n[q] = 0;
+        T.radius[q] = rad[q];
+        for (int j = 0; j < kTierMaxNodes; ++j) T.x[q * kTierMaxNodes + j] = T.w[q * kTierMaxNodes + j] = 0.0;
+        if (n + 4 > S) continue;                       // not worth it for small S
+        const double half = 0.5 * (1.0 - 1.0 / S);      // the sample points span [-half, half] x exptime
+        long double x[kTierMaxNodes], w[kTierMaxNodes], sum = 0.0L;
+        for (int j = 0; j < n; ++j) x[j] = -half * cosl((2 * j + 1) * 3.14159265358979323846264338327950288L / (2 * n));
+        for (int j = 0; j < n; ++j) {
+            long double acc = 0.0L;
+            for (int s = 1; s <= S; ++s) {
+                const long double xs = ((long double)s - 0.5L) / S - 0.5L;
+                long double l = 1.0L;
+                for (int m = 0; m < n; ++m) if (m != j) l *= (xs - x[m]) / (x[j] - x[m]);
+                acc += l;
+            }
+            w[j] = acc / S;
+            sum += w[j];
+        }
+        for (int j = 0; j < n; ++j) {
+            T.x[q * kTierMaxNodes + j] = (double)x[j];
+            T.w[q * kTierMaxNodes + j] = (double)(w[j] / sum);
+        }
+        T.n[q] = n;
+        any = true;
+    }
+    return any;
+}
+
 int pick_rows_per_wave(int n_time, long n)
 {
     if (g_rows_per_wave > 0) return g_rows_per_wave;
@@ -429,7 +480,8 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     a.nbatch = (a.n + a.B - 1) / a.B;
     const long max_grid = 1L << 20;
     const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
-    const size_t lds = (size_t)a.B * (2 * kRowDoubles + kSecPoints) * sizeof(double);
+    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers;
+    const size_t lds = ((size_t)a.B * (2 * kRowDoubles + kSecPoints) + 2 * kTiers * kTierMaxNodes) * sizeof(double);
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step)    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
@@ -479,7 +531,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -491,7 +543,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -630,6 +682,13 @@ int trx_set_rows_per_wave(int rows)
 int trx_set_kepler_stepping(int on)
 {
     g_step = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* test/bench knob (not in the public header): 0 = evaluate all S sub-exposures of every cell */
+int trx_set_supersample_tiers(int on)
+{
+    g_tiers = on ? 1 : 0;
     return TRX_OK;
 }
 
