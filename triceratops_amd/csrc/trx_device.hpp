@@ -568,7 +568,7 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 // same S points -- a fixed weighted sum of n model values.  The model is analytic away from the
 // limb contacts z = 1 + k and z = |1 - k|; the interpolation error falls geometrically with the
 // distance to the nearest (real or complex) contact time in units of the half exposure
-// (profiles/r01_j_tier_error.txt), so each tier carries the zero-free radius it needs.
+// (profiles/r01_l_tier_error.txt), so each tier carries the zero-free radius it needs.
 constexpr int kTiers = 4, kTierMaxNodes = 12;
 struct TierTable {
     int n[kTiers];                         // nodes per tier, ascending; 0 = tier unused
@@ -577,78 +577,103 @@ struct TierTable {
     double w[kTiers * kTierMaxNodes];      // weights of the flux deficits 1 - f
 };
 
-// Mean model flux of one exposure (centre t), S sub-exposures: the body of
-// pytransit's evaluate_pv for one (row, time) cell.  `tiers` = LDS copy of the TierTable
-// arrays ([x | w]) or null to evaluate all S sub-exposures everywhere.
-template <bool FP32 = false>
-__device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
-                                                double exptime, int S, double dS, double rS, bool stepping,
-                                                const TierTable& tt, const double* tiers)
+// What one (row, time) cell has to evaluate: n nodes of tier `tier` (-1 = all S sub-exposures),
+// or nothing (n = 0: the exposure is unocculted and its mean flux is exactly 1).
+struct CellPlan {
+    int n = 0, tier = -1;
+    double sE = 0.0, cE = 1.0, Mprev = 0.0;     // eccentric-anomaly state carried along the nodes
+    bool anchored = false;                       // state holds a solution (at the exposure centre)
+};
+
+__device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
+                                              const TierTable& tt, bool use_tiers)
 {
+    CellPlan p;
     const double phase = c.nmot * (t - c.t0);
     const double dMc = reduce_2pi(phase);
     // the reduction is good to ~1e-16 |phase|: widen the window by that much
     const double slack = 1e-15 * fabs(phase);
-    if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return 1.0;
-    const double opp = 1.0 + c.k;
-    const double opp2 = opp * opp;
-    double sE = 0.0, cE = 1.0, Mprev = 0.0;
-    int tier = -1, n = S;
-    if (tiers) {
-        // orbit at the exposure centre: position, velocity and the quadratic model of z^2(t)
-        Mprev = phase + c.Mtr;
-        kepler_full(Mprev, c.e, sE, cE);
-        const double rho = rcp_fast(fma(-c.e, cE, 1.0));
-        const double ce = cE - c.e;
-        const double X = fma(c.ax, ce, c.bx * sE), Y = fma(c.ay, ce, c.by * sE);
-        const double yc = Y * c.cosi;
-        const double nr = c.nmot * rho;
-        const double Xp = fma(c.bx, cE, -c.ax * sE) * nr, Yp = fma(c.by, cE, -c.ay * sE) * nr;
-        const double ycp = Yp * c.cosi;
-        const double z2 = fma(X, X, yc * yc);
-        const double g1 = fabs(2.0 * fma(X, Xp, yc * ycp));
-        const double g2 = fabs(fma(Xp, Xp, ycp * ycp) - (nr * nr) * rho * z2);
-        const double omk = 1.0 - c.k;
-        const double G = fmin(fabs(z2 - opp2), fabs(z2 - omk * omk));   // distance of z^2 to the contacts
-        const double hx = 0.5 * fabs(exptime);
-        const double om = fabs(nr) * rho;                                // bound on the angular rate
+    if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return p;
+    p.n = S;
+    if (!use_tiers) return p;
+    // orbit at the exposure centre: position, velocity and the quadratic model of z^2(t)
+    const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
+    p.Mprev = phase + c.Mtr;
+    kepler_full(p.Mprev, c.e, p.sE, p.cE);
+    p.anchored = true;
+    const double rho = rcp_fast(fma(-c.e, p.cE, 1.0));
+    const double ce = p.cE - c.e;
+    const double X = fma(c.ax, ce, c.bx * p.sE), Y = fma(c.ay, ce, c.by * p.sE);
+    const double yc = Y * c.cosi;
+    const double nr = c.nmot * rho;
+    const double Xp = fma(c.bx, p.cE, -c.ax * p.sE) * nr, Yp = fma(c.by, p.cE, -c.ay * p.sE) * nr;
+    const double ycp = Yp * c.cosi;
+    const double z2 = fma(X, X, yc * yc);
+    const double g1 = fabs(2.0 * fma(X, Xp, yc * ycp));
+    const double g2 = fabs(fma(Xp, Xp, ycp * ycp) - (nr * nr) * rho * z2);
+    const double G = fmin(fabs(z2 - opp2), fabs(z2 - omk * omk));   // distance of z^2 to the contacts
+    const double hx = 0.5 * fabs(exptime);
+    const double om = fabs(nr) * rho;                                // bound on the angular rate
 #pragma unroll
-        for (int q = kTiers - 1; q >= 0; --q) {
-            // smallest node count first (q = 0) wins: scan from the largest
-            const double tau = tt.radius[q] * hx;
-            const bool ok = tt.n[q] > 0 && G >= 1.25 * fma(g2 * tau, tau, g1 * tau) &&
-                            om * tau <= 0.15 && Y > fabs(Yp) * tau;
-            if (ok) { tier = q; n = tt.n[q]; }
-        }
-        // whole exposure off the disc: every sub-exposure is exactly 1
-        const double tau1 = 1.5 * hx;
-        if (z2 > opp2 && G >= 1.25 * fma(g2 * tau1, tau1, g1 * tau1) && om * tau1 <= 0.15) return 1.0;
+    for (int q = kTiers - 1; q >= 0; --q) {
+        // scanned from the largest node count down: the smallest admissible one wins
+        const double tau = tt.radius[q] * hx;
+        const bool ok = tt.n[q] > 0 && G >= 1.25 * fma(g2 * tau, tau, g1 * tau) &&
+                        om * tau <= 0.15 && Y > fabs(Yp) * tau;
+        if (ok) { p.tier = q; p.n = tt.n[q]; }
     }
-    const double* xs = tiers ? tiers + (tier < 0 ? 0 : tier) * kTierMaxNodes : nullptr;
-    const double* ws = tiers ? xs + kTiers * kTierMaxNodes : nullptr;
+    // whole exposure off the disc: every sub-exposure is exactly 1
+    const double tau1 = 1.5 * hx;
+    if (z2 > opp2 && G >= 1.25 * fma(g2 * tau1, tau1, g1 * tau1) && om * tau1 <= 0.15) p.n = 0;
+    return p;
+}
+
+// Node s (1-based) of the plan: advances the orbit; returns z^2 (NaN propagates) and Y (< 0 on
+// the far side of the orbit).  frac = node offset / exptime.
+__device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, double exptime,
+                                          double frac, bool stepping, double& Y)
+{
+    const double M = c.nmot * ((t + exptime * frac) - c.t0) + c.Mtr;
+    bool have = false;
+    if (stepping && p.anchored) have = kepler_step(M - p.Mprev, c.e, p.sE, p.cE);
+    if (!have) kepler_full(M, c.e, p.sE, p.cE);
+    p.anchored = true;
+    p.Mprev = M;
+    const double ce = p.cE - c.e;
+    const double X = fma(c.ax, ce, c.bx * p.sE);
+    Y = fma(c.ay, ce, c.by * p.sE);
+    const double yc = Y * c.cosi;
+    return fma(X, X, yc * yc);
+}
+
+template <bool FP32>
+__device__ __forceinline__ double disc_flux(double z, double k, const Limb& L)
+{
+    return FP32 ? ma_flux_f32(z, k, L) : ma_flux(z, k, L);
+}
+
+// Mean model flux of one exposure (centre t) evaluated by one lane: the body of pytransit's
+// evaluate_pv for one (row, time) cell.  Used for the 25-point secondary-eclipse scan (S = 1);
+// the time axis of the light curve goes through the packed path of rows_kernel.
+__device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
+                                                double exptime, int S, double dS, double rS, bool stepping,
+                                                const TierTable& tt)
+{
+    CellPlan p = plan_cell(c, t, exptime, S, tt, false);
+    if (p.n == 0) return 1.0;
+    const double opp = 1.0 + c.k, opp2 = opp * opp;
     double acc = 0.0;
 #pragma unroll 1
-    for (int s = 1; __any(s <= n); ++s) {
-        if (s <= n) {
-            // exptime*((s-0.5)/S - 0.5) up to an ulp of the offset (~1e-20 d)
-            const double frac = (tier < 0) ? fma((double)s - 0.5, rS, -0.5) : xs[s - 1];
-            const double M = c.nmot * ((t + exptime * frac) - c.t0) + c.Mtr;
-            bool have = false;
-            if (stepping && (s > 1 || tiers)) have = kepler_step(M - Mprev, c.e, sE, cE);
-            if (!have) kepler_full(M, c.e, sE, cE);
-            Mprev = M;
-            const double ce = cE - c.e;
-            const double X = fma(c.ax, ce, c.bx * sE);
-            const double Y = fma(c.ay, ce, c.by * sE);
-            const double yc = Y * c.cosi;
-            const double z2 = fma(X, X, yc * yc);
-            double f = 1.0;
-            if (Y >= 0.0 && z2 < opp2) f = FP32 ? ma_flux_f32(sqrt_fast(z2), c.k, L) : ma_flux(sqrt_fast(z2), c.k, L);
-            else if (z2 != z2) f = z2;
-            acc += (tier < 0) ? f : ws[s - 1] * (1.0 - f);
-        }
+    for (int s = 1; s <= S; ++s) {
+        double Y;
+        // exptime*((s-0.5)/S - 0.5) up to an ulp of the offset (~1e-20 d)
+        const double z2 = node_z2(c, p, t, exptime, fma((double)s - 0.5, rS, -0.5), stepping, Y);
+        double f = 1.0;
+        if (Y >= 0.0 && z2 < opp2) f = ma_flux(sqrt_fast(z2), c.k, L);
+        else if (z2 != z2) f = z2;
+        acc += f;
     }
-    return (tier < 0) ? acc / dS : 1.0 - acc;
+    return acc / dS;
 }
 
 }  // namespace trx

@@ -58,12 +58,36 @@ struct RowsArgs {
     double* out_sec;   // MODE_GRID: [n] or null
     int B;
     long nbatch;
-    int use_tiers;
+    int use_tiers, SB;
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
     double s2, dS, rS;
 };
+
+// nodes of a 64-cell chunk staged in LDS per pass: 12 x 64 x (8 + 2) B = 7.5 KB per wave, so that
+// LDS never limits the 16 waves per CU the register budget allows; 12 covers every reduced
+// node set in one pass, the all-sub-exposure cells near the contacts take two
+// (profiles/r01_k_ab_pack.txt: 20 -> 11.70 ms, 12 -> 11.24, 10 -> 11.26, 8 -> 11.41 at 3 waves/SIMD)
+#ifndef TRX_NODES_PER_PASS
+#define TRX_NODES_PER_PASS 12
+#endif
+constexpr int kMaxNodesPerPass = TRX_NODES_PER_PASS;
+
+// a wave-uniform double moved to a scalar register pair
+__device__ __forceinline__ double uniform(double v)
+{
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// number of set bits of `m` below this lane
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
 __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
@@ -73,10 +97,13 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
     return k;
 }
 
-// register budget: 3 waves/SIMD (168 VGPRs) measured best on MI355X (profiles/r01_ab_waves.txt);
-// the few spills land in the once-per-row prologue
+// register budget: with the staged evaluation the kernel waits on LDS round trips between its
+// stages and gains from a 4th wave per SIMD (128 VGPRs): 11.24 -> 10.53 ms per launch.  That
+// budget holds without scratch because the row constants ride in SGPRs in the time loop and are
+// built in place in LDS in the prologue (12 B/lane left, once per row); 5 waves spill into the
+// hot loops (14.4 ms).  profiles/r01_k_ab_pack.txt
 #ifndef TRX_WAVES_PER_EU
-#define TRX_WAVES_PER_EU 3
+#define TRX_WAVES_PER_EU 4
 #endif
 
 template <int MODE, bool STEP, bool FP32>
@@ -88,6 +115,10 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     RowC* srows = rows + B;                                           // secondary-eclipse orbits
     double* sec = lds + 2 * (size_t)B * kRowDoubles;                  // [B][25]
     double* tier_xw = sec + (size_t)B * kSecPoints;                   // [x | w] of the tier table
+    const int SB = a.SB;                                              // nodes per lane per pass
+    const int cap = 64 * SB;
+    double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
+    unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
     if (a.use_tiers && threadIdx.x == 0) {
         // constant indices only: a dynamically indexed by-value kernel argument is copied to scratch
 #pragma unroll
@@ -111,7 +142,9 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         // ---- phase 1: per-row constants ------------------------------------------------
         if (lane < nb) {
             const double* p = a.params + base + lane;
-            RowC c;
+            // built in place in LDS: a local copy keeps 36 VGPRs live across the libm calls of
+            // orbit_init and pushes the prologue into scratch
+            RowC& c = rows[lane];
             double u1, u2;
             if (a.model == TRX_MODEL_RAW) {
                 u1 = p[7 * n]; u2 = p[8 * n];
@@ -141,13 +174,12 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                     c.xeb = 0.0;
                     c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
                 } else {
-                    RowC sc;
+                    RowC& sc = srows[lane];
                     const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
                     orbit_init(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
                     const Limb L = limb_weights(u1, u2);
                     sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
                     sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
-                    srows[lane] = sc;
                     if (is_host) {                                          // :427-432
                         c.xeb = feb / fcomp;
                         ysec = fcomp / feb;
@@ -162,7 +194,6 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
             const Limb L = limb_weights(u1, u2);
             c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
             c.excl = 0.0;
-            rows[lane] = c;
         }
         __syncthreads();
 
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
                 double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
                 if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers, nullptr);
+                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
             }
             __syncthreads();
             if (lane < nb) {
@@ -197,20 +228,93 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         }
 
         // ---- phase 4: the light-curve model over the time axis --------------------------
+        // Lanes are 64 consecutive time stamps of one row.  Neighbouring cells need different
+        // numbers of model evaluations (5-12 nodes, all S sub-exposures near the contacts, none
+        // off the disc), so the evaluations are not run where they are found.  Stage A: each lane
+        // plans its cell, advances the orbit along its nodes and files every occulted node, by
+        // case (disc inside the limb / crossing it), in a list in LDS.  Stage B: the Mandel-Agol
+        // flux over the lists, 64 items of ONE case per pass.  Stage C: each lane sums its cell's
+        // nodes in their original order.
         for (int r = 0; r < nb; ++r) {
-            const RowC c = rows[r];
+            // the row constants are wave-uniform: held in scalar registers they cost no VGPRs
+            // (36 otherwise, which at 128 VGPRs per lane spill into the time loop)
+            RowC c;
+            {
+                const double* src = reinterpret_cast<const double*>(&rows[r]);
+                double* dst = reinterpret_cast<double*>(&c);
+#pragma unroll
+                for (int q = 0; q < kRowDoubles; ++q) dst[q] = uniform(src[q]);
+            }
             const Limb L{c.cle, c.cld, c.ced};
+            const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
             double acc = 0.0;
-            for (int j = lane; j < a.n_time; j += 64) {
-                double m = exposure_flux<FP32>(c, L, a.time[j], a.exptime, a.S, a.dS, a.rS, STEP,
-                                               a.tiers, a.use_tiers ? tier_xw : nullptr);
-                if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
-                if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
-                if (MODE == MODE_GRID) {
-                    a.out[(size_t)(base + r) * a.n_time + j] = m;
-                } else {
-                    const double d = a.flux[j] - m;
-                    acc += (d * d) / s2;                                    // :486, :537, :586
+            for (int j0 = 0; j0 < a.n_time; j0 += 64) {
+                const int j = j0 + lane;
+                const bool valid = j < a.n_time;
+                const double t = valid ? a.time[j] : 0.0;
+                CellPlan pl;
+                if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
+                const double* ws = xs + kTiers * kTierMaxNodes;
+                double fsum = 0.0;
+                for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
+                    int n_in = 0, n_lb = 0, ns = 0;
+                    // stage A
+                    for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
+                        const int s = s0 + si + 1;
+                        int cls = 0;
+                        double v = 1.0;
+                        if (s <= pl.n) {
+                            const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
+                            double Y;
+                            const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
+                            if (Y >= 0.0 && z2 < opp2) {
+                                v = sqrt_fast(z2);
+                                cls = (c.k < 1.0 && v <= omk) ? 1 : 2;
+                            } else if (z2 != z2) {
+                                v = z2;
+                            }
+                        }
+                        const int idx = si * 64 + lane;
+                        zbuf[idx] = v;
+                        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+                        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
+                        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
+                        n_in += __popcll(m1);
+                        n_lb += __popcll(m2);
+                        ns = si + 1;
+                    }
+                    __syncthreads();
+                    // stage B: inside items first (padded to whole passes), then the rest
+                    const int n_in_pad = (n_in + 63) & ~63;
+                    for (int i = lane; i < n_in_pad + n_lb; i += 64) {
+                        const bool head = i < n_in_pad;
+                        if (!head || i < n_in) {
+                            const int idx = head ? items[i] : items[cap - 1 - (i - n_in_pad)];
+                            zbuf[idx] = disc_flux<FP32>(zbuf[idx], c.k, L);
+                        }
+                    }
+                    __syncthreads();
+                    // stage C
+                    for (int si = 0; si < ns; ++si) {
+                        const int s = s0 + si + 1;
+                        if (s <= pl.n) {
+                            const double f = zbuf[si * 64 + lane];
+                            fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (valid) {
+                    double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
+                    if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
+                    if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
+                    if (MODE == MODE_GRID) {
+                        a.out[(size_t)(base + r) * a.n_time + j] = m;
+                    } else {
+                        const double d = a.flux[j] - m;
+                        acc += (d * d) / s2;                                // :486, :537, :586
+                    }
                 }
             }
             if (MODE == MODE_LNL) {
@@ -421,7 +525,7 @@ int n_params(int model)
 
 // Chebyshev node sets and the weights that reproduce the S-point average of their interpolant:
 // w_j = mean over the S sample points of the j-th Lagrange basis polynomial (see TierTable).
-// Radii from the measured error decay (profiles/r01_j_tier_error.txt): <= ~2e-14 per tier.
+// Radii from the measured error decay (profiles/r01_l_tier_error.txt): <= ~2e-14 per tier.
 int g_tiers = 1;
 bool fill_tiers(TierTable& T, int S)
 {
@@ -481,7 +585,9 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     const long max_grid = 1L << 20;
     const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers;
-    const size_t lds = ((size_t)a.B * (2 * kRowDoubles + kSecPoints) + 2 * kTiers * kTierMaxNodes) * sizeof(double);
+    a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
+    const size_t lds = ((size_t)a.B * (2 * kRowDoubles + kSecPoints) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
+                     + (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short));
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step)    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
@@ -531,7 +637,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -543,7 +649,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
