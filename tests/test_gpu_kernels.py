@@ -363,3 +363,21 @@ def test_concurrent_streams_do_not_interfere():
         lnL = np.full(30000, -np.inf)
         lnL[:3000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h
         assert abs(float(lnz.cpu()[0]) - O.log_mean_exp(lnL, 30000)) < 1e-9
+
+
+def test_node_census_knob_reports_the_plan_of_every_cell():
+    """trx_set_debug_node_counts: grid mode returns the number of model evaluations per cell --
+    0 exactly where the flux is exactly 1 without evaluation, nsupersample near the contacts, and
+    one of the reduced node counts elsewhere"""
+    rng, t, _ = _lc(2000)
+    rows = _lib.dev(synth.tp_rows(rng, 64))
+    L = _lib.lib()
+    flux = _lib.flux_grid(0, 0, _lib.dev(t), rows, synth.EXPTIME, 20, False)[0].cpu().numpy()
+    L.trx_set_debug_node_counts(1)
+    try:
+        n = _lib.flux_grid(0, 0, _lib.dev(t), rows, synth.EXPTIME, 20, False)[0].cpu().numpy()
+    finally:
+        L.trx_set_debug_node_counts(0)
+    assert set(np.unique(n)) <= {0.0, 5.0, 7.0, 10.0, 12.0, 20.0} and {0.0, 5.0, 20.0} <= set(np.unique(n))
+    assert np.all(flux[n == 0] == 1.0) and np.all(n[flux < 1.0] > 0)
+    assert 1.5 < n.mean() < 6.0

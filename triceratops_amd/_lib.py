@@ -75,6 +75,8 @@ def lib():
     L.trx_set_kepler_stepping.argtypes = [c_int]
     L.trx_set_supersample_tiers.restype = c_int
     L.trx_set_supersample_tiers.argtypes = [c_int]
+    L.trx_set_debug_node_counts.restype = c_int
+    L.trx_set_debug_node_counts.argtypes = [c_int]
     L.trx_version.restype = ctypes.c_char_p
     L.trx_last_error.restype = ctypes.c_char_p
     L.trx_device_count.restype = c_int

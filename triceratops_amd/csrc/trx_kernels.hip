@@ -58,7 +58,7 @@ struct RowsArgs {
     double* out_sec;   // MODE_GRID: [n] or null
     int B;
     long nbatch;
-    int use_tiers, SB;
+    int use_tiers, SB, debug_nodes;
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                     double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
                     if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                     if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
+                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
                     if (MODE == MODE_GRID) {
                         a.out[(size_t)(base + r) * a.n_time + j] = m;
                     } else {
@@ -527,6 +528,7 @@ int n_params(int model)
 // w_j = mean over the S sample points of the j-th Lagrange basis polynomial (see TierTable).
 // Radii from the measured error decay (profiles/r01_l_tier_error.txt): <= ~2e-14 per tier.
 int g_tiers = 1;
+int g_debug_nodes = 0;  // grid mode writes the number of model evaluations per cell instead of the flux
 bool fill_tiers(TierTable& T, int S)
 {
     static const int nn[kTiers] = {5, 7, 10, 12};
@@ -637,7 +639,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -649,7 +651,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -795,6 +797,14 @@ int trx_set_kepler_stepping(int on)
 int trx_set_supersample_tiers(int on)
 {
     g_tiers = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* test/bench knob (not in the public header): trx_flux_grid writes the number of model
+   evaluations planned for each cell (0, a reduced node count, or nsupersample) instead of the flux */
+int trx_set_debug_node_counts(int on)
+{
+    g_debug_nodes = on ? 1 : 0;
     return TRX_OK;
 }
 
