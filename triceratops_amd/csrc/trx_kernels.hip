@@ -134,7 +134,15 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     const long n = a.n;
     const double s2 = a.s2;
 
-    for (long batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    // Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one), each with its own L2.
+    // A row's 10-11 parameters are single 8-byte reads from 10-11 arrays, eight neighbouring rows
+    // per 64 B line: with batch = block index every XCD fetches every line.  So virtual block v
+    // takes batch (v % 8) * ceil(nbatch / 8) + v / 8: each XCD works through one contiguous
+    // eighth of the rows and its L2 sees each parameter line once (FETCH_SIZE 34 -> 7 MB).
+    const long per_xcd = (a.nbatch + 7) / 8;
+    for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
+        const long batch = (v & 7) * per_xcd + (v >> 3);
+        if ((v >> 3) >= per_xcd || batch >= a.nbatch) continue;
         const long base = batch * B;
         const int nb = (int)((n - base < B) ? (n - base) : B);
         double ysec = 0.0;
@@ -585,7 +593,8 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     a.rS = 1.0 / a.dS;
     a.nbatch = (a.n + a.B - 1) / a.B;
     const long max_grid = 1L << 20;
-    const unsigned grid = (unsigned)(a.nbatch < max_grid ? a.nbatch : max_grid);
+    const long want_grid = 8 * ((a.nbatch + 7) / 8);          // a multiple of 8: v % 8 == blockIdx % 8
+    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers;
     a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
     const size_t lds = ((size_t)a.B * (2 * kRowDoubles + kSecPoints) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
