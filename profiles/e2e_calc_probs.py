@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=1_000_000)
 ap.add_argument("--nearby", type=int, default=20)
 ap.add_argument("--n-time", type=int, default=100)
-ap.add_argument("--sampling", default="numpy", choices=["numpy", "device"])
+ap.add_argument("--sampling", default="numpy", choices=["numpy", "numpy-device", "device"])
 args = ap.parse_args()
 
 import triceratops_amd

@@ -65,20 +65,7 @@ def test_priors_match_host_functions():
                   g["bound_TP_nocc_" + tag], 1e-10)
 
 
-class NumpyStreamRng:
-    """replays numpy's global legacy stream exactly where the reference consumes it"""
-
-    def uniform(self, n, device):
-        return T(np.random.rand(n))
-
-    def beta(self, n, a, b, device):
-        return T(np.random.beta(a, b, size=n))
-
-    def randint(self, hi, n, device):
-        return torch.as_tensor(np.random.randint(0, hi, n))
-
-    def discard(self, n):
-        np.random.rand(n)
+NumpyStreamRng = dp.NumpyStreamRng
 
 
 G = gold("lnz_cases.npz")
@@ -145,6 +132,14 @@ def test_sampling_switch(monkeypatch):
         triceratops_amd.set_sampling("numpy")
     with pytest.raises(ValueError):
         triceratops_amd.set_sampling("cuda")
+    # numpy-device: the numpy stream feeds the device pipeline; per-draw-loop calls stay on the host
+    triceratops_amd.set_sampling("numpy-device")
+    try:
+        assert isinstance(dp.RNG, dp.NumpyStreamRng)
+        n0 = len(calls)
+        assert ml.lnZ_TTP(1, 2, 3, 4, 5, 6, 7, 8, 100, True)["lnZ"] == 0.0 and len(calls) == n0 + 1
+    finally:
+        triceratops_amd.set_sampling("numpy")
 
 
 @pytest.mark.gpu

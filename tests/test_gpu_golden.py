@@ -193,3 +193,24 @@ def test_unused_lnz_functions_end_to_end(case):
     g = gold("lnz_extra.npz")
     np.random.seed(int(g[case + "_seed"][0]))
     check_extra(call_extra(ml, case, g), case, g, 1e-9)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if not c.endswith("_serial")])
+def test_numpy_device_sampling_reproduces_the_reference_draws(case):
+    """set_sampling('numpy-device'): numpy's stream feeds the GPU-resident pipeline, so the same
+    seed gives the reference's draws; derived columns are computed in torch instead of numpy, hence
+    1e-8 instead of 1e-9 + 1e-12 |lnZ|"""
+    import triceratops_amd
+    from triceratops_amd import marginal_likelihoods as ml
+    name, variant = case.split("_")
+    P = [2.5, 4.0] if variant == "range" else 3.3
+    cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
+    triceratops_amd.set_sampling("numpy-device")
+    try:
+        np.random.seed(int(G[case + "_seed"][0]))
+        res = _call(ml, name, P, int(G["N"][0]), True, cc, "J" if cc else "TESS")
+    finally:
+        triceratops_amd.set_sampling("numpy")
+    for i, d in enumerate(res if isinstance(res, tuple) else (res,)):
+        want = G["%s_lnZ%d" % (case, i)][0]
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-8 + 1e-12 * abs(want)

@@ -8,8 +8,9 @@ __version__ = "0.1.0"
 
 
 def set_sampling(mode):
-    """'numpy' (default): priors sampled on the host from numpy's global stream, draw-for-draw
-    reproducible against the reference; 'device': the whole scenario on the GPU."""
+    """'numpy' (default): priors sampled on the host from numpy's global stream, bit-for-bit the
+    reference's host arithmetic; 'numpy-device': the same stream and draws, everything downstream
+    of the uniforms on the GPU; 'device': the whole scenario on the GPU with torch's generator."""
     from .marginal_likelihoods import set_sampling as _set
     _set(mode)
 

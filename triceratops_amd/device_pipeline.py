@@ -51,6 +51,24 @@ class TorchRng:
         pass
 
 
+class NumpyStreamRng:
+    """numpy's global legacy stream, consumed exactly where the reference consumes it (including
+    the draws it never uses), copied to the device: the same Monte-Carlo draws as the reference
+    under the same np.random.seed, with everything downstream of the uniforms on the GPU."""
+
+    def uniform(self, n, device):
+        return torch.as_tensor(np.random.rand(n)).to(device)
+
+    def beta(self, n, a, b, device):
+        return torch.as_tensor(np.random.beta(a, b, size=n)).to(device)
+
+    def randint(self, hi, n, device):
+        return torch.as_tensor(np.random.randint(0, hi, n)).to(device)
+
+    def discard(self, n):
+        np.random.rand(n)
+
+
 RNG = TorchRng()
 
 

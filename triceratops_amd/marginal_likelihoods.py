@@ -683,23 +683,40 @@ def lnZ_NEB_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
 
 
 # ---------------------------------------------------------------------------------------
-# where the priors are sampled: "numpy" (host, reproduces the reference's random stream draw for
-# draw) or "device" (whole scenario on the GPU, triceratops_amd/device_pipeline.py)
+# where the priors are sampled:
+#   "numpy"         host numpy, the reference's own arithmetic: draw-for-draw and bit-for-bit
+#   "numpy-device"  numpy's global stream supplies the uniforms in the reference's order, everything
+#                   downstream runs on the GPU (triceratops_amd/device_pipeline.py): the same draws
+#                   as the reference, derived columns equal to rounding, ~3-5x faster than "numpy";
+#                   parallel=False calls keep the host path (the per-draw loop semantics)
+#   "device"        torch's device generator: statistically equivalent, fastest
 _sampling = {"mode": "numpy"}
 
 
 def set_sampling(mode):
-    if mode not in ("numpy", "device"):
-        raise ValueError("sampling mode must be 'numpy' or 'device'")
+    if mode not in ("numpy", "numpy-device", "device"):
+        raise ValueError("sampling mode must be 'numpy', 'numpy-device' or 'device'")
+    if mode != "numpy":
+        from . import device_pipeline
+        device_pipeline.RNG = (device_pipeline.NumpyStreamRng() if mode == "numpy-device"
+                               else device_pipeline.TorchRng())
     _sampling["mode"] = mode
 
 
 def _dispatch(fn):
     import functools
+    import inspect
+    sig = inspect.signature(fn)
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        if _sampling["mode"] == "device":
+        mode = _sampling["mode"]
+        if mode == "numpy-device":
+            bound = sig.bind(*args, **kwargs)
+            bound.apply_defaults()
+            if not bound.arguments["parallel"]:
+                mode = "numpy"
+        if mode != "numpy":
             from . import device_pipeline
             return getattr(device_pipeline, fn.__name__)(*args, **kwargs)
         return fn(*args, **kwargs)
