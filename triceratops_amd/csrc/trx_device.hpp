@@ -3,9 +3,12 @@
 // Everything here is scalar-per-lane fp64: the path is elementwise + reduction (no MFMA
 // shape anywhere), bounded by fp64 VALU issue and the div/sqrt/transcendental sequences,
 // not by HBM.  Design notes (DESIGN.md has the full derivations):
-//   * Kepler's equation is solved once per light-curve point; the S sub-exposures of that
-//     point are reached by Newton steps on dE using Taylor kernels for sin(dE), cos(dE)-1
-//     (|dE| ~ 1e-4 rad), so no trig range reduction runs inside the supersample loop.
+//   * Kepler's equation is solved once per light-curve point (at the exposure centre); the nodes
+//     or sub-exposures of that point are reached by Newton steps on dE using Taylor kernels for
+//     sin(dE), cos(dE)-1 (|dE| ~ 1e-3 rad), so no trig range reduction runs in the node loop.
+//   * the S-point exposure average is taken from 5-12 Chebyshev nodes wherever the model is
+//     analytic over the exposure (TierTable / plan_cell), from all S sub-exposures near the limb
+//     contacts, and is exactly 1 off the disc.
 //   * the two Bulirsch `cel` integrals of a Mandel-Agol evaluation share one AGM loop and
 //     one reciprocal per iteration.
 //   * a per-row mean-anomaly window (analytic bound of |X| < 1+k around inferior

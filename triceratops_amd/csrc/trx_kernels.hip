@@ -1,16 +1,19 @@
 // libtrx.so: HIP kernels + C ABI (include/trx.h) for gfx950.
 //
 // Kernels
-//   rows_kernel<MODE, STEP>   one wavefront (64-thread workgroup) per batch of B Monte-Carlo
-//                             rows.  Phase 1: lanes < B derive the per-row constant block
-//                             (unit conversion, radius-ratio rule, orbit constants, transit
-//                             window, dilution, limb weights) and stage it in LDS.
-//                             Phase 2 (EB): the B x 25 secondary-eclipse cells are spread
-//                             over the lanes.  Phase 3: lanes < B reduce them to the
-//                             secondary depth / exclusion flag.  Phase 4: for each row the
-//                             lanes stride the time axis (coalesced time/flux loads), run the
-//                             supersampled model, and either wave-reduce chi^2 (MODE_LNL,
-//                             shuffle butterfly) or store the model row (MODE_GRID).
+//   rows_kernel<MODE, STEP, FP32>
+//                             one wavefront (64-thread workgroup) per batch of B Monte-Carlo
+//                             rows, 4 waves per SIMD.  Phase 1: lanes < B derive the per-row
+//                             constant block (unit conversion, radius-ratio rule, orbit
+//                             constants, transit window, dilution, limb weights) in place in
+//                             LDS.  Phases 2-3 (EB): the B x 25 secondary-eclipse cells are
+//                             spread over the lanes, lanes < B reduce them to the secondary
+//                             depth / exclusion flag.  Phase 4: for each row the lanes take 64
+//                             consecutive time stamps; every lane plans its cell (none, 5-12
+//                             Chebyshev nodes or all S sub-exposures), the (cell, node)
+//                             evaluations of the chunk are packed by case through LDS, and the
+//                             result is either wave-reduced to chi^2 (MODE_LNL, shuffle
+//                             butterfly) or stored as the model row (MODE_GRID).
 //   chi2_grid_kernel          row reduction over a materialised (n, n_time) grid, HBM bound.
 //   lme_partial_kernel / lme_final_kernel
 //                             log-mean-exp: single pass online (max, sum exp) per thread,
