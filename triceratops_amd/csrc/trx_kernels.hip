@@ -578,10 +578,11 @@ bool fill_tiers(TierTable& T, int S)
 int pick_rows_per_wave(int n_time, long n)
 {
     if (g_rows_per_wave > 0) return g_rows_per_wave;
-    // keep the serial per-row prologue below ~2% of a batch while leaving enough batches
-    // to balance 256 CUs: B * n_time >~ 1024
-    int B = 1;
-    while (B < 16 && (long)B * n_time < 1024) B <<= 1;
+    // measured (profiles/r01_n_rows_per_wave.txt): rows are processed one after the other by the
+    // wave, so more rows per wave only amortise the prologue's idle lanes while lengthening the
+    // wave and, through the per-row LDS blocks, costing occupancy.  2 is best from 100 to 500
+    // points, 1 at 2000.
+    int B = (n_time >= 1024) ? 1 : ((n_time >= 64) ? 2 : 4);
     while (B > 1 && n / B < 8192) B >>= 1;
     return B;
 }
