@@ -289,12 +289,26 @@ def _col(v, N, device):
     return v if isinstance(v, torch.Tensor) else torch.full((N,), float(v), dtype=F64, device=device)
 
 
+def _gather_rows(cols, idx, device):
+    """[len(cols), len(idx)] block: one index_select over the stacked tensor columns and one
+    broadcast copy for the scalar ones (instead of one gather / fill kernel per column)"""
+    n = int(idx.numel())
+    block = torch.empty((len(cols), n), dtype=F64, device=device)
+    t_rows = [i for i, c in enumerate(cols) if isinstance(c, torch.Tensor)]
+    s_rows = [i for i, c in enumerate(cols) if not isinstance(c, torch.Tensor)]
+    if t_rows:
+        block[t_rows] = torch.stack([cols[i] for i in t_rows]).index_select(1, idx)
+    if s_rows:
+        vals = torch.tensor([0.0 if cols[i] is None else float(cols[i]) for i in s_rows], dtype=F64)
+        block[s_rows] = vals.to(device, non_blocking=True)[:, None]
+    return block
+
+
 def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exptime, nsamples):
     idx = torch.nonzero(mask, as_tuple=False).flatten()
     dev = time_d.device
     n = int(idx.numel())
-    block = torch.stack([c[idx] if isinstance(c, torch.Tensor)
-                         else torch.full((n,), float(c), dtype=F64, device=dev) for c in cols]).contiguous()
+    block = _gather_rows(cols, idx, dev)
     lp = None if lnprior is None else lnprior[idx].contiguous()
     flags = FLAG_COMPANION_IS_HOST if is_host else 0
     h, lnz = _lib.lnz_scenario(model, flags, time_d, flux_d, sigma, block, exptime, nsamples, lp, N,
@@ -307,14 +321,7 @@ def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exp
 def _table(best, lnz, N, device, **cols):
     """one device->host copy: the N_BEST x 14 table and lnZ"""
     k = int(best.numel())
-    rows = []
-    for key in _COLS:
-        v = cols[key]
-        if isinstance(v, torch.Tensor):
-            rows.append(v[best])
-        else:
-            rows.append(torch.full((k,), 0.0 if v is None else float(v), dtype=F64, device=device))
-    tab = torch.stack(rows).cpu().numpy()
+    tab = _gather_rows([cols[key] for key in _COLS], best, device).cpu().numpy()
     res = {}
     for i, key in enumerate(_COLS):
         col = np.zeros(N_BEST) if not isinstance(cols[key], torch.Tensor) else np.full(N_BEST, np.nan)
