@@ -54,7 +54,7 @@ def parse():
                          "sub-exposures (the plain algorithm's instruction stream; profiles/r01_*_all_sub*.json)")
     ap.add_argument("--fp32-model", action="store_true",
                     help="BASELINE config 5: fp32 Mandel-Agol arithmetic, fp64 orbit/chi^2/log-mean-exp "
-                         "(flux within 1e-6, chi^2/2 within 2e-4 relative of the fp64 path)")
+                         "(flux within 2e-6, chi^2/2 within 2e-4 relative of the fp64 path)")
     return ap.parse_args()
 
 
@@ -225,8 +225,8 @@ def main():
                          "note": "dominant kernel rows_kernel<lnl> is fp64-VALU bound (no MFMA shape, "
                                  "~0.05 B/eval of HBM traffic); HBM-bound reductions under 'kernels'. "
                                  "achieved = algorithmic flops of the plain S-sub-exposure algorithm / "
-                                 "launch time; the kernel reaches the same averages (to 1e-13) from fewer "
-                                 "Chebyshev nodes where the exposure is far from the limb contacts, so "
+                                 "launch time; the kernel reaches the same averages (to 1e-13) from a few "
+                                 "Gauss nodes where the exposure is far from the limb contacts, so "
                                  "frac_all_subexposures (shortcut off, every sub-exposure evaluated) is "
                                  "the figure for the instruction stream itself"},
             "kernels": kernels,

@@ -82,11 +82,11 @@ def _raw_stress_rows(rng, n):
 
 
 @pytest.mark.parametrize("exptime,S,unfolded", [(0.00139, 20, False), (0.0204, 20, False), (0.0204, 50, False),
-                                                (0.00139, 12, False), (0.00139, 20, True), (0.00139, 8, False)])
+                                                (0.00139, 12, False), (0.00139, 20, True), (0.00139, 7, False)])
 def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfolded):
-    """The kernel averages the model over fewer Chebyshev nodes where the exposure is far from the
+    """The kernel averages the model over a few Gauss nodes where the exposure is far from the
     limb contacts (trx_device.hpp TierTable).  Against the same kernel evaluating all S
-    sub-exposures: flux within 2e-13 everywhere, bit-identical where no tier applies (S < 9) and
+    sub-exposures: flux within 2e-13 everywhere, bit-identical where no tier applies (S < 8) and
     exactly 1 out of transit; and against the oracle within the usual 5e-13."""
     rng = np.random.default_rng(100 + S)
     rows = _raw_stress_rows(rng, 1500)
@@ -104,7 +104,7 @@ def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfol
     assert np.nanmax(d) < 2e-13, np.nanmax(d)
     assert np.array_equal(np.isnan(g[1]), np.isnan(g[0]))
     assert np.array_equal(g[1] == 1.0, g[0] == 1.0)                # out of transit stays exactly 1
-    if S < 9:
+    if S < 8:
         assert np.array_equal(g[1], g[0], equal_nan=True)
     else:
         assert (d > 0).mean() > 0.02                               # the reduced sets are in use
@@ -303,7 +303,8 @@ def test_entry_points_capture_into_a_hip_graph_and_replay():
 def test_mixed_precision_model_tolerance(n_time):
     """TRX_FLAG_FP32_MODEL (BASELINE config 5): fp64 orbit and geometric differences, fp32
     Mandel-Agol arithmetic, fp64 chi^2 / log-mean-exp.  Stated tolerance vs the fp64 path:
-    flux 1e-6 absolute, chi^2/2 2e-4 relative, identical exclusion pattern."""
+    flux 2e-6 absolute (an fp32 evaluation is good to ~1e-6 of the eclipse depth and a cell now
+    averages 3-6 of them, not 20), chi^2/2 2e-4 relative, identical exclusion pattern."""
     rng, t, flux = _lc(n_time, seed=3)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)
     for model, rows in ((0, synth.tp_rows(rng, 3000, True)), (1, synth.eb_rows(rng, 3000, False, True)),
@@ -311,7 +312,7 @@ def test_mixed_precision_model_tolerance(n_time):
         r_d = _lib.dev(rows)
         g64, s64 = _lib.flux_grid(model, 0, t_d, r_d[:, :500].contiguous(), synth.EXPTIME, 20)
         g32, s32 = _lib.flux_grid(model, _lib.FLAG_FP32_MODEL, t_d, r_d[:, :500].contiguous(), synth.EXPTIME, 20)
-        assert float((g32 - g64).abs().max()) < 1e-6
+        assert float((g32 - g64).abs().max()) < 2e-6
         h64 = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20)
         h32 = _lib.lnl_batch(model, _lib.FLAG_FP32_MODEL, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20)
         fin = torch.isfinite(h64)
@@ -378,6 +379,6 @@ def test_node_census_knob_reports_the_plan_of_every_cell():
         n = _lib.flux_grid(0, 0, _lib.dev(t), rows, synth.EXPTIME, 20, False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
-    assert set(np.unique(n)) <= {0.0, 5.0, 7.0, 10.0, 12.0, 20.0} and {0.0, 5.0, 20.0} <= set(np.unique(n))
+    assert set(np.unique(n)) <= {0.0, 3.0, 4.0, 5.0, 6.0, 20.0} and {0.0, 3.0, 20.0} <= set(np.unique(n))
     assert np.all(flux[n == 0] == 1.0) and np.all(n[flux < 1.0] > 0)
-    assert 1.5 < n.mean() < 6.0
+    assert 1.0 < n.mean() < 4.0

@@ -6,7 +6,7 @@
 //   * Kepler's equation is solved once per light-curve point (at the exposure centre); the nodes
 //     or sub-exposures of that point are reached by Newton steps on dE using Taylor kernels for
 //     sin(dE), cos(dE)-1 (|dE| ~ 1e-3 rad), so no trig range reduction runs in the node loop.
-//   * the S-point exposure average is taken from 5-12 Chebyshev nodes wherever the model is
+//   * the S-point exposure average is taken from the 3-6 point Gauss rule of that measure wherever the model is
 //     analytic over the exposure (TierTable / plan_cell), from all S sub-exposures near the limb
 //     contacts, and is exactly 1 off the disc.
 //   * the two Bulirsch `cel` integrals of a Mandel-Agol evaluation share one AGM loop and
@@ -566,13 +566,13 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 
 // Reduced node sets for the exposure average (filled on the host for the launch's S).
 // The reference averages the model over S equally spaced sub-exposures.  Where the model is an
-// analytic function of time over the exposure, that average is reproduced to ~1e-14 by
-// interpolating the model through n < S Chebyshev nodes and averaging the interpolant over the
-// same S points -- a fixed weighted sum of n model values.  The model is analytic away from the
-// limb contacts z = 1 + k and z = |1 - k|; the interpolation error falls geometrically with the
+// analytic function of time over the exposure, that average is reproduced to ~1e-14 by the
+// n-point Gauss rule of that very measure (S points of weight 1/S), n << S: a fixed weighted sum
+// of n model values, exact for polynomials of degree 2n-1.  The model is analytic away from the
+// limb contacts z = 1 + k and z = |1 - k|; the rule's error falls geometrically with the
 // distance to the nearest (real or complex) contact time in units of the half exposure
-// (profiles/r01_l_tier_error.txt), so each tier carries the zero-free radius it needs.
-constexpr int kTiers = 4, kTierMaxNodes = 12;
+// (profiles/r01_p_tier_error.txt), so each tier carries the zero-free radius it needs.
+constexpr int kTiers = 4, kTierMaxNodes = 8;
 struct TierTable {
     int n[kTiers];                         // nodes per tier, ascending; 0 = tier unused
     double radius[kTiers];                 // required contact-free radius / half exposure
@@ -615,7 +615,10 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     const double g1 = fabs(2.0 * fma(X, Xp, yc * ycp));
     const double g2 = fabs(fma(Xp, Xp, ycp * ycp) - (nr * nr) * rho * z2);
     const double G = fmin(fabs(z2 - opp2), fabs(z2 - omk * omk));   // distance of z^2 to the contacts
-    const double hx = 0.5 * fabs(exptime);
+    // the rule's error is relative to the eclipse depth (~k^2 up to total eclipses): deep
+    // eclipses get up to 1.5x the radius so that the ABSOLUTE flux error stays below ~1e-13
+    const double kd = fmin(c.k, 1.0);
+    const double hx = 0.5 * fabs(exptime) * fma(0.5 * kd, kd, 1.0);
     const double om = fabs(nr) * rho;                                // bound on the angular rate
 #pragma unroll
     for (int q = kTiers - 1; q >= 0; --q) {

@@ -9,8 +9,8 @@
 //                             LDS.  Phases 2-3 (EB): the B x 25 secondary-eclipse cells are
 //                             spread over the lanes, lanes < B reduce them to the secondary
 //                             depth / exclusion flag.  Phase 4: for each row the lanes take 64
-//                             consecutive time stamps; every lane plans its cell (none, 5-12
-//                             Chebyshev nodes or all S sub-exposures), the (cell, node)
+//                             consecutive time stamps; every lane plans its cell (none, 3-6
+//                             Gauss nodes or all S sub-exposures), the (cell, node)
 //                             evaluations of the chunk are packed by case through LDS, and the
 //                             result is either wave-reduced to chi^2 (MODE_LNL, shuffle
 //                             butterfly) or stored as the model row (MODE_GRID).
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 
         // ---- phase 4: the light-curve model over the time axis --------------------------
         // Lanes are 64 consecutive time stamps of one row.  Neighbouring cells need different
-        // numbers of model evaluations (5-12 nodes, all S sub-exposures near the contacts, none
+        // numbers of model evaluations (3-6 nodes, all S sub-exposures near the contacts, none
         // off the disc), so the evaluations are not run where they are found.  Stage A: each lane
         // plans its cell, advances the orbit along its nodes and files every occulted node, by
         // case (disc inside the limb / crossing it), in a list in LDS.  Stage B: the Mandel-Agol
@@ -535,38 +535,88 @@ int n_params(int model)
     }
 }
 
-// Chebyshev node sets and the weights that reproduce the S-point average of their interpolant:
-// w_j = mean over the S sample points of the j-th Lagrange basis polynomial (see TierTable).
-// Radii from the measured error decay (profiles/r01_l_tier_error.txt): <= ~2e-14 per tier.
+// Node sets for the exposure average: the n-point GAUSS rule of the discrete measure the reference
+// averages over (S equally spaced points, weight 1/S each).  It reproduces the S-point average of
+// every polynomial of degree <= 2n-1, so for a model that is analytic over the exposure its error
+// falls like rho^(-2n) with the distance to the nearest limb contact -- half the nodes of an
+// interpolatory rule of the same accuracy.  Nodes = roots of the degree-n orthogonal polynomial
+// of the measure (Stieltjes recurrence, roots by bisection between the roots of degree n-1),
+// weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
+// decay (profiles/r01_p_tier_error.txt): <= ~2e-14 per tier.
 int g_tiers = 1;
 int g_debug_nodes = 0;  // grid mode writes the number of model evaluations per cell instead of the flux
 bool fill_tiers(TierTable& T, int S)
 {
-    static const int nn[kTiers] = {5, 7, 10, 12};
-    static const double rad[kTiers] = {36.0, 11.0, 5.5, 3.25};
+    static const int nn[kTiers] = {3, 4, 5, 6};
+    static const double rad[kTiers] = {60.0, 13.0, 6.0, 3.5};
+    typedef long double ld;
+    ld xs[4096];
+    const bool usable = S <= 4096;
+    for (int s = 1; usable && s <= S; ++s) xs[s - 1] = ((ld)s - 0.5L) / S - 0.5L;
+    // recurrence p_{k+1} = (x - al[k]) p_k - be[k] p_{k-1}, norms h[k] = <p_k, p_k>
+    ld al[kTierMaxNodes + 1], be[kTierMaxNodes + 1], h[kTierMaxNodes + 1];
+    auto poly = [&](int deg, ld x) -> ld {            // monic orthogonal polynomial of degree deg
+        ld pm = 0.0L, p = 1.0L;
+        for (int k = 0; k < deg; ++k) {
+            const ld pn = (x - al[k]) * p - (k > 0 ? be[k] : 0.0L) * pm;
+            pm = p;
+            p = pn;
+        }
+        return p;
+    };
+    const int nmax = nn[kTiers - 1];
+    if (usable) {
+        for (int k = 0; k <= nmax && k < S; ++k) {
+            ld num = 0.0L, den = 0.0L;
+            for (int s = 0; s < S; ++s) {
+                const ld p = poly(k, xs[s]);
+                num += xs[s] * p * p;
+                den += p * p;
+            }
+            h[k] = den / S;
+            al[k] = num / den;
+            be[k] = (k > 0) ? h[k] / h[k - 1] : h[0];
+        }
+    }
     bool any = false;
     for (int q = 0; q < kTiers; ++q) {
         const int n = nn[q];
         T.n[q] = 0;
         T.radius[q] = rad[q];
         for (int j = 0; j < kTierMaxNodes; ++j) T.x[q * kTierMaxNodes + j] = T.w[q * kTierMaxNodes + j] = 0.0;
-        if (n + 4 > S) continue;                       // not worth it for small S
-        const double half = 0.5 * (1.0 - 1.0 / S);      // the sample points span [-half, half] x exptime
-        long double x[kTierMaxNodes], w[kTierMaxNodes], sum = 0.0L;
-        for (int j = 0; j < n; ++j) x[j] = -half * cosl((2 * j + 1) * 3.14159265358979323846264338327950288L / (2 * n));
-        for (int j = 0; j < n; ++j) {
-            long double acc = 0.0L;
-            for (int s = 1; s <= S; ++s) {
-                const long double xs = ((long double)s - 0.5L) / S - 0.5L;
-                long double l = 1.0L;
-                for (int m = 0; m < n; ++m) if (m != j) l *= (xs - x[m]) / (x[j] - x[m]);
-                acc += l;
+        if (!usable || 2 * n + 2 > S) continue;       // needs degree 2n-1 well below S
+        // roots of p_m interlace those of p_{m-1}: build them degree by degree
+        ld roots[kTierMaxNodes + 2], prev[kTierMaxNodes + 2];
+        int np_ = 0;
+        for (int m = 1; m <= n; ++m) {
+            ld edges[kTierMaxNodes + 3];
+            edges[0] = -0.5L;
+            for (int i = 0; i < np_; ++i) edges[i + 1] = prev[i];
+            edges[np_ + 1] = 0.5L;
+            for (int i = 0; i < m; ++i) {
+                ld lo = edges[i], hi = edges[i + 1];
+                const bool up = poly(m, hi) > 0.0L;
+                for (int it = 0; it < 200; ++it) {
+                    const ld mid = 0.5L * (lo + hi);
+                    if ((poly(m, mid) > 0.0L) == up) hi = mid; else lo = mid;
+                }
+                roots[i] = 0.5L * (lo + hi);
             }
-            w[j] = acc / S;
+            np_ = m;
+            for (int i = 0; i < m; ++i) prev[i] = roots[i];
+        }
+        ld w[kTierMaxNodes], sum = 0.0L;
+        for (int j = 0; j < n; ++j) {
+            ld acc = 0.0L;
+            for (int k = 0; k < n; ++k) {
+                const ld p = poly(k, roots[j]);
+                acc += p * p / h[k];
+            }
+            w[j] = 1.0L / acc;
             sum += w[j];
         }
         for (int j = 0; j < n; ++j) {
-            T.x[q * kTierMaxNodes + j] = (double)x[j];
+            T.x[q * kTierMaxNodes + j] = (double)roots[j];
             T.w[q * kTierMaxNodes + j] = (double)(w[j] / sum);
         }
         T.n[q] = n;
