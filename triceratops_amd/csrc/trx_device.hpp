@@ -6,7 +6,7 @@
 //   * Kepler's equation is solved once per light-curve point (at the exposure centre); the nodes
 //     or sub-exposures of that point are reached by Newton steps on dE using Taylor kernels for
 //     sin(dE), cos(dE)-1 (|dE| ~ 1e-3 rad), so no trig range reduction runs in the node loop.
-//   * the S-point exposure average is taken from the 3-6 point Gauss rule of that measure wherever the model is
+//   * the S-point exposure average is taken from the 3-9 point Gauss rule of that measure wherever the model is
 //     analytic over the exposure (TierTable / plan_cell), from all S sub-exposures near the limb
 //     contacts, and is exactly 1 off the disc.
 //   * the two Bulirsch `cel` integrals of a Mandel-Agol evaluation share one AGM loop and
@@ -571,8 +571,8 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 // of n model values, exact for polynomials of degree 2n-1.  The model is analytic away from the
 // limb contacts z = 1 + k and z = |1 - k|; the rule's error falls geometrically with the
 // distance to the nearest (real or complex) contact time in units of the half exposure
-// (profiles/r01_p_tier_error.txt), so each tier carries the zero-free radius it needs.
-constexpr int kTiers = 4, kTierMaxNodes = 8;
+// (profiles/r01_q_tier_error.txt), so each tier carries the zero-free radius it needs.
+constexpr int kTiers = 7, kTierMaxNodes = 10;
 struct TierTable {
     int n[kTiers];                         // nodes per tier, ascending; 0 = tier unused
     double radius[kTiers];                 // required contact-free radius / half exposure

@@ -9,7 +9,7 @@
 //                             LDS.  Phases 2-3 (EB): the B x 25 secondary-eclipse cells are
 //                             spread over the lanes, lanes < B reduce them to the secondary
 //                             depth / exclusion flag.  Phase 4: for each row the lanes take 64
-//                             consecutive time stamps; every lane plans its cell (none, 3-6
+//                             consecutive time stamps; every lane plans its cell (none, 3-9
 //                             Gauss nodes or all S sub-exposures), the (cell, node)
 //                             evaluations of the chunk are packed by case through LDS, and the
 //                             result is either wave-reduced to chi^2 (MODE_LNL, shuffle
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 
         // ---- phase 4: the light-curve model over the time axis --------------------------
         // Lanes are 64 consecutive time stamps of one row.  Neighbouring cells need different
-        // numbers of model evaluations (3-6 nodes, all S sub-exposures near the contacts, none
+        // numbers of model evaluations (3-9 nodes, all S sub-exposures near the contacts, none
         // off the disc), so the evaluations are not run where they are found.  Stage A: each lane
         // plans its cell, advances the orbit along its nodes and files every occulted node, by
         // case (disc inside the limb / crossing it), in a list in LDS.  Stage B: the Mandel-Agol
@@ -542,13 +542,13 @@ int n_params(int model)
 // interpolatory rule of the same accuracy.  Nodes = roots of the degree-n orthogonal polynomial
 // of the measure (Stieltjes recurrence, roots by bisection between the roots of degree n-1),
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
-// decay (profiles/r01_p_tier_error.txt): <= ~2e-14 per tier.
+// decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 int g_tiers = 1;
 int g_debug_nodes = 0;  // grid mode writes the number of model evaluations per cell instead of the flux
 bool fill_tiers(TierTable& T, int S)
 {
-    static const int nn[kTiers] = {3, 4, 5, 6};
-    static const double rad[kTiers] = {60.0, 13.0, 6.0, 3.5};
+    static const int nn[kTiers] = {3, 4, 5, 6, 7, 8, 9};
+    static const double rad[kTiers] = {60.0, 13.0, 6.0, 3.5, 2.7, 2.1, 1.8};
     typedef long double ld;
     ld xs[4096];
     const bool usable = S <= 4096;
