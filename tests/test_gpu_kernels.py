@@ -382,3 +382,17 @@ def test_node_census_knob_reports_the_plan_of_every_cell():
     assert set(np.unique(n)) <= {0.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 20.0} and {0.0, 3.0, 20.0} <= set(np.unique(n))
     assert np.all(flux[n == 0] == 1.0) and np.all(n[flux < 1.0] > 0)
     assert 1.0 < n.mean() < 4.0
+
+
+@pytest.mark.parametrize("S,exptime", [(1, 0.0), (1, 0.02), (2, 0.02), (3, 0.00139), (8, 0.02), (64, 0.02), (65, 0.02)])
+def test_supersampling_edge_counts_match_oracle(S, exptime):
+    """nsamples = 1 (no supersampling, also with a zero exposure), tiny S where no reduced node set
+    applies, S = 8 (the smallest with one), and S around the 64-lane mark"""
+    rng = np.random.default_rng(40 + S)
+    rows = _raw_stress_rows(rng, 400)
+    rows = np.ascontiguousarray(rows[:, rows[0] <= 1.0][:, :200])
+    t = np.linspace(-0.4, 0.4, 333)
+    got = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), exptime, S,
+                         want_secdepth=False)[0].cpu().numpy()
+    want = O.evaluate_pv(t, rows[:7].T, rows[7:].T, exptime, S)
+    assert np.abs(got - want).max() < ATOL_FLUX
