@@ -69,23 +69,23 @@ NumpyStreamRng = dp.NumpyStreamRng
 
 
 G = gold("lnz_cases.npz")
-PAR_CASES = [str(c) for c in G["cases"] if not str(c).endswith("_serial")]
+PAR_CASES = [str(c) for c in G["cases"]]      # vector-path and per-draw-loop ("_serial") cases
 
 
-def _call(name, P, cc, filt):
+def _call(name, P, cc, filt, parallel=True):
     s = dict(zip(("M_s", "R_s", "Teff", "Z", "plx", "Tmag", "Jmag", "Hmag", "Kmag"), (float(v) for v in G["star"])))
     base = (G["time"], G["flux"], float(G["sigma"][0]), P, s["M_s"], s["R_s"], s["Teff"])
     tri = os.path.join(GOLD, "trilegal_synth.csv")
     fn = getattr(dp, "lnZ_" + name)
-    N = int(G["N"][0])
+    N = int(G["N"][0]) if parallel else 300
     if name in ("TTP", "TEB"):
-        return fn(*base, 0.0, N, True)
+        return fn(*base, 0.0, N, parallel)
     if name in ("PTP", "PEB", "STP", "SEB"):
-        return fn(*base, 0.0, s["plx"], cc, filt, N, True)
+        return fn(*base, 0.0, s["plx"], cc, filt, N, parallel)
     mags = (s["Tmag"], s["Jmag"], s["Hmag"], s["Kmag"])
     if name in ("DTP", "DEB"):
-        return fn(*base, 0.0, *mags, tri, cc, filt, N, True)
-    return fn(*base, *mags, tri, cc, filt, N, True)
+        return fn(*base, 0.0, *mags, tri, cc, filt, N, parallel)
+    return fn(*base, *mags, tri, cc, filt, N, parallel)
 
 
 @pytest.mark.parametrize("case", PAR_CASES)
@@ -98,12 +98,12 @@ def test_device_pipeline_reproduces_reference_when_fed_the_numpy_stream(case, mo
     P = [2.5, 4.0] if variant == "range" else 3.3
     cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
     np.random.seed(int(G[case + "_seed"][0]))
-    res = _call(name, P, cc, "J" if cc else "TESS")
+    res = _call(name, P, cc, "J" if cc else "TESS", parallel=variant != "serial")
     dicts = res if isinstance(res, tuple) else (res,)
     assert len(dicts) == int(G[case + "_nres"][0])
     for i, d in enumerate(dicts):
         want = G["%s_lnZ%d" % (case, i)][0]
-        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-8, (case, i)
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-8 + 1e-12 * abs(want), (case, i)
         logw = G["%s_logw%d" % (case, i)]
         # Equal chi^2 values (flat models) have no defined order: with fewer than 100 finite draws
         # compare the finite rows as a set, otherwise the head of the table.

@@ -195,7 +195,7 @@ def test_unused_lnz_functions_end_to_end(case):
     check_extra(call_extra(ml, case, g), case, g, 1e-9)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c.endswith("_serial")])
+@pytest.mark.parametrize("case", CASES)
 def test_numpy_device_sampling_reproduces_the_reference_draws(case):
     """set_sampling('numpy-device'): numpy's stream feeds the GPU-resident pipeline, so the same
     seed gives the reference's draws; derived columns are computed in torch instead of numpy, hence
@@ -208,7 +208,8 @@ def test_numpy_device_sampling_reproduces_the_reference_draws(case):
     triceratops_amd.set_sampling("numpy-device")
     try:
         np.random.seed(int(G[case + "_seed"][0]))
-        res = _call(ml, name, P, int(G["N"][0]), True, cc, "J" if cc else "TESS")
+        parallel = variant != "serial"
+        res = _call(ml, name, P, int(G["N"][0]) if parallel else 300, parallel, cc, "J" if cc else "TESS")
     finally:
         triceratops_amd.set_sampling("numpy")
     for i, d in enumerate(res if isinstance(res, tuple) else (res,)):

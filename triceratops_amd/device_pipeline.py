@@ -18,7 +18,7 @@ import torch
 from scipy.interpolate import PPoly
 
 from . import _lib, funcs
-from ._lib import FLAG_COMPANION_IS_HOST, MODEL_EB, MODEL_EB_TWIN, MODEL_TP
+from ._lib import FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, MODEL_EB, MODEL_EB_TWIN, MODEL_TP
 from .constants import G, Msun, Rearth, Rsun, au, pi
 from . import marginal_likelihoods as ml
 
@@ -279,10 +279,14 @@ def _periods(P_orb, N, device):
     return torch.full((N,), float(P_orb), dtype=F64, device=device)
 
 
-def _transits(Ptra, incs):
-    inc_min = torch.where(Ptra <= 1.0, torch.arccos(torch.clamp(Ptra, -1.0, 1.0)) * 180.0 / pi,
+def _transits(Ptra, incs, parallel=True):
+    """draws inclined enough to transit.  Vector path of the reference: inc_min = 90 where
+    Ptra > 1; its per-draw loop skips such draws (`continue`)."""
+    ok = Ptra <= 1.0
+    inc_min = torch.where(ok, torch.arccos(torch.clamp(Ptra, -1.0, 1.0)) * 180.0 / pi,
                           torch.full_like(Ptra, 90.0))
-    return incs >= inc_min
+    hit = incs >= inc_min
+    return hit if parallel else (hit & ok)
 
 
 def _col(v, N, device):
@@ -304,13 +308,15 @@ def _gather_rows(cols, idx, device):
     return block
 
 
-def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exptime, nsamples):
+def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exptime, nsamples,
+              parallel=True):
     idx = torch.nonzero(mask, as_tuple=False).flatten()
     dev = time_d.device
     n = int(idx.numel())
     block = _gather_rows(cols, idx, dev)
     lp = None if lnprior is None else lnprior[idx].contiguous()
-    flags = FLAG_COMPANION_IS_HOST if is_host else 0
+    # the reference's per-draw loop calls the scalar lnL_* (abs(k - 1) < 1e-6 rule, 1/k secondary)
+    flags = (FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if parallel else FLAG_SCALAR_K)
     h, lnz = _lib.lnz_scenario(model, flags, time_d, flux_d, sigma, block, exptime, nsamples, lp, N,
                                float(np.log(sigma)))
     k = min(N_BEST, n)
@@ -340,12 +346,12 @@ def _planet_branch(ctx, P_orb, rps, incs, eccs, argps, a, M_host, R_host, u1, u2
     size = rps * Rearth + R_host * Rsun
     Ptra = size / a * ((1 + eccs * sinw) / (1 - eccs ** 2))
     b = a * (1 - eccs ** 2) / (1 + eccs * sinw) * torch.cos(incs * pi / 180) / (R_host * Rsun)
-    mask = _transits(Ptra, incs) & ~(size > a * (1 - eccs))
+    mask = _transits(Ptra, incs, ctx["parallel"]) & ~(size > a * (1 - eccs))
     if extra is not None:
         mask = mask & extra
     cols = (rps, P_orb, incs, a, R_host, u1, u2, eccs, argps, 0.0 if fr_comp is None else fr_comp)
     best, lnz = _evidence(MODEL_TP, is_host, ctx["time"], ctx["flux"], ctx["sigma"], cols, mask,
-                          lnprior, N, ctx["exptime"], ctx["nsamples"])
+                          lnprior, N, ctx["exptime"], ctx["nsamples"], ctx["parallel"])
     return _table(best, lnz, N, dev, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=P_orb, inc=incs, b=b,
                   R_p=rps, ecc=eccs, argp=argps, M_EB=None, R_EB=None, fluxratio_EB=None,
                   fluxratio_comp=fr_comp)
@@ -366,22 +372,24 @@ def _binary_branches(ctx, P_orb, qs, incs, eccs, argps, masses, radii, fluxratio
     for model, per, sma, coll, qsel in (
             (MODEL_EB, P_orb, a, size > a * (1 - eccs), qs < 0.95),
             (MODEL_EB_TWIN, 2 * P_orb, a_twin, (2 * R_host * Rsun) > a_twin * (1 - eccs), qs >= 0.95)):
-        mask = _transits(size / sma * e_corr, incs) & ~coll & qsel
+        mask = _transits(size / sma * e_corr, incs, ctx["parallel"]) & ~coll & qsel
+        if not ctx["parallel"] and model == MODEL_EB_TWIN:
+            mask = mask & (size / a * e_corr <= 1.0)    # the loop `continue`s before the twin test
         if extra is not None:
             mask = mask & extra
         cols = (radii, fluxratios, per, incs, sma, R_host, u1, u2, eccs, argps, frc)
         best, lnz = _evidence(model, is_host, ctx["time"], ctx["flux"], ctx["sigma"], cols, mask,
-                              lnprior, N, ctx["exptime"], ctx["nsamples"])
+                              lnprior, N, ctx["exptime"], ctx["nsamples"], ctx["parallel"])
         out.append(_table(best, lnz, N, dev, M_s=M_host, R_s=R_host, u1=u1, u2=u2, P_orb=per,
                           inc=incs, b=sma * geo, R_p=None, ecc=eccs, argp=argps, M_EB=masses,
                           R_EB=radii, fluxratio_EB=fluxratios, fluxratio_comp=fr_comp))
     return out[0], out[1]
 
 
-def _ctx(time, flux, sigma, N, exptime, nsamples):
+def _ctx(time, flux, sigma, N, exptime, nsamples, parallel=True):
     dev = _dev()
     return {"time": _lib.dev(time, dev), "flux": _lib.dev(flux, dev), "sigma": float(sigma), "N": int(N),
-            "exptime": exptime, "nsamples": nsamples, "device": dev}
+            "exptime": exptime, "nsamples": nsamples, "device": dev, "parallel": bool(parallel)}
 
 
 def _rand(ctx):
@@ -417,7 +425,7 @@ def _full(ctx, v):
 # ---------------------------------------------------------------------------------------
 def lnZ_TTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     rps, incs, eccs, argps = _draw_planet(ctx, _full(ctx, M_s), float(P.mean()), flatpriors)
@@ -427,7 +435,7 @@ def lnZ_TTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N=1000000, parallel=Fal
 
 def lnZ_TEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     incs, qs, eccs, argps = _draw_binary(ctx, M_s, float(P.mean()))
@@ -444,7 +452,7 @@ def _ratio(f):
 def lnZ_PTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
             N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
             nsamples=20, molusc_file=None):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     qc = _bound_companions(ctx, M_s, molusc_file)
@@ -461,7 +469,7 @@ def lnZ_PTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_fil
 def lnZ_PEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
             N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
             nsamples=20, molusc_file=None):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     incs, qs, eccs, argps = _draw_binary(ctx, M_s, float(P.mean()))
@@ -502,7 +510,7 @@ def _companion_host(ctx, M_s, R_s, Teff, Z, mission, molusc_file, teff_cap):
 def lnZ_STP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
             N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
             nsamples=20, molusc_file=None):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     qc, mc, Rc, _, frc, u1s, u2s = _companion_host(ctx, M_s, R_s, Teff, Z, mission, molusc_file, 10000)
     lnprior = (torch.zeros_like(frc) if molusc_file is not None else
@@ -516,7 +524,7 @@ def lnZ_STP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_fil
 def lnZ_SEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
             N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
             nsamples=20, molusc_file=None):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     incs, qs, eccs, argps = _draw_binary(ctx, M_s, float(P.mean()))
     qc, mc, Rc, Tc, frc, u1s, u2s = _companion_host(ctx, M_s, R_s, Teff, Z, mission, molusc_file, 13000)
@@ -573,7 +581,7 @@ def _randint(ctx, hi):
 def lnZ_DTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
             contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     field = _Field(ctx, trilegal_fname, Tmag, Jmag, Hmag, Kmag, mission, False)
@@ -587,7 +595,7 @@ def lnZ_DTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag,
 def lnZ_DEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
             contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     u1, u2 = ml._ldc(mission).star(Z, Teff, ml._logg(M_s, R_s))
     incs, qs, eccs, argps = _draw_binary(ctx, M_s, float(P.mean()))
@@ -603,7 +611,7 @@ def lnZ_DEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag,
 def lnZ_BTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
             contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     field = _Field(ctx, trilegal_fname, Tmag, Jmag, Hmag, Kmag, mission, True)
     idxs = _randint(ctx, field.N_comp)
@@ -618,7 +626,7 @@ def lnZ_BTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, tr
 def lnZ_BEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
             contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
             flatpriors=False, exptime=0.00139, nsamples=20):
-    ctx = _ctx(time, flux, sigma, N, exptime, nsamples)
+    ctx = _ctx(time, flux, sigma, N, exptime, nsamples, parallel)
     P = _periods(P_orb, N, ctx["device"])
     incs = sample_inc(_rand(ctx))
     qs = sample_q(_rand(ctx), M_s)

@@ -694,8 +694,7 @@ def lnZ_NEB_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
 #   "numpy"         host numpy, the reference's own arithmetic: draw-for-draw and bit-for-bit
 #   "numpy-device"  numpy's global stream supplies the uniforms in the reference's order, everything
 #                   downstream runs on the GPU (triceratops_amd/device_pipeline.py): the same draws
-#                   as the reference, derived columns equal to rounding, ~3-5x faster than "numpy";
-#                   parallel=False calls keep the host path (the per-draw loop semantics)
+#                   as the reference, derived columns equal to rounding, ~6x faster than "numpy"
 #   "device"        torch's device generator: statistically equivalent, fastest
 _sampling = {"mode": "numpy"}
 
@@ -712,17 +711,10 @@ def set_sampling(mode):
 
 def _dispatch(fn):
     import functools
-    import inspect
-    sig = inspect.signature(fn)
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         mode = _sampling["mode"]
-        if mode == "numpy-device":
-            bound = sig.bind(*args, **kwargs)
-            bound.apply_defaults()
-            if not bound.arguments["parallel"]:
-                mode = "numpy"
         if mode != "numpy":
             from . import device_pipeline
             return getattr(device_pipeline, fn.__name__)(*args, **kwargs)
