@@ -319,8 +319,23 @@ def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exp
     flags = (FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if parallel else FLAG_SCALAR_K)
     h, lnz = _lib.lnz_scenario(model, flags, time_d, flux_d, sigma, block, exptime, nsamples, lp, N,
                                float(np.log(sigma)))
-    k = min(N_BEST, n)
-    best = idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx
+    # best draws = smallest chi^2/2.  With torch's own generator a device top-k is all there is
+    # to it.  When numpy's stream is replayed the table has to be the reference's: its order for
+    # more than N_BEST finite, distinct values is the top-k's, but few surviving draws, or the
+    # equal chi^2 of draws whose model is flat over the data window, come out in whatever order
+    # the reference's (-lnL).argsort() gives the ties -- so that very call is made on the host.
+    if not isinstance(RNG, NumpyStreamRng):
+        k = min(N_BEST, n)
+        return (idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx), lnz
+    best = None
+    if n > N_BEST:
+        hv, hi = torch.topk(h, N_BEST + 1, largest=False, sorted=True)
+        if bool(torch.isfinite(hv[-1]) & (hv[1:] > hv[:-1]).all()):
+            best = idx[hi[:N_BEST]]
+    if best is None:
+        lnL = np.full(N, -np.inf)
+        lnL[idx.cpu().numpy()] = -0.5 * np.log(2 * pi) - np.log(sigma) - h.cpu().numpy()
+        best = torch.as_tensor((-lnL).argsort()[:N_BEST]).to(dev)
     return best, lnz
 
 
