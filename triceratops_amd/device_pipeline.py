@@ -294,17 +294,16 @@ def _col(v, N, device):
 
 
 def _gather_rows(cols, idx, device):
-    """[len(cols), len(idx)] block: one index_select over the stacked tensor columns and one
-    broadcast copy for the scalar ones (instead of one gather / fill kernel per column)"""
+    """[len(cols), len(idx)] block: one index_select over the stacked tensor columns (instead of
+    one gather kernel per column) and a fill per scalar column"""
     n = int(idx.numel())
     block = torch.empty((len(cols), n), dtype=F64, device=device)
     t_rows = [i for i, c in enumerate(cols) if isinstance(c, torch.Tensor)]
     s_rows = [i for i, c in enumerate(cols) if not isinstance(c, torch.Tensor)]
     if t_rows:
         block[t_rows] = torch.stack([cols[i] for i in t_rows]).index_select(1, idx)
-    if s_rows:
-        vals = torch.tensor([0.0 if cols[i] is None else float(cols[i]) for i in s_rows], dtype=F64)
-        block[s_rows] = vals.to(device, non_blocking=True)[:, None]
+    for i in s_rows:      # fill kernels stay asynchronous (a host-to-device copy of the values would not)
+        block[i].fill_(0.0 if cols[i] is None else float(cols[i]))
     return block
 
 
