@@ -82,7 +82,8 @@ def _raw_stress_rows(rng, n):
 
 
 @pytest.mark.parametrize("exptime,S,unfolded", [(0.00139, 20, False), (0.0204, 20, False), (0.0204, 50, False),
-                                                (0.00139, 12, False), (0.00139, 20, True), (0.00139, 7, False)])
+                                                (0.00139, 12, False), (0.00139, 20, True), (0.00139, 7, False),
+                                                (0.00139, 13, False), (0.0204, 17, False), (0.00139, 8, False)])
 def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfolded):
     """The kernel averages the model over a few Gauss nodes where the exposure is far from the
     limb contacts (trx_device.hpp TierTable).  Against the same kernel evaluating all S
@@ -107,7 +108,7 @@ def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfol
     if S < 8:
         assert np.array_equal(g[1], g[0], equal_nan=True)
     else:
-        assert (d > 0).mean() > 0.02                               # the reduced sets are in use
+        assert (d > 0).mean() > 0.01                               # the reduced sets are in use
     k1 = rows[0] <= 1.0
     want = O.evaluate_pv(t, rows[:7, k1][:, :300].T, rows[7:, k1][:, :300].T, exptime, S)
     assert np.abs(g[1][k1][:300] - want).max() < ATOL_FLUX
