@@ -296,14 +296,11 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                         ns = si + 1;
                     }
                     __syncthreads();
-                    // stage B: inside items first (padded to whole passes), then the rest
-                    const int n_in_pad = (n_in + 63) & ~63;
-                    for (int i = lane; i < n_in_pad + n_lb; i += 64) {
-                        const bool head = i < n_in_pad;
-                        if (!head || i < n_in) {
-                            const int idx = head ? items[i] : items[cap - 1 - (i - n_in_pad)];
-                            zbuf[idx] = disc_flux<FP32>(zbuf[idx], c.k, L);
-                        }
+                    // stage B: inside items, then the rest, back to back: at most one pass holds both
+                    // cases (they share the cel loop, so the mixed pass costs less than a padded extra one)
+                    for (int i = lane; i < n_in + n_lb; i += 64) {
+                        const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
+                        zbuf[idx] = disc_flux<FP32>(zbuf[idx], c.k, L);
                     }
                     __syncthreads();
                     // stage C
