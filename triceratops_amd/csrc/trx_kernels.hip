@@ -92,6 +92,18 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// Optional phase timers (build with -DTRX_PHASE_TIMERS; profiles/phase_cycles.py): wave cycles
+// spent in the prologue (0), cell plans (1), stage A (2), stage B (3), stage C and the rest of
+// the time loop (4), summed over all waves.  Not compiled into the product library.
+#ifdef TRX_PHASE_TIMERS
+__device__ unsigned long long g_phase_cycles[8];
+#define TRX_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TRX_TOCK(slot, from) tm[slot] += __builtin_readcyclecounter() - (from)
+#else
+#define TRX_TICK(var)
+#define TRX_TOCK(slot, from)
+#endif
+
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
 __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 {
@@ -142,6 +154,9 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     // per 64 B line: with batch = block index every XCD fetches every line.  So virtual block v
     // takes batch (v % 8) * ceil(nbatch / 8) + v / 8: each XCD works through one contiguous
     // eighth of the rows and its L2 sees each parameter line once (FETCH_SIZE 34 -> 7 MB).
+#ifdef TRX_PHASE_TIMERS
+    unsigned long long tm[5] = {0, 0, 0, 0, 0};
+#endif
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
         const long batch = (v & 7) * per_xcd + (v >> 3);
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         const long base = batch * B;
         const int nb = (int)((n - base < B) ? (n - base) : B);
         double ysec = 0.0;
+        TRX_TICK(t_pro);
 
         // ---- phase 1: per-row constants ------------------------------------------------
         if (lane < nb) {
@@ -246,6 +262,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         // case (disc inside the limb / crossing it), in a list in LDS.  Stage B: the Mandel-Agol
         // flux over the lists, 64 items of ONE case per pass.  Stage C: each lane sums its cell's
         // nodes in their original order.
+        TRX_TOCK(0, t_pro);
         for (int r = 0; r < nb; ++r) {
             // the row constants are wave-uniform: held in scalar registers they cost no VGPRs
             // (36 otherwise, which at 128 VGPRs per lane spill into the time loop)
@@ -264,12 +281,16 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 const bool valid = j < a.n_time;
                 const double t = valid ? a.time[j] : 0.0;
                 CellPlan pl;
+                TRX_TICK(t_plan);
                 if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                TRX_TOCK(1, t_plan);
+                TRX_TICK(t_rest);
                 const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
                 const double* ws = xs + kTiers * kTierMaxNodes;
                 double fsum = 0.0;
                 for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
                     int n_in = 0, n_lb = 0, ns = 0;
+                    TRX_TICK(t_a);
                     // stage A
                     for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
                         const int s = s0 + si + 1;
@@ -296,6 +317,8 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                         ns = si + 1;
                     }
                     __syncthreads();
+                    TRX_TOCK(2, t_a);
+                    TRX_TICK(t_b);
                     // stage B: inside items, then the rest, back to back: at most one pass holds both
                     // cases (they share the cel loop, so the mixed pass costs less than a padded extra one)
                     for (int i = lane; i < n_in + n_lb; i += 64) {
@@ -303,6 +326,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                         zbuf[idx] = disc_flux<FP32>(zbuf[idx], c.k, L);
                     }
                     __syncthreads();
+                    TRX_TOCK(3, t_b);
                     // stage C
                     for (int si = 0; si < ns; ++si) {
                         const int s = s0 + si + 1;
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                         acc += (d * d) / s2;                                // :486, :537, :586
                     }
                 }
+                TRX_TOCK(4, t_rest);
             }
             if (MODE == MODE_LNL) {
                 double h = 0.5 * wave_sum(acc);
@@ -334,6 +359,12 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         }
         __syncthreads();
     }
+#ifdef TRX_PHASE_TIMERS
+    if (lane == 0) {
+        tm[4] -= tm[2] + tm[3];              // "rest" brackets the staged loop
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -867,6 +898,18 @@ int trx_set_debug_node_counts(int on)
     g_debug_nodes = on ? 1 : 0;
     return TRX_OK;
 }
+
+#ifdef TRX_PHASE_TIMERS
+/* debug builds only: read (and clear) the phase cycle counters */
+int trx_debug_phase_cycles(unsigned long long* out8)
+{
+    TRX_HIP(hipDeviceSynchronize());
+    TRX_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof(zero)));
+    return TRX_OK;
+}
+#endif
 
 const char* trx_version(void) { return "triceratops_amd libtrx 0.1.0 (gfx950)"; }
 const char* trx_last_error(void) { return g_err; }
