@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from triceratops_amd import _lib
 L = _lib.lib()
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2026)
 worst = 0.0
 for exptime, S, span, npts in ((0.00139, 20, 0.5, 3000), (0.0204, 20, 1.0, 2000), (0.0417, 30, 2.0, 2000),
                                (0.000231, 20, 0.2, 3000), (0.00139, 100, 0.4, 1500), (0.0204, 9, 0.8, 1500)):
