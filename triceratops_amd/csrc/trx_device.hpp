@@ -187,9 +187,10 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
         pp += g2;
         const double g = em;
         em += q;
-        // the gap squares every step: stopping at a relative gap of 2e-6 leaves ~5e-13 relative
-        // on the integrals, i.e. < 1e-13 on the flux (Bulirsch's sqrt(eps) costs one more step)
-        if (fabs(g - q) <= g * 2e-6) return true;
+        // the gap squares every step: stopping at a relative gap of 5e-7 leaves ~3e-14 relative
+        // on the integrals (Bulirsch's sqrt(eps) = 1e-8 costs 2.4 % more time for nothing; 2e-6
+        // was 0.8 % faster but let grazing small-planet rows drift 3e-13 from the oracle)
+        if (fabs(g - q) <= g * 5e-7) return true;
         q = 2.0 * sqrt_pos(e);
         e = q * em;
         return false;
