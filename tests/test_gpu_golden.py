@@ -1,9 +1,9 @@
 """GPU parity against the golden vectors made from the imported reference
 (tests/golden/make_golden.py) and end-to-end against the CPU oracle.
 
-Tolerances (fp64): chi^2/2 relative 1e-9; lnZ |diff| <= 1e-9 + 1e-12 |lnZ| (the relative term
-only matters for hopeless fits: a deep EB against a shallow transit has chi^2 ~ 7e5, where one ulp
-of the model flux already moves lnZ by 1e-9); FPP / NFPP absolute 1e-9; probabilities absolute 1e-9.
+Tolerances (fp64): chi^2/2 relative 1e-9; lnZ absolute 1e-9 (measured worst 1.8e-10, on a hopeless
+fit with chi^2 ~ 7e5 where one ulp of the model flux moves lnZ by 1e-10); FPP / NFPP absolute 1e-9;
+probabilities absolute 1e-9.
 """
 import os
 
@@ -71,7 +71,7 @@ def test_lnz_functions_end_to_end(case):
     dicts = res if isinstance(res, tuple) else (res,)
     for i, d in enumerate(dicts):
         want = G["%s_lnZ%d" % (case, i)][0]
-        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-9 + 1e-12 * abs(want)
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-9
         n_fin = min(100, int(np.isfinite(G["%s_logw%d" % (case, i)]).sum()))
         for k in ("P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB", "R_EB"):
             assert np.allclose(d[k][:n_fin], G["%s_res%d_%s" % (case, i, k)][:n_fin], rtol=1e-12), (case, k)
