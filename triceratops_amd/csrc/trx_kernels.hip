@@ -127,13 +127,15 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     extern __shared__ double lds[];
     const int B = a.B;
     RowC* rows = reinterpret_cast<RowC*>(lds);
-    RowC* srows = rows + B;                                           // secondary-eclipse orbits
-    double* sec = lds + 2 * (size_t)B * kRowDoubles;                  // [B][25]
-    double* tier_xw = sec + (size_t)B * kSecPoints;                   // [x | w] of the tier table
+    double* tier_xw = lds + (size_t)B * kRowDoubles;                  // [x | w] of the tier table
     const int SB = a.SB;                                              // nodes per lane per pass
     const int cap = 64 * SB;
     double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
     unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
+    // the secondary-eclipse orbit blocks and scan values live only through phases 1-3: they
+    // overlay the slab, which only the time loop uses (so rows per wave cost 144 B of LDS each)
+    RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // [B] secondary-eclipse orbits
+    double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
     if (a.use_tiers && threadIdx.x == 0) {
         // constant indices only: a dynamically indexed by-value kernel argument is copied to scratch
 #pragma unroll
@@ -657,10 +659,9 @@ int pick_rows_per_wave(int n_time, long n)
 {
     if (g_rows_per_wave > 0) return g_rows_per_wave;
     // measured (profiles/r01_n_rows_per_wave.txt): rows are processed one after the other by the
-    // wave, so more rows per wave only amortise the prologue's idle lanes while lengthening the
-    // wave and, through the per-row LDS blocks, costing occupancy.  2 is best from 100 to 500
-    // points, 1 at 2000.
-    int B = (n_time >= 1024) ? 1 : ((n_time >= 64) ? 2 : 4);
+    // wave, so more rows per wave only amortise the prologue's idle lanes while making fewer,
+    // longer waves.  4 is best up to ~250 points, 2 up to ~1000, 1 at 2000.
+    int B = (n_time >= 1024) ? 1 : ((n_time >= 256) ? 2 : 4);
     while (B > 1 && n / B < 8192) B >>= 1;
     return B;
 }
@@ -679,8 +680,10 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers;
     a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
-    const size_t lds = ((size_t)a.B * (2 * kRowDoubles + kSecPoints) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
-                     + (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short));
+    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short));
+    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
+    if (slab < overlay) slab = overlay;
+    const size_t lds = ((size_t)a.B * kRowDoubles + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step)    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
