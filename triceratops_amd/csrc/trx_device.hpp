@@ -189,7 +189,7 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
         em += q;
         // the gap squares every step: stopping at a relative gap of 5e-7 leaves ~3e-14 relative
         // on the integrals (Bulirsch's sqrt(eps) = 1e-8 costs 2.4 % more time for nothing; 2e-6
-        // was 0.8 % faster but let grazing small-planet rows drift 3e-13 from the oracle)
+        // was 0.8 % faster but let grazing small-planet rows drift by 3e-13)
         if (fabs(g - q) <= g * 5e-7) return true;
         q = 2.0 * sqrt_pos(e);
         e = q * em;
