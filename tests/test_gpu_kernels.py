@@ -328,9 +328,10 @@ def test_mixed_precision_model_tolerance(n_time):
 
 
 def test_large_batches_spot_checked():
-    """3e6 rows x 48 points (grid-stride over > 2^20 workgroups is not reached, B = 16 rows per
-    wave is) and 200 rows x 20000 points: random rows against the oracle, and bitwise equality
-    between the batched launch and the same rows launched alone (no cross-row state)."""
+    """3e6 rows x 48 points (4 rows per wave; and 1 row per wave, which walks the grid-stride loop
+    over > 2^20 batches with the XCD-aware batch mapping) and 200 rows x 20000 points: random rows
+    against the oracle, and bitwise equality between the batched launch and the same rows launched
+    alone (no cross-row state)."""
     rng, t, flux = _lc(48, seed=9)
     rows = synth.tp_rows(rng, 3_000_000, True)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)
@@ -340,6 +341,13 @@ def test_large_batches_spot_checked():
     alone = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
     assert np.array_equal(alone, h[pick])
     assert np.isfinite(h).all()
+    L = _lib.lib()
+    L.trx_set_rows_per_wave(1)
+    try:
+        h1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
+    finally:
+        L.trx_set_rows_per_wave(0)
+    assert np.array_equal(h1, h)
     rng, t, flux = _lc(20000, seed=10)
     rows = synth.eb_rows(rng, 200, True, True)
     h = _lib.lnl_batch(2, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
