@@ -503,6 +503,7 @@ struct RowC {
 constexpr int kRowDoubles = sizeof(RowC) / sizeof(double);
 
 // Orbit constants from pytransit-shaped (k, t0, p, a, i, e, w).  Runs once per row.
+template <bool WINDOW = true>
 __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double per, double a,
                                            double inc, double e, double w, double exptime)
 {
@@ -526,6 +527,13 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
     c.by = a * rt * cw;
     double si;
     sincos_red(inc, si, c.cosi);
+    if (!WINDOW) {
+        // no window (the 25-point secondary-eclipse scan sits inside its eclipse window anyway):
+        // every cell is evaluated
+        c.wlo = -INFINITY;
+        c.whi = INFINITY;
+        return;
+    }
     // Window: X(E) = ax (cosE - e) + bx sinE = A cos(E - phi) - ax e; transit needs |X| < 1+k.
     const double R = (1.0 + k) * (1.0 + 1e-9) + 1e-12;
     const double A = sqrt(c.ax * c.ax + c.bx * c.bx);

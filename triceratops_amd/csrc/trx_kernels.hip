@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 } else {
                     RowC& sc = srows[lane];
                     const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
-                    orbit_init(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
                     const Limb L = limb_weights(u1, u2);
                     sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
                     sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
