@@ -138,6 +138,18 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
 /* Tuning knob for benchmarks/tests: rows staged per wavefront (1,2,4,8,16; 0 = automatic). */
 int trx_set_rows_per_wave(int rows);
 
+/* Diagnostics (process-wide switches, default 1 / 1 / 0; no reference counterpart):
+ *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of
+ *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
+ *    model is analytic (the two agree to ~1e-13 in flux);
+ *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
+ *    previous one;
+ *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
+ *    for each cell instead of the flux. */
+int trx_set_supersample_tiers(int on);
+int trx_set_kepler_stepping(int on);
+int trx_set_debug_node_counts(int on);
+
 const char* trx_version(void);
 const char* trx_last_error(void);
 int trx_device_count(void);

@@ -880,21 +880,21 @@ int trx_set_rows_per_wave(int rows)
     return TRX_OK;
 }
 
-/* test/bench knob (not in the public header): 0 = full Kepler solve per sub-exposure */
+/* diagnostics (include/trx.h): 0 = full Kepler solve per sub-exposure */
 int trx_set_kepler_stepping(int on)
 {
     g_step = on ? 1 : 0;
     return TRX_OK;
 }
 
-/* test/bench knob (not in the public header): 0 = evaluate all S sub-exposures of every cell */
+/* diagnostics (include/trx.h): 0 = evaluate all S sub-exposures of every cell */
 int trx_set_supersample_tiers(int on)
 {
     g_tiers = on ? 1 : 0;
     return TRX_OK;
 }
 
-/* test/bench knob (not in the public header): trx_flux_grid writes the number of model
+/* diagnostics (include/trx.h): trx_flux_grid writes the number of model
    evaluations planned for each cell (0, a reduced node count, or nsupersample) instead of the flux */
 int trx_set_debug_node_counts(int on)
 {
