@@ -13,9 +13,13 @@
  *   - pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()) unless the
  *     function name ends in _host;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
- *     stream) and the call returns without synchronising; no allocation, no
- *     host-device sync, no global mutable state: safe to capture into a hipGraph and
- *     to call concurrently on different streams / devices;
+ *     stream) and the call returns without synchronising; no allocation and no
+ *     host-device sync inside the enqueue functions: safe to capture into a hipGraph and
+ *     to call concurrently on different streams / devices.  The library's only state is
+ *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
+ *     read-only afterwards) and (ii) the process-wide tuning / diagnostics switches declared
+ *     at the end of this header (atomics read once per enqueue; meant for benchmarks and
+ *     tests -- do not flip them while other threads are launching);
  *   - return value: 0 = ok, TRX_ERR_* otherwise (never throws); trx_last_error()
  *     gives a thread-local message for the last non-zero return on this thread;
  *   - numerical exclusions travel in-band exactly as in the reference:
@@ -135,7 +139,8 @@ int trx_flux_grid_host(int model, int flags,
                        double* out_flux, double* out_secdepth);
 int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out);
 
-/* Tuning knob for benchmarks/tests: rows staged per wavefront (1,2,4,8,16; 0 = automatic). */
+/* Tuning knob for benchmarks/tests (process-wide, like the diagnostics below): rows staged per
+ * wavefront (1,2,4,8,16; 0 = automatic). */
 int trx_set_rows_per_wave(int rows);
 
 /* Diagnostics (process-wide switches, default 1 / 1 / 0; no reference counterpart):

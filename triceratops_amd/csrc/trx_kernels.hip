@@ -23,6 +23,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/trx.h"
 #include "trx_device.hpp"
 
@@ -607,8 +610,10 @@ __global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict_
 
 // ---------------------------------------------------------------------------------------
 constexpr int kLmeMaxBlocks = 2048;
-int g_rows_per_wave = 0;  // 0 = auto
-int g_step = 1;           // sub-exposure Kepler stepping (0 = full solve per sub-exposure)
+// Process-wide diagnostics switches (include/trx.h, "Diagnostics"): read once per enqueue, relaxed
+// atomics so that a concurrent setter is a data-race-free (if unordered) change of mode.
+std::atomic<int> g_rows_per_wave{0};  // 0 = auto
+std::atomic<int> g_step{1};           // sub-exposure Kepler stepping (0 = full solve per sub-exposure)
 
 int n_params(int model)
 {
@@ -629,14 +634,14 @@ int n_params(int model)
 // of the measure (Stieltjes recurrence, roots by bisection between the roots of degree n-1),
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
-int g_tiers = 1;
-int g_debug_nodes = 0;  // grid mode writes the number of model evaluations per cell instead of the flux
-bool fill_tiers(TierTable& T, int S)
+std::atomic<int> g_tiers{1};
+std::atomic<int> g_debug_nodes{0};  // grid mode writes the number of model evaluations per cell instead of the flux
+bool compute_tiers(TierTable& T, int S)
 {
     static const int nn[kTiers] = {3, 4, 5, 6, 7, 8, 9};
     static const double rad[kTiers] = {60.0, 13.0, 6.0, 3.5, 2.7, 2.1, 1.8};
     typedef long double ld;
-    ld xs[4096];
+    static ld xs[4096];               // callers hold fill_tiers' mutex
     const bool usable = S <= 4096;
     for (int s = 1; usable && s <= S; ++s) xs[s - 1] = ((ld)s - 0.5L) / S - 0.5L;
     // recurrence p_{k+1} = (x - al[k]) p_k - be[k] p_{k-1}, norms h[k] = <p_k, p_k>
@@ -711,9 +716,33 @@ bool fill_tiers(TierTable& T, int S)
     return any;
 }
 
+// The table depends on S only and costs ~0.8 ms of long-double work at S = 20 (as much as a small
+// kernel): computed once per S and kept (S = 20, the reference's default, and the few other
+// values a process ever uses).  The cache is the library's only state besides the diagnostics
+// switches; a mutex makes concurrent first calls safe.
+bool fill_tiers(TierTable& T, int S)
+{
+    constexpr int kSlots = 16;
+    static std::mutex mu;
+    static int keys[kSlots];
+    static bool oks[kSlots];
+    static TierTable tabs[kSlots];
+    static int used = 0, next = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (keys[i] == S) { T = tabs[i]; return oks[i]; }
+    const bool ok = compute_tiers(T, S);
+    const int slot = (used < kSlots) ? used++ : (next++ % kSlots);
+    keys[slot] = S;
+    oks[slot] = ok;
+    tabs[slot] = T;
+    return ok;
+}
+
 int pick_rows_per_wave(int n_time, long n)
 {
-    if (g_rows_per_wave > 0) return g_rows_per_wave;
+    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
+    if (forced > 0) return forced;
     // measured (profiles/r01_n_rows_per_wave.txt): rows are processed one after the other by the
     // wave, so more rows per wave only amortise the prologue's idle lanes while making fewer,
     // longer waves.  4 is best up to ~250 points, 2 up to ~1000, 1 at 2000.
@@ -734,14 +763,14 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     const long max_grid = 1L << 20;
     const long want_grid = 8 * ((a.nbatch + 7) / 8);          // a multiple of 8: v % 8 == blockIdx % 8
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
-    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers;
+    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
     size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short));
     const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
     if (slab < overlay) slab = overlay;
     const size_t lds = ((size_t)a.B * kRowDoubles + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    if (!g_step)    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
+    if (!g_step.load(std::memory_order_relaxed))    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
     else            hipLaunchKernelGGL((rows_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
     TRX_HIP(hipGetLastError());
@@ -801,7 +830,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
