@@ -104,8 +104,29 @@ def binned_toi1228(n_bins=200, half_width=0.4):
     return tb, fb, float(np.std(fb[:50]))
 
 
+def import_reference_target():
+    """triceratops/triceratops.py imports the catalogue / plotting stack at module level; stub it.
+    Objects are created without running __init__ (which queries MAST/TessCut/TRILEGAL)."""
+    for name in ("lightkurve", "astroquery", "astroquery.mast", "astroquery.vizier",
+                 "astropy.coordinates", "astropy.wcs", "astropy.wcs.utils", "astropy.units"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["astroquery.mast"].Catalogs = object
+    sys.modules["astroquery.mast"].Tesscut = object
+    sys.modules["astroquery.vizier"].Vizier = object
+    sys.modules["astropy.coordinates"].SkyCoord = object
+    sys.modules["astropy.wcs"].WCS = object
+    sys.modules["astropy.wcs.utils"].pixel_to_skycoord = object
+    import matplotlib
+    matplotlib.use("Agg")
+    import triceratops.triceratops as rtr
+    return rtr
+
+
 def main():
     install_shims()
+    if "--only-toi465" in sys.argv:
+        toi465(import_reference_target(), os.path.join(HERE, "trilegal_synth.csv"))
+        return
     import triceratops.funcs as rfuncs
     import triceratops.likelihoods as rlik
     import triceratops.marginal_likelihoods as rml
@@ -331,21 +352,8 @@ def main():
                         out=captured[0][3],
                         **{"res_" + k: np.asarray(v, dtype=float) for k, v in res.items() if k != "lnZ"})
     # ---- (5) the reference's own target.calc_depths / calc_probs -------------------------------
-    # triceratops/triceratops.py imports the catalogue / plotting stack at module level; stub it.
-    # The object is created without running __init__ (which queries MAST/TessCut/TRILEGAL).
-    for name in ("lightkurve", "astroquery", "astroquery.mast", "astroquery.vizier",
-                 "astropy.coordinates", "astropy.wcs", "astropy.wcs.utils", "astropy.units"):
-        sys.modules.setdefault(name, types.ModuleType(name))
-    sys.modules["astroquery.mast"].Catalogs = object
-    sys.modules["astroquery.mast"].Tesscut = object
-    sys.modules["astroquery.vizier"].Vizier = object
-    sys.modules["astropy.coordinates"].SkyCoord = object
-    sys.modules["astropy.wcs"].WCS = object
-    sys.modules["astropy.wcs.utils"].pixel_to_skycoord = object
-    import matplotlib
-    matplotlib.use("Agg")
     import pandas as pd
-    import triceratops.triceratops as rtr
+    rtr = import_reference_target()
     # the lnZ_* were star-imported into rtr at import time, before the capture wrappers existed
     write_molusc(os.path.join(HERE, "molusc_synth.csv"), np.random.default_rng(5))
 
@@ -466,7 +474,111 @@ def main():
     ops["gauss_grid"] = rfuncs.Gauss2D(gx, gy, 5.3, 4.7, 0.75, 2.5)
     ops["gauss_scalar"] = np.array([rfuncs.Gauss2D(4.9, 5.2, 5.3, 4.7, 0.75, 2.5)])
     np.savez_compressed(os.path.join(HERE, "target_ops.npz"), **ops)
+    toi465(rtr, tri_path)
     print("wrote", sorted(os.listdir(HERE)))
+
+
+# ---- (8) BASELINE config 3: TOI-465.01 (examples/example.ipynb cells 3-18) --------------------
+def toi465_stars():
+    """the 26 stars of examples/example.ipynb cell 7 (notebook output, after calc_depths(0.005))"""
+    import pandas as pd
+    nan = np.nan
+    return pd.DataFrame({
+        "ID": [270380593, 270380591, 514519134, 270380594, 630359580, 630359579, 270380595, 630359572,
+               270380592, 630359577, 630359570, 270380590, 630359578, 630359576, 630359569, 630359581,
+               630359575, 630359589, 270380600, 630359574, 630359571, 630359568, 630359683, 270380588,
+               630359682, 270380599],
+        "Tmag": [10.7307, 20.0711, 19.7713, 16.0568, 19.8256, 18.7953, 16.7050, 20.3657, 16.7702,
+                 19.3124, 19.4021, 16.7147, 20.3807, 20.5930, 20.7690, 19.0413, 20.2057, 19.4333,
+                 18.2569, 20.7012, 20.5628, 19.7183, 20.6261, 16.9112, 19.0436, 19.6075],
+        "Jmag": [9.906, 16.829, nan, 14.576, nan, nan, 15.478, nan, 15.909, nan, nan, 15.491, nan, nan,
+                 nan, nan, nan, nan, 16.575, nan, nan, nan, nan, 16.083, nan, 16.950],
+        "Hmag": [9.473, 16.420, nan, 13.973, nan, nan, 15.022, nan, 15.495, nan, nan, 14.853, nan, nan,
+                 nan, nan, nan, nan, 16.091, nan, nan, nan, nan, 15.432, nan, 16.386],
+        "Kmag": [9.339, 15.772, nan, 13.765, nan, nan, 14.588, nan, 15.531, nan, nan, 14.608, nan, nan,
+                 nan, nan, nan, nan, 15.503, nan, nan, nan, nan, 15.354, nan, 15.660],
+        "ra": [32.781765, 32.780541, 32.780333, 32.770020, 32.785538, 32.768955, 32.804587, 32.757731,
+               32.809521, 32.760939, 32.780396, 32.787580, 32.760596, 32.814931, 32.807530, 32.784037,
+               32.817551, 32.813509, 32.763755, 32.737279, 32.750030, 32.821061, 32.738867, 32.819544,
+               32.741726, 32.737178],
+        "dec": [2.418021, 2.404015, 2.403886, 2.426293, 2.431950, 2.433112, 2.428540, 2.402821,
+                2.411144, 2.437847, 2.389176, 2.388617, 2.440020, 2.421735, 2.396169, 2.454356,
+                2.426406, 2.439309, 2.454164, 2.418009, 2.383120, 2.390708, 2.446400, 2.380961,
+                2.453939, 2.452297],
+        "mass": [0.811, nan, nan, 0.513011, nan, nan, 0.64, nan, 0.95, nan, nan, 0.668646, nan, nan, nan,
+                 0.45, nan, nan, nan, nan, nan, nan, nan, 0.85, nan, nan],
+        "rad": [0.847380, nan, nan, 0.515342, nan, nan, 0.795370, nan, 0.534628, nan, nan, 0.707274, nan,
+                nan, nan, 0.385007, nan, nan, nan, nan, nan, nan, nan, 0.496960, nan, nan],
+        "Teff": [4936.0, nan, nan, 3516.0, nan, nan, 4073.0, nan, 5439.0, 3750.0, nan, 4016.0, nan, nan,
+                 nan, 3479.0, nan, nan, 3874.0, nan, nan, nan, nan, 5080.0, 3583.0, nan],
+        "plx": [8.163660, nan, nan, 2.251200, -0.477026, 0.087234, 0.839486, -1.642620, 0.595253,
+                1.619320, 0.345174, 0.894513, nan, nan, 1.620700, -0.127052, 1.092730, 2.080520,
+                0.801983, nan, nan, 0.089077, nan, 0.683115, 0.907077, nan],
+        "fluxratio": [9.986416e-01, 2.904046e-05, 3.615892e-05, 1.252310e-03, 2.507577e-05,
+                      1.156098e-05, 3.595686e-06, 2.355716e-09, 6.261372e-07, 6.005195e-09,
+                      2.524618e-09, 7.237678e-09, 3.974583e-10, 3.570753e-11, 3.284628e-11,
+                      1.842151e-13, 3.791387e-13, 1.958695e-13, 7.389879e-15, 1.503412e-19,
+                      1.765258e-21, 4.631424e-20, 4.447183e-26, 3.037689e-24, 2.707183e-27,
+                      1.995252e-30],
+        "tdepth": [0.005007] + [0.0] * 25})
+
+
+def toi465_blend_stars():
+    """BASELINE config 3's shape, "20 contaminating stars": the target and its 20 nearest neighbours
+    of the table above with SYNTHETIC aperture flux ratios (target 0.8, every neighbour 0.01), so that
+    all 20 neighbours spawn NTP/NEB/NEBx2P scenarios: 75 scenarios.  (In the real field no neighbour
+    is bright enough to host a 5000 ppm signal and the notebook's run has 15 scenarios.)"""
+    st = toi465_stars().iloc[:21].copy()
+    st["fluxratio"] = [0.8] + [0.01] * 20
+    st["tdepth"] = 0.005 / st["fluxratio"].values
+    return st
+
+
+def binned_toi465(n_bins=100):
+    """examples/example.ipynb cell 9: TessLightCurve(...).bin(time_bin_size=(tmax - tmin)/100) and
+    flux_err_0 = mean of the binned flux errors (lightkurve: mean flux per bin, error of the mean
+    sqrt(sum err^2)/n per bin; bins of fixed width starting at the first time stamp)."""
+    import pandas as pd
+    lc = pd.read_csv(os.path.join(REF, "examples", "TOI465_01_lightcurve.csv"), header=None)
+    t, y, e = lc[0].values.astype(float), lc[1].values.astype(float), lc[2].values.astype(float)
+    width = (t.max() - t.min()) / n_bins
+    idx = np.minimum(((t - t.min()) / width).astype(int), n_bins - 1)
+    tb = np.array([t.min() + (i + 0.5) * width for i in range(n_bins) if np.any(idx == i)])
+    fb = np.array([y[idx == i].mean() for i in range(n_bins) if np.any(idx == i)])
+    eb = np.array([np.sqrt(np.sum(e[idx == i] ** 2)) / np.sum(idx == i) for i in range(n_bins)
+                   if np.any(idx == i)])
+    return (t, y, e), tb, fb, float(np.mean(eb))
+
+
+def toi465(rtr, tri_path):
+    """the reference's own calc_probs on TOI-465.01 with its contrast curve (example.ipynb cell 18),
+    (a) the notebook's star table (15 scenarios) and (b) the 1 + 20-star blend (75 scenarios)"""
+    import contextlib
+    import io
+    import shutil
+    raw, tb, fb, sg = binned_toi465()
+    cc_dst = os.path.join(HERE, "toi465_cc.csv")
+    shutil.copyfile(os.path.join(REF, "examples", "TOI465_01_contrastcurve.csv"), cc_dst)   # data file
+    out = {"raw_time": raw[0], "raw_flux": raw[1], "raw_flux_err": raw[2], "time": tb, "flux": fb,
+           "sigma": np.array([sg]), "P_orb": np.array([3.836169])}
+    for tag, stars, N, seed in (("real", toi465_stars(), 3000, 465), ("blend", toi465_blend_stars(), 1500, 4651)):
+        tg = object.__new__(rtr.target)
+        tg.ID, tg.mission, tg.sectors = 270380593, "TESS", np.array([4])
+        tg.search_radius, tg.N_pix, tg.trilegal_fname, tg.trilegal_url = 10, 22, tri_path, None
+        tg.stars = stars
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tg.calc_probs(tb, fb, sg, 3.836169, contrast_curve_file=cc_dst, N=N, parallel=True, verbose=0)
+        out[tag + "_lnZ"], out[tag + "_prob"] = np.array(tg.lnZ), tg.probs["prob"].values
+        out[tag + "_FPP"], out[tag + "_NFPP"] = np.array([tg.FPP]), np.array([tg.NFPP])
+        out[tag + "_scenario"] = np.array(list(tg.probs["scenario"]))
+        out[tag + "_ID"] = tg.probs["ID"].values
+        out[tag + "_N"], out[tag + "_seed"] = np.array([N]), np.array([seed])
+        for col in ("M_s", "R_s", "P_orb", "inc", "b", "ecc", "w", "R_p", "M_EB", "R_EB"):
+            out[tag + "_" + col] = tg.probs[col].values
+        for c in stars.columns:
+            out[tag + "_stars_" + c] = stars[c].values.astype(float)
+    np.savez_compressed(os.path.join(HERE, "toi465_calc_probs.npz"), **out)
 
 
 def write_molusc(path, rng, n=900):
