@@ -1,37 +1,63 @@
 #!/usr/bin/env python3
 """bench.py -- light-curve-point x sample evaluations per second of the marginal-likelihood hot path.
 
-One *step* = one pass of the hot path over BASELINE.json configs[1]: a synthetic 2000-point
-light curve, all 18 scenario families (TP/EB/EBx2P x T,P,S,D,B,N), N_samples rows each, fp64:
-for every family the fused likelihood kernel (trx_lnl_batch) then the log-mean-exp evidence
-(trx_lnz_from_halfchi2).  Inputs are resident in HBM before the timed region.  With N > 1 ranks
-(one process per GPU, RCCL) every rank runs the same per-GPU work on its own rows (weak scaling:
-scenarios x TOIs shard with no data-path collective) and the step ends with ONE all_gather of the
-per-scenario lnZ vector.
+`python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment
+the script starts its own N ranks (python -m torch.distributed.run, one process per GPU, RCCL,
+rendezvous on 127.0.0.1) BEFORE anything touches the GPU and exits with their status; under an
+external launcher it checks that WORLD_SIZE == --gpus.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     dominant kernel (the fused likelihood kernel): it is fp64-VALU bound, not HBM/MFMA
-               (SURVEY.md 8d); achieved = algorithmic fp64 flop / mean launch duration measured
-               with events on the launch stream.  Its HBM-side numbers and the two HBM-bound
-               reduction kernels are reported under "kernels".
-  cpu_baseline the CPU oracle (a port: the reference's pytransit engine is not installable) on
-               a bounded sample of the same rows, all host cores.
+--mode grid (default; BASELINE.json configs[1], the configuration the metric is quoted on)
+    One step = a synthetic 2000-point light curve x all 18 scenario families (TP/EB/EBx2P x
+    T,P,S,D,B,N) x N_samples transiting rows, fp64: for every family the fused likelihood kernel
+    (trx_lnl_batch) then the log-mean-exp evidence (trx_lnz_from_halfchi2).  Inputs are resident in
+    HBM before the timed region.  N > 1: every rank runs the same per-GPU work on its own rows
+    (weak scaling: scenarios x TOIs shard with no data-path collective) and the step ends with ONE
+    all_gather of the per-scenario lnZ vector.
+--mode batch (BASELINE.json configs[3]: 64 synthetic TOIs x 18 scenarios x N = 1e6)
+    One step = calc_probs_many over the whole batch with the scenario pipeline on the device: the
+    64 x 11 lnZ_* units (64 x 18 scenarios) are dealt to the ranks by cost (LPT), every rank draws
+    and evaluates its own units, ONE all_gather assembles all tables (strong scaling).
+
+One JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     dominant kernel = the fused likelihood kernel; it is fp64-VALU bound, not HBM/MFMA
+               (SURVEY.md 8d).  achieved = EXECUTED model evaluations (the kernel's own census,
+               measured in this run) x the plain operation count of one evaluation / mean launch
+               duration measured with events on the launch stream: always < peak.  The figure that
+               prices the launch as if all S sub-exposures had been evaluated is reported separately
+               (plain_algorithm_*; it can exceed the peak -- that is the Gauss-node shortcut, not
+               throughput), and so is the same workload timed in this run with the shortcut off
+               (all_subexposures).  traffic = HBM bytes per launch from rocprofv3 PMC passes
+               (FETCH_SIZE / WRITE_SIZE, separate passes) collected by this run in child processes.
+  kernels      the two HBM-bound reductions (chi^2 over a materialised grid, log-mean-exp).
+  cpu_baseline the CPU oracle (a port: the reference's pytransit engine is not installable) on a
+               bounded sample of the same rows: all host cores (value), single thread, and the
+               reference-shaped numpy pipeline over a materialised (n, n_time) grid.
+  e2e          end-to-end calc_probs() wall-clock (the second half of the BASELINE metric) on
+               TOI-465.01 (BASELINE configs[2]: real light curve + contrast curve, 1 + 20 stars,
+               75 scenarios, N = 1e6) in the three sampling modes.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 N_TIME = 2000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # MI355X fp64 vector peak = 1/2 of the 157.3 TF fp32 vector peak
-# algorithmic fp64 operations per sub-exposure of the PLAIN restatement (oracle/trx_oracle.c),
+# algorithmic fp64 operations of ONE model evaluation of the PLAIN restatement (oracle/trx_oracle.c),
 # counted one per add/sub/mul/div/sqrt/compare and one per libm call:
 F_ORBIT = 100.0                # offset+mean anomaly 8, Kepler (guess 8 + 3 Halley iterations x 22) 74, position 15
 F_MA = 200.0                   # case analysis 40, two cel integrals (4 iterations x 14 + 10) x 2, combination 19
@@ -42,49 +68,234 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-samples", type=int, default=100_000, help="rows per scenario family")
-    ap.add_argument("--n-time", type=int, default=N_TIME)
+    ap.add_argument("--mode", choices=["grid", "batch"], default="grid")
+    ap.add_argument("--n-samples", type=int, default=100_000, help="grid mode: rows per scenario family")
+    ap.add_argument("--n-time", type=int, default=None, help="light-curve points (grid: 2000, batch: 200)")
+    ap.add_argument("--tois", type=int, default=64, help="batch mode: number of synthetic TOIs")
+    ap.add_argument("--batch-n", type=int, default=1_000_000, help="batch mode: Monte-Carlo draws per scenario")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each of the three CPU legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel, census and e2e legs")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
+                    help="collect FETCH_SIZE / WRITE_SIZE of the dominant kernel with rocprofv3 child runs (N = 1)")
     # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
     # with every rank on cuda:0 and a gloo process group (RCCL refuses two ranks on one device)
     ap.add_argument("--debug-single-device", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-subexposures", action="store_true",
-                    help="switch the reduced-node exposure average off: every cell evaluates all nsamples "
-                         "sub-exposures (the plain algorithm's instruction stream; profiles/r01_*_all_sub*.json)")
+                    help="switch the reduced-node exposure average off for the timed steps")
     ap.add_argument("--fp32-model", action="store_true",
-                    help="BASELINE config 5: fp32 Mandel-Agol arithmetic, fp64 orbit/chi^2/log-mean-exp "
-                         "(flux within 2e-6, chi^2/2 within 2e-4 relative of the fp64 path)")
+                    help="BASELINE config 5: fp32 Mandel-Agol arithmetic, fp64 orbit/chi^2/log-mean-exp")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+def launch_ranks_if_needed(args):
+    """--gpus N without a launcher: become the launcher.  Runs before torch is imported, so this
+    process never initialises the GPU; the ranks are ordinary child processes."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d or drop one of them"
+                     % (args.gpus, env_world, args.gpus))
+        return
+    if args.gpus <= 1:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def collect_pmc(args):
+    """HBM traffic of the dominant kernel: two rocprofv3 --pmc child runs of this same script (one
+    counter per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass), each one step of the same
+    workload.  Called before this process touches the GPU.  Returns a dict or None."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+             "--no-extras", "--pmc", "off", "--n-samples", str(args.n_samples), "--n-time", str(args.n_time)]
+    if args.fp32_model:
+        child.append("--fp32-model")
+    if args.all_subexposures:
+        child.append("--all-subexposures")
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="trx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True,
+                                   text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None
+            if p.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "rows_kernel<0" in row["Kernel_Name"].replace(" ", "") and row["Counter_Name"] == counter:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None
+            got[counter] = (float(np.mean(list(per.values()))), len(per))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 on the read side; KB units
+    bytes_ = (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    return {"bytes_per_launch": bytes_, "fetch_size_kb": got["FETCH_SIZE"][0], "write_size_kb": got["WRITE_SIZE"][0],
+            "launches": got["FETCH_SIZE"][1],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command, in this run; "
+                      "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 read-side factor, MI355X_MICROARCH.md)"}
+
+
+def committed_traffic(n_time, n_rows):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    for rec in json.load(open(path)):
+        if rec["n_time"] == n_time and rec["n_samples"] == n_rows:
+            return {"bytes_per_launch": (2.0 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024.0,
+                    "fetch_size_kb": rec["fetch_size_kb"], "write_size_kb": rec["write_size_kb"],
+                    "source": "NOT measured in this run: committed profile " + rec["source"]}
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-    from triceratops_amd import _lib, synth
-
+    if args.n_time is None:
+        args.n_time = N_TIME if args.mode == "grid" else 200
+    launch_ranks_if_needed(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    extras = not args.no_extras
+    traffic = None
+    if world == 1 and args.mode == "grid" and extras and args.pmc == "auto":
+        try:
+            traffic = collect_pmc(args)          # child processes, before this one touches the GPU
+        except Exception:
+            traffic = None
+
+    import torch
+    import torch.distributed as dist
+    from triceratops_amd import _lib
+
     debug_one = args.debug_single_device
-    if world > 1 and not debug_one:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo")
+        torch.cuda.set_device(0 if debug_one else local_rank)
+        if debug_one:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     _lib.require_gpu()
+    device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
+    ctx = dict(args=args, world=world, rank=rank, device=device, debug_one=debug_one, extras=extras,
+               traffic=traffic)
+    out = run_grid(ctx) if args.mode == "grid" else run_batch(ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _sync(ctx):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize(ctx["device"])
+    if ctx["world"] > 1:
+        dist.barrier()
+    torch.cuda.synchronize(ctx["device"])
+
+
+def _max_over_ranks(ctx, elapsed):
+    import torch
+    import torch.distributed as dist
+    if ctx["world"] > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx["debug_one"] else ctx["device"])
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    return elapsed
+
+
+def census(rows_of, fams, t_d, n_sample=512):
+    """per-cell statistics of the model kernel on a sample of every family's rows: the number of
+    model evaluations the kernel plans (debug knob of trx_flux_grid) and the occulted fraction"""
+    from triceratops_amd import _lib, synth
+    L_ = _lib.lib()
+    evals, p_in = [], []
+    for i, fam in enumerate(fams):
+        blk = rows_of(i)[:, :n_sample].contiguous()
+        g, _ = _lib.flux_grid(fam[1], 0, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
+        p_in.append(float((g < 1.0).double().mean()))
+        L_.trx_set_debug_node_counts(1)
+        try:
+            c, _ = _lib.flux_grid(fam[1], 0, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
+            evals.append(float(c.mean()))
+        finally:
+            L_.trx_set_debug_node_counts(0)
+    return float(np.mean(evals)), float(np.mean(p_in))
+
+
+def hbm_kernels(ctx, f_d, n_time):
+    """the two HBM-bound reductions at sizes past the caches"""
+    import torch
+    from triceratops_amd import _lib, synth
+    device = ctx["device"]
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) * 1e-3 / reps
+
+    kernels = {}
+    n_grid = 200_000
+    grid = torch.rand((n_grid, n_time), dtype=torch.float64, device=device)
+    dt = timed(lambda: _lib.chi2_grid(f_d, grid, synth.SIGMA))
+    gb = (grid.numel() * 8 + n_grid * 8) / 1e9
+    kernels["chi2_grid_kernel"] = {"bound": "hbm", "bytes": gb * 1e9, "ms": dt * 1e3, "GBps": gb / dt,
+                                   "frac": gb / dt / HBM_PEAK_GBS}
+    del grid
+    big = torch.empty(400_000_000, dtype=torch.float64, device=device).uniform_(-3000.0, -1.0)
+    dt = timed(lambda: _lib.log_mean_exp(big, big.numel()))
+    gb = big.numel() * 8 / 1e9
+    kernels["lme_partial_kernel"] = {"bound": "hbm", "bytes": gb * 1e9, "ms": dt * 1e3, "GBps": gb / dt,
+                                     "frac": gb / dt / HBM_PEAK_GBS,
+                                     "input": "4e8 log-weights ~ U(-3000, -1) (SURVEY 8d stress vector)"}
+    del big
+    return kernels
+
+
+# ---------------------------------------------------------------------------------------------
+def run_grid(ctx):
+    import torch
+    import torch.distributed as dist
+    from triceratops_amd import _lib, synth
+    args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
     if args.all_subexposures:
         _lib.lib().trx_set_supersample_tiers(0)
-    device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
 
     def gather(dst, src):
-        if debug_one:                      # gloo moves host tensors
+        if ctx["debug_one"]:                      # gloo moves host tensors
             buf = torch.empty(dst.numel(), dtype=dst.dtype)
             dist.all_gather_into_tensor(buf, src.cpu())
             dst.copy_(buf)
@@ -109,19 +320,21 @@ def main():
     lnsigma = float(np.log(synth.SIGMA))
     n_total = 10 * n_rows  # the masked rows are ~10% of the draws of a real lnZ_* call
 
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in fams] for _ in range(args.steps)]
+    def events():
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in fams]
 
-    def step(events=None):
+    ev = [events() for _ in range(args.steps)]
+
+    def step(evs=None):
         lnz = []
         for i, (name, model, is_host, has_comp) in enumerate(fams):
             flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0)
-            if events is not None:
-                events[i][0].record()
+            if evs is not None:
+                evs[i][0].record()
             _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME,
                            synth.NSAMPLES, out=h_d[i])
-            if events is not None:
-                events[i][1].record()
+            if evs is not None:
+                evs[i][1].record()
             lnz.append(_lib.lnz_from_halfchi2(h_d[i], lnprior_d[i], n_total, lnsigma))
         mine = torch.cat(lnz)
         if world > 1:
@@ -130,177 +343,333 @@ def main():
             lnz_all.copy_(mine)
         return lnz_all
 
-    def sync():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
     for _ in range(args.warmup):
         step()
-    sync()
+    _sync(ctx)
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(ev[s])
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if debug_one else device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0])
+    _sync(ctx)
+    elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
 
     lnz_host = lnz_all.cpu().numpy()
     evals_per_step_per_gpu = float(n_time) * n_rows * len(fams)
     value = evals_per_step_per_gpu * world * args.steps / elapsed
-
-    # ---- per-kernel numbers (rank 0, N=1 only adds the extra diagnostics) -------------------
     kern_ms = np.array([[a.elapsed_time(b) for (a, b) in ev[s]] for s in range(args.steps)])
     mean_launch_s = float(kern_ms.mean()) * 1e-3
-    out = None
-    if rank == 0:
-        # fraction of sub-exposures inside the occultation region, from the model grid of a sample
-        p_in = []
-        for i, fam in enumerate(fams[:3]):
-            g, _ = _lib.flux_grid(fam[1], 0, t_d, rows_d[i][:, :512].contiguous(), synth.EXPTIME,
-                                  synth.NSAMPLES, False)
-            p_in.append(float((g < 1.0).double().mean()))
-        p_in = float(np.mean(p_in))
-        # model evaluations the kernel actually plans per cell (census knob), same sample
-        L_ = _lib.lib()
+    if rank != 0:
+        return None
+
+    cells_per_launch = float(n_time) * n_rows
+    n_par = np.mean([r.shape[0] for r in rows_h])
+    alg_bytes_per_launch = (8.0 * n_par + 8.0) * n_rows + 16.0 * n_time
+    roof = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "mean_launch_ms": mean_launch_s * 1e3, "cells_per_launch": cells_per_launch,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "hbm_GBps_algorithmic": alg_bytes_per_launch / mean_launch_s / 1e9}
+    kernels = {}
+    if ctx["extras"]:
+        evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d)
+        if args.all_subexposures:
+            evals_per_cell_timed = None        # census knob reports plans; with tiers off every in-window cell runs S
+        flop_exec = evals_per_cell * (F_ORBIT + F_MA)
+        achieved = flop_exec * cells_per_launch / mean_launch_s / 1e12
+        plain_flop = synth.NSAMPLES * (F_ORBIT + p_in * F_MA)
+        plain_tf = plain_flop * cells_per_launch / mean_launch_s / 1e12
+        roof.update({"achieved": achieved, "frac": achieved / FP64_VALU_PEAK_TF,
+                     "model_evaluations_per_cell": evals_per_cell, "flop_per_model_evaluation": F_ORBIT + F_MA,
+                     "p_in": p_in, "plain_algorithm_flop_per_cell": plain_flop,
+                     "plain_algorithm_equivalent_tflops": plain_tf,
+                     "plain_algorithm_equivalent_frac": plain_tf / FP64_VALU_PEAK_TF})
+        # the same workload with every sub-exposure evaluated, timed here (one pass over the 18 families)
+        if not args.all_subexposures and not args.fp32_model:
+            L_ = _lib.lib()
+            L_.trx_set_supersample_tiers(0)
+            try:
+                step()
+                torch.cuda.synchronize(device)
+                e2 = events()
+                step(e2)
+                torch.cuda.synchronize(device)
+            finally:
+                L_.trx_set_supersample_tiers(1)
+            ms_all = float(np.mean([a.elapsed_time(b) for (a, b) in e2]))
+            tf_all = plain_flop * cells_per_launch / (ms_all * 1e-3) / 1e12
+            roof["all_subexposures"] = {"mean_launch_ms": ms_all, "tflops": tf_all, "frac": tf_all / FP64_VALU_PEAK_TF,
+                                        "evals_per_s": cells_per_launch / (ms_all * 1e-3)}
+        tr = ctx["traffic"]
+        if tr is None:
+            tr = committed_traffic(n_time, n_rows)
+        roof["traffic"] = tr["bytes_per_launch"] if tr else None
+        roof["traffic_detail"] = tr
+        kernels = hbm_kernels(ctx, f_d, n_time)
+    else:
+        # no census in this run: price every cell at ONE model evaluation (a lower bound of the executed work)
+        achieved = (F_ORBIT + F_MA) * cells_per_launch / mean_launch_s / 1e12
+        roof.update({"achieved": achieved, "frac": achieved / FP64_VALU_PEAK_TF, "traffic": None})
+    roof["note"] = ("dominant kernel rows_kernel<lnl> is fp64-VALU bound (no MFMA shape, ~0.05 B/eval of HBM "
+                    "traffic). achieved = executed model evaluations (census of this run) x %d plain operations / "
+                    "launch time. plain_algorithm_* prices the launch as if all %d sub-exposures of every cell "
+                    "had been evaluated; the kernel reaches those averages (to 1e-13) from 3-9 Gauss nodes, so "
+                    "that figure is an algorithmic-equivalence number, not a roofline fraction"
+                    % (int(F_ORBIT + F_MA), synth.NSAMPLES))
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(t, flux, rows_h, fams, args.cpu_seconds)
+    e2e = None
+    if ctx["extras"] and not args.no_e2e and world == 1:
+        e2e = e2e_calc_probs()
+
+    return {
+        "metric": "light-curve-point x sample evals/sec", "value": value,
+        "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: synthetic %d-point light curve, 18 "
+                               "scenario families x %d transiting rows, nsamples=%d supersampling, "
+                               "fused lnL + log-mean-exp" % (n_time, n_rows, synth.NSAMPLES),
+                   "n_time": n_time, "n_samples": n_rows, "n_scenarios": len(fams),
+                   "evals_per_step_per_gpu": evals_per_step_per_gpu,
+                   "all_subexposures": bool(args.all_subexposures),
+                   "parallelism": "scenario-sharded x%d, one all_gather of lnZ" % world},
+        "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "e2e": e2e,
+        "lnZ_checksum": float(np.nansum(lnz_host[np.isfinite(lnz_host)])),
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+def run_batch(ctx):
+    """BASELINE configs[3]: `--tois` synthetic TOIs x 18 scenarios x N draws through calc_probs_many"""
+    import torch
+    import triceratops_amd
+    from triceratops_amd import _lib, synth
+    args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
+    triceratops_amd.set_sampling("device")
+    if args.fp32_model:
+        triceratops_amd.set_precision("fp32")
+    if ctx["debug_one"]:
+        import torch.distributed as dist    # noqa: F401  (gloo group: sharding moves host tensors)
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    cc = os.path.join(GOLD, "contrast_curve_synth.csv")
+    # every rank builds the same jobs (tiny host tables + one 200-point light curve per TOI)
+    jobs = synth.toi_jobs(args.tois, n_time=args.n_time, N=args.batch_n, seed=synth.SEED,
+                          trilegal_fname=tri, contrast_curve_file=cc)
+    small = synth.toi_jobs(min(args.tois, 2 * world), n_time=args.n_time, N=20000, seed=synth.SEED,
+                           trilegal_fname=tri, contrast_curve_file=cc)
+
+    def step(js, seed):
+        np.random.seed(seed)
+        torch.manual_seed(seed + 1000 * rank)
+        return triceratops_amd.calc_probs_many(js)
+
+    step(small, 1)                           # library load, tables, allocator
+    for w in range(args.warmup):
+        step(jobs, 10 + w)
+    _sync(ctx)
+    _lib.reset_stats()
+    _lib.TRACE = []
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        out = step(jobs, 100 + s)
+    _sync(ctx)
+    elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
+    trace, _lib.TRACE = _lib.TRACE, None
+    stats = dict(_lib.STATS)
+    # cells evaluated over all ranks
+    cells = torch.tensor([float(stats["cells"]), float(stats["rows"])], dtype=torch.float64,
+                         device="cpu" if ctx["debug_one"] or world == 1 else device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(cells)
+    if rank != 0:
+        return None
+    n_scen = sum(len(tg.lnZ) for tg in out)
+    nominal = float(args.batch_n) * args.n_time * n_scen * args.steps
+    kern_s = sum(a.elapsed_time(b) for (_, _, _, _, a, b, _) in trace) * 1e-3
+    cells_rank0 = float(sum(n * nt for (_, _, n, nt, _, _, _) in trace))
+    # census on the traced samples (first launches of this rank)
+    L_ = _lib.lib()
+    ev_cells, tot = 0.0, 0.0
+    for (model, flags, n, nt, _, _, blk) in trace:
+        if blk is None or blk.shape[1] == 0:
+            continue
         L_.trx_set_debug_node_counts(1)
         try:
-            evals_per_cell = float(np.mean([
-                float(_lib.flux_grid(fam[1], 0, t_d, rows_d[i][:, :512].contiguous(), synth.EXPTIME,
-                                     synth.NSAMPLES, False)[0].mean()) for i, fam in enumerate(fams[:3])]))
+            c, _ = _lib.flux_grid(model, flags & 3, jobs_time(jobs, device), blk.contiguous(), 0.00139, 20, False)
         finally:
             L_.trx_set_debug_node_counts(0)
-        flop_per_eval = synth.NSAMPLES * (F_ORBIT + p_in * F_MA)
-        evals_per_launch = float(n_time) * n_rows
-        achieved_tf = flop_per_eval * evals_per_launch / mean_launch_s / 1e12
-        n_par = np.mean([r.shape[0] for r in rows_h])
-        alg_bytes_per_launch = (8.0 * n_par + 8.0) * n_rows + 16.0 * n_time
-        kernels = {"rows_kernel<lnl>": {
-            "bound": "fp64_valu", "mean_launch_ms": mean_launch_s * 1e3,
-            "all_subexposures": bool(args.all_subexposures),
-            "evals_per_launch": evals_per_launch, "p_in": p_in, "flop_per_eval": flop_per_eval,
-            "model_evaluations_per_cell": evals_per_cell,
-            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            "hbm_GBps": alg_bytes_per_launch / mean_launch_s / 1e9}}
-
-        # HBM-bound reductions at a size past the caches: chi^2 over a materialised grid, LME
-        def timed(fn, reps=5):
-            fn()
-            torch.cuda.synchronize(device)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(reps):
-                fn()
-            b.record()
-            torch.cuda.synchronize(device)
-            return a.elapsed_time(b) * 1e-3 / reps
-
-        n_grid = 200_000
-        grid = torch.rand((n_grid, n_time), dtype=torch.float64, device=device)
-        dt = timed(lambda: _lib.chi2_grid(f_d, grid, synth.SIGMA))
-        gb = (grid.numel() * 8 + n_grid * 8) / 1e9
-        kernels["chi2_grid_kernel"] = {"bound": "hbm", "bytes": gb * 1e9, "ms": dt * 1e3,
-                                       "GBps": gb / dt, "frac": gb / dt / HBM_PEAK_GBS}
-        del grid
-        big = torch.empty(400_000_000, dtype=torch.float64, device=device).uniform_(-3000.0, -1.0)
-        dt = timed(lambda: _lib.log_mean_exp(big, big.numel()))
-        gb = big.numel() * 8 / 1e9
-        kernels["lme_partial_kernel"] = {"bound": "hbm", "bytes": gb * 1e9, "ms": dt * 1e3,
-                                         "GBps": gb / dt, "frac": gb / dt / HBM_PEAK_GBS}
-        del big
-
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(t, flux, rows_h, fams, args.cpu_seconds)
-
-        out = {
-            "metric": "light-curve-point x sample evals/sec", "value": value,
-            "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic %d-point light curve, 18 "
-                                   "scenario families x %d transiting rows, nsamples=%d supersampling, "
-                                   "fused lnL + log-mean-exp" % (n_time, n_rows, synth.NSAMPLES),
-                       "n_time": n_time, "n_samples": n_rows, "n_scenarios": len(fams),
-                       "evals_per_step_per_gpu": evals_per_step_per_gpu,
-                       "parallelism": "scenario-sharded x%d, one all_gather of lnZ" % world},
-            "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TF,
-                         "frac_all_subexposures": all_sub_frac(n_time, n_rows, args),
-                         "frac_executed": (evals_per_cell * (F_ORBIT + F_MA) * evals_per_launch / mean_launch_s
-                                           / 1e12 / FP64_VALU_PEAK_TF),
-                         "unit": "TFLOP/s", "frac": achieved_tf / FP64_VALU_PEAK_TF,
-                         "traffic": pmc_traffic(n_time, n_rows),
-                         "note": "dominant kernel rows_kernel<lnl> is fp64-VALU bound (no MFMA shape, "
-                                 "~0.05 B/eval of HBM traffic); HBM-bound reductions under 'kernels'. "
-                                 "achieved = algorithmic flops of the plain S-sub-exposure algorithm / "
-                                 "launch time; the kernel reaches the same averages (to 1e-13) from a few "
-                                 "Gauss nodes where the exposure is far from the limb contacts, so "
-                                 "frac_all_subexposures (shortcut off, every sub-exposure evaluated) is "
-                                 "the figure for the instruction stream itself and frac_executed counts "
-                                 "only the model evaluations the kernel really runs (x 300 plain flops each)"},
-            "kernels": kernels,
-            "cpu_baseline": cpu,
-            "lnZ_checksum": float(np.nansum(lnz_host[np.isfinite(lnz_host)])),
-        }
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        ev_cells += float(c.sum())
+        tot += float(c.numel())
+    evals_per_cell = ev_cells / max(tot, 1.0)
+    achieved = evals_per_cell * (F_ORBIT + F_MA) * cells_rank0 / max(kern_s, 1e-12) / 1e12
+    fpps = [float(tg.FPP) for tg in out]
+    return {
+        "metric": "light-curve-point x sample evals/sec", "value": float(cells[0]) / elapsed,
+        "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
+                               "light curves, calc_probs_many with device-side sampling; value counts the "
+                               "(draw, time) cells that pass the geometry mask and reach the model"
+                               % (args.tois, args.batch_n, args.n_time),
+                   "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
+                   "evaluated_cells_per_step": float(cells[0]) / args.steps,
+                   "evaluated_rows_per_step": float(cells[1]) / args.steps,
+                   "nominal_evals_per_s": nominal / elapsed,
+                   "calc_probs_per_s": args.tois * args.steps / elapsed,
+                   "parallelism": "lnZ_* units dealt to %d ranks by cost (LPT), one all_gather of the tables" % world},
+        "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_VALU_PEAK_TF, "traffic": None,
+                     "kernel_seconds_rank0": kern_s, "kernel_share_of_step": kern_s / elapsed,
+                     "model_evaluations_per_cell": evals_per_cell,
+                     "note": "likelihood + log-mean-exp launches of rank 0 (events around trx_lnz_scenario); the "
+                             "rest of the step is the device-side draw / derive / mask / compact chain"},
+        "cpu_baseline": None,
+        "fpp_mean": float(np.mean(fpps)), "fpp_checksum": float(np.sum(fpps)),
+    }
 
 
-def all_sub_frac(n_time, n_rows, args):
-    """roofline fraction of the same workload with every sub-exposure evaluated (this run when
-    --all-subexposures is given, else the committed run of that mode, profiles/all_subexposures.json)"""
-    if args.fp32_model:
-        return None
-    path = os.path.join(ROOT, "profiles", "all_subexposures.json")
-    if args.all_subexposures or not os.path.exists(path):
-        return None
-    rec = json.load(open(path))
-    if rec.get("n_time") == n_time and rec.get("n_samples") == n_rows:
-        return rec["frac"]
-    return None
+def jobs_time(jobs, device):
+    from triceratops_amd import _lib
+    return _lib.dev(jobs[0][1]["time"], device)
 
 
-def pmc_traffic(n_time, n_rows):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 factor 2 on the read
-    side, MI355X_MICROARCH.md section HBM).  None when no profile matches this workload."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# ---------------------------------------------------------------------------------------------
+def e2e_calc_probs():
+    """end-to-end calc_probs() wall-clock on TOI-465.01 (BASELINE configs[2]): the reference's example
+    light curve (100 binned points) + contrast curve, target + 20 neighbours (75 scenarios), N = 1e6,
+    parallel=True, in the three sampling modes; plus the 15-scenario run of the notebook's own star table."""
+    import pandas as pd
+    import torch
+    import triceratops_amd
+    from triceratops_amd.triceratops import target
+    path = os.path.join(GOLD, "toi465_calc_probs.npz")
     if not os.path.exists(path):
         return None
-    for rec in json.load(open(path)):
-        if rec["n_time"] == n_time and rec["n_samples"] == n_rows:
-            return (2.0 * rec["fetch_size_kb"] + rec["write_size_kb"]) * 1024.0
-    return None
+    g = np.load(path)
+    cols = ("ID", "Tmag", "Jmag", "Hmag", "Kmag", "ra", "dec", "mass", "rad", "Teff", "plx", "fluxratio", "tdepth")
+    res = {"workload": "TOI-465.01: examples/TOI465_01_lightcurve.csv binned to 100 points + "
+                       "TOI465_01_contrastcurve.csv, P_orb = 3.836169 d, N = 1e6 draws per scenario, parallel=True; "
+                       "synthetic TRILEGAL table; reference notebook (unstated laptop): ~61 s per 15-scenario run",
+           "seconds": {}, "FPP": {}}
+    for tag, modes in (("blend", ("device", "numpy-device", "numpy")), ("real", ("device", "numpy-device"))):
+        st = pd.DataFrame({c: g["%s_stars_%s" % (tag, c)] for c in cols})
+        st["ID"] = st["ID"].astype(np.int64)
+        for mode in modes:
+            triceratops_amd.set_sampling(mode)
+            try:
+                best = None
+                for rep in range(2 if mode != "numpy" else 1):
+                    tg = target(270380593, np.array([4]), stars=st.copy(),
+                                trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"))
+                    if rep == 0 and mode != "numpy":      # warm-up at small N: tables, allocator
+                        np.random.seed(1)
+                        tg.calc_probs(g["time"], g["flux"], float(g["sigma"][0]), float(g["P_orb"][0]),
+                                      contrast_curve_file=os.path.join(GOLD, "toi465_cc.csv"), N=20000,
+                                      parallel=True, verbose=0)
+                    np.random.seed(465)
+                    torch.manual_seed(465)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tg.calc_probs(g["time"], g["flux"], float(g["sigma"][0]), float(g["P_orb"][0]),
+                                  contrast_curve_file=os.path.join(GOLD, "toi465_cc.csv"), N=1_000_000,
+                                  parallel=True, verbose=0)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                key = "%s_%dscen_%s" % (tag, len(tg.lnZ), mode)
+                res["seconds"][key] = best
+                res["FPP"][key] = float(tg.FPP)
+            finally:
+                triceratops_amd.set_sampling("numpy")
+    return res
 
 
 def cpu_baseline(t, flux, rows_h, fams, budget_s):
-    """The CPU oracle on a bounded sample of the same rows, all host cores (OpenMP)."""
+    """The CPU oracle on a bounded sample of the same rows: all host cores (OpenMP over rows), one
+    thread, and the reference-shaped numpy pipeline (materialised (n, n_time) grid + the elementwise
+    passes and row sum of likelihoods.py:352-357, 427-438, 486, 534-538) around the oracle's
+    pytransit-shaped evaluate_pv."""
     from oracle import oracle as O
     from triceratops_amd import synth
     cores = O.num_threads()
-    per = 8
-    t0 = time.perf_counter()
-    for fam, rows in zip(fams[:3], rows_h[:3]):
-        O.lnl_batch(fam[1], t, flux, synth.SIGMA, rows[:, :per * cores], companion_is_host=fam[2])
-    probe = time.perf_counter() - t0
-    rate = 3 * per * cores * t.size / probe
-    per_fam = int(max(per * cores, min(rows_h[0].shape[1], budget_s * rate / t.size / len(fams))))
-    t0 = time.perf_counter()
-    evals = 0
-    for fam, rows in zip(fams, rows_h):
-        O.lnl_batch(fam[1], t, flux, synth.SIGMA, rows[:, :per_fam], companion_is_host=fam[2])
-        evals += per_fam * t.size
-    dt = time.perf_counter() - t0
-    return {"value": evals / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "first %d rows of each of the 18 families x %d points (%.1f s, OpenMP over rows)"
-                      % (per_fam, t.size, dt)}
+
+    def leg(run, n_threads, what):
+        O.set_num_threads(n_threads)
+        per = 4
+        t0 = time.perf_counter()
+        for fam, rows in zip(fams[:3], rows_h[:3]):
+            run(fam, rows[:, :per * n_threads])
+        probe = time.perf_counter() - t0
+        rate = 3 * per * n_threads * t.size / probe
+        per_fam = int(max(per * n_threads, min(rows_h[0].shape[1], budget_s * rate / t.size / len(fams))))
+        t0 = time.perf_counter()
+        evals = 0
+        for fam, rows in zip(fams, rows_h):
+            run(fam, rows[:, :per_fam])
+            evals += per_fam * t.size
+        dt = time.perf_counter() - t0
+        return {"value": evals / dt, "unit": "evals/s", "cores": n_threads, "kind": "port",
+                "sample": "first %d rows of each of the 18 families x %d points (%.1f s, %s)"
+                          % (per_fam, t.size, dt, what)}
+
+    def fused(fam, rows):
+        O.lnl_batch(fam[1], t, flux, synth.SIGMA, rows, companion_is_host=fam[2])
+
+    def numpy_grid(fam, rows):
+        # the reference's dataflow: unit conversion in numpy, evaluate_pv -> (n, n_time) fp64 grid,
+        # dilution passes over the grid, 0.5 * sum((flux - model)**2 / sigma**2, axis=1)
+        name, model, is_host, _ = fam
+        Rsun, Rearth = 6.957e10, 6.3781e8
+        if model == 0:
+            R_p, P, inc, a, R_s, u1, u2, ecc, argp, cfr = rows
+            k = R_p * Rearth / (R_s * Rsun)
+            F_eb = None
+        else:
+            R_EB, ebfr, P, inc, a, R_s, u1, u2, ecc, argp, cfr = rows
+            k = R_EB / R_s
+            k = np.where((k - 1.0) < 1e-6, k * 0.999, k)
+            F_eb = (ebfr / (1 - ebfr)).reshape(-1, 1)
+        F_comp = (cfr / (1 - cfr)).reshape(-1, 1)
+        pvp = np.array([k, np.zeros_like(k), P, a / (R_s * Rsun), inc * np.pi / 180, ecc,
+                        (90 - argp) * np.pi / 180]).T
+        ldc = np.array([u1, u2]).T
+        grid = O.evaluate_pv(t, pvp, ldc, synth.EXPTIME, synth.NSAMPLES)
+        if F_eb is None:
+            F_d = 1 / F_comp if is_host else F_comp
+            grid = (grid + F_d) / (1 + F_d)
+        else:
+            pvs = pvp.copy()
+            ks = R_s / rows[0]
+            pvs[:, 0] = np.where((ks - 1.0) < 1e-6, ks * 0.999, ks)
+            pvs[:, 6] = (90 - argp + 180) * np.pi / 180
+            sec = np.min(O.evaluate_pv(np.linspace(-0.05, 0.05, 25), pvs, ldc, 0.0, 1), axis=1, keepdims=True)
+            if is_host:
+                x, y, F_d = F_eb / F_comp, F_comp / F_eb, 1 / (F_comp + F_eb)
+            else:
+                x, y, F_d = F_eb, 1 / F_eb, F_comp / (1 + F_eb)
+            grid = (grid + x) / (1 + x)
+            sec = (sec + y) / (1 + y)
+            grid = (grid + F_d) / (1 + F_d)
+            secdepth = 1 - (sec + F_d) / (1 + F_d)
+        h = 0.5 * np.sum((flux - grid) ** 2 / synth.SIGMA ** 2, axis=1)
+        if model == 1:
+            h[(secdepth >= 1.5 * synth.SIGMA).ravel()] = np.inf
+        return h
+
+    try:
+        allc = leg(fused, cores, "fused C restatement, OpenMP over rows on all cores")
+        one = leg(fused, 1, "fused C restatement, one thread")
+        grid = leg(numpy_grid, cores, "numpy materialised-grid pipeline of the reference around the oracle's "
+                                      "evaluate_pv, model on all cores, numpy passes on one")
+    finally:
+        O.set_num_threads(cores)
+    allc["single_thread"] = one
+    allc["numpy_grid"] = grid
+    return allc
 
 
 if __name__ == "__main__":

@@ -256,7 +256,7 @@ void trxo_evaluate_pv(const double* time, int n_time, const double* pvp, const d
                       long n, double exptime, int nsamples, double* out)
 {
     if (nsamples < 1) nsamples = 1;
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r) {
         const double* v = pvp + 7 * r;
         trxo_orbit o;
@@ -380,7 +380,7 @@ void trxo_lnl_batch(int model, int flags, const double* time, const double* flux
                     double* out_halfchi2)
 {
     if (nsamples < 1) nsamples = 1;
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r)
         out_halfchi2[r] = trxo_row_eval(model, flags, time, flux, n_time, sigma, params + r, n,
                                         exptime, nsamples, NULL, NULL);
@@ -391,7 +391,7 @@ void trxo_flux_grid(int model, int flags, const double* time, int n_time, const 
                     long n, double exptime, int nsamples, double* out_flux, double* out_secdepth)
 {
     if (nsamples < 1) nsamples = 1;
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r) {
         double sd = 0.0;
         (void)trxo_row_eval(model, flags, time, NULL, n_time, 1.0, params + r, n, exptime,

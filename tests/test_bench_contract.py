@@ -11,7 +11,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--n-samples", "2048", "--n-time", "256", "--steps", "2", "--warmup", "1"]
+SMALL = ["--n-samples", "2048", "--n-time", "256", "--steps", "2", "--warmup", "1", "--no-e2e"]
 
 
 def _last_json(out):
@@ -35,20 +35,53 @@ def _check_common(d, n_gpus):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
 
 
+def test_gpus_flag_must_agree_with_the_launcher():
+    """--gpus is checked against WORLD_SIZE before anything is imported (runs without a GPU)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="3", RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
 @pytest.mark.gpu
 def test_single_gpu_line():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-seconds", "1"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _last_json(p.stdout)
     _check_common(d, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "evals/s" and c["sample"]
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
+    assert c["numpy_grid"]["value"] > 0
     assert d["value"] > 50 * c["value"]
+    r = d["roofline"]
+    # executed work is priced below the plain 20-sub-exposure equivalent, and the run with the
+    # shortcut off (timed in the same process) is slower than the default one
+    assert r["achieved"] < r["plain_algorithm_equivalent_tflops"]
+    assert r["all_subexposures"]["mean_launch_ms"] > r["mean_launch_ms"]
+    assert 1.0 < r["model_evaluations_per_cell"] < 20.0
+    # traffic comes from PMC child runs of this very command (or is null when rocprofv3 is missing)
+    if r["traffic"] is not None:
+        assert "in this run" in r["traffic_detail"]["source"]
+        assert r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    for k in ("chi2_grid_kernel", "lme_partial_kernel"):
+        assert 0 < d["kernels"][k]["frac"] < 1
 
 
 @pytest.mark.gpu
 def test_two_ranks_control_flow_on_one_device():
+    """`python bench.py --gpus 2` with no external launcher: bench.py starts the two ranks itself"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device"]
+                       + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    _check_common(d, 2)
+    assert d["cpu_baseline"] is None           # timed on rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_two_ranks_under_an_external_launcher():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -59,6 +92,17 @@ def test_two_ranks_control_flow_on_one_device():
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device"] + SMALL,
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
+    _check_common(_last_json(p.stdout), 2)
+
+
+@pytest.mark.gpu
+def test_batch_mode_two_ranks():
+    """BASELINE configs[3] mode at a reduced size: 4 TOIs x 18 scenarios, dealt to two ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device",
+                        "--mode", "batch", "--tois", "4", "--batch-n", "50000", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
-    _check_common(d, 2)
-    assert d["cpu_baseline"] is None           # timed on rank 0 at N = 1 only
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_scenarios"] == 72
+    assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1

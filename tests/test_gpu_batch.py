@@ -1,0 +1,116 @@
+"""BASELINE configs[3] and [4] on one GPU: a single-GPU shard of the 64-TOI batch (8 TOIs x 18
+scenarios x N = 1e6 through calc_probs_many) in fp64 and in the mixed-precision mode
+(TRX_FLAG_FP32_MODEL: fp32 flux model, fp64 orbit / chi^2 / log-mean-exp), and the fp32 kernel
+against the CPU ORACLE (not against the fp64 kernel) on all 18 scenario families.
+
+Mixed-precision tolerances (printed by the tests, stated in DESIGN.md section 9):
+  flux      |fp32 - oracle| <= 2e-6 absolute
+  chi^2/2   <= 3e-4 relative (or 0.05 absolute for near-perfect fits), identical +inf pattern
+  lnZ       <= 0.5 absolute on scenarios that carry probability, FPP / NFPP <= 1e-3 absolute
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from helpers import GOLD
+from oracle import oracle as O
+from triceratops_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+FLUX_ATOL_FP32 = 2e-6
+H_RTOL_FP32 = 3e-4
+H_ATOL_FP32 = 0.05
+
+
+@pytest.mark.parametrize("n_time", [200, 2000])
+def test_fp32_model_against_the_oracle(n_time):
+    rng = np.random.default_rng(synth.SEED + 5)
+    t = synth.time_grid(n_time)
+    curve = O.flux_grid(O.MODEL_TP, t, synth.reference_tp_row())[0][0]
+    flux = synth.noisy_light_curve(rng, curve)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    n = 2000 if n_time == 200 else 200
+    worst_h, worst_f = 0.0, 0.0
+    for fam in synth.FAMILIES:
+        name, model, is_host, _ = fam
+        rows = synth.family_rows(rng, fam, n)
+        flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | _lib.FLAG_FP32_MODEL
+        got = _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, _lib.dev(rows), synth.EXPTIME,
+                             synth.NSAMPLES).cpu().numpy()
+        want = O.lnl_batch(model, t, flux, synth.SIGMA, rows, companion_is_host=is_host)
+        assert np.array_equal(np.isposinf(want), np.isposinf(got)), name
+        fin = np.isfinite(want)
+        err = np.abs(got[fin] - want[fin])
+        assert np.all(err <= H_RTOL_FP32 * np.abs(want[fin]) + H_ATOL_FP32), (name, err.max())
+        worst_h = max(worst_h, float(np.max(err / np.maximum(np.abs(want[fin]), 1.0))))
+        g32, _ = _lib.flux_grid(model, flags, t_d, _lib.dev(rows[:, :64].copy()), synth.EXPTIME,
+                                synth.NSAMPLES, False)
+        g64, _ = O.flux_grid(model, t, rows[:, :64].copy(), companion_is_host=is_host)
+        df = float(np.max(np.abs(g32.cpu().numpy() - g64)))
+        assert df <= FLUX_ATOL_FP32, (name, df)
+        worst_f = max(worst_f, df)
+    print("fp32 model vs CPU oracle, %d points x 18 families x %d rows: max |dflux| = %.2e, "
+          "max relative d(chi^2/2) = %.2e" % (n_time, n, worst_f, worst_h))
+
+
+def _jobs(n_tois, N):
+    return synth.toi_jobs(n_tois, n_time=200, N=N, seed=synth.SEED + 4,
+                          trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"),
+                          contrast_curve_file=os.path.join(GOLD, "contrast_curve_synth.csv"))
+
+
+def _batch(n_tois, N, sampling, precision, seed=11):
+    import triceratops_amd
+    triceratops_amd.set_sampling(sampling)
+    triceratops_amd.set_precision(precision)
+    try:
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        jobs = _jobs(n_tois, N)
+        _lib.reset_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = triceratops_amd.calc_probs_many(jobs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return out, dt, dict(_lib.STATS)
+    finally:
+        triceratops_amd.set_sampling("numpy")
+        triceratops_amd.set_precision("fp64")
+
+
+def test_config4_shard_fp64_vs_mixed_precision():
+    """8 TOIs x 18 scenarios x N = 1e6 (one GPU's share of the 64-TOI batch), same draws (numpy's
+    stream feeding the device pipeline) in both precisions"""
+    N = 1_000_000
+    a, dt64, st64 = _batch(8, N, "numpy-device", "fp64")
+    b, dt32, st32 = _batch(8, N, "numpy-device", "fp32")
+    assert st64 == st32 and st64["launches"] == 8 * 18      # 6 planet calls + 6 binary calls x 2 branches per TOI
+    d_lnz, d_fpp, d_nfpp = 0.0, 0.0, 0.0
+    for x, y in zip(a, b):
+        assert len(x.lnZ) == 18 and x.FPP_degenerate is False
+        fin = np.isfinite(x.lnZ)
+        assert np.array_equal(fin, np.isfinite(y.lnZ))
+        live = fin & (x.probs.prob.values > 1e-6)
+        d_lnz = max(d_lnz, float(np.abs(x.lnZ[live] - y.lnZ[live]).max()))
+        d_fpp, d_nfpp = max(d_fpp, abs(x.FPP - y.FPP)), max(d_nfpp, abs(x.NFPP - y.NFPP))
+    print("config-4 shard, 8 TOIs x 18 x N=1e6, 200 points: fp64 %.2f s, fp32 model %.2f s; %d rows "
+          "evaluated; max |dlnZ| = %.3g (scenarios with prob > 1e-6), max |dFPP| = %.3g, max |dNFPP| = %.3g"
+          % (dt64, dt32, st64["rows"], d_lnz, d_fpp, d_nfpp))
+    assert d_lnz < 0.5 and d_fpp < 1e-3 and d_nfpp < 1e-3
+
+
+def test_config4_shard_device_sampling():
+    """the same shard with the whole scenario on the GPU (what bench.py --mode batch times)"""
+    out, dt, st = _batch(8, 1_000_000, "device", "fp64")
+    out2, dt2, _ = _batch(8, 1_000_000, "device", "fp64")
+    print("config-4 shard, device sampling: %.2f s first, %.2f s repeated, %d rows, %.3g cells/s"
+          % (dt, dt2, st["rows"], st["cells"] / dt2))
+    for x, y in zip(out, out2):
+        assert x.FPP_degenerate is False and 0.0 <= x.FPP <= 1.0 and len(x.lnZ) == 18
+        assert abs(x.FPP - y.FPP) < 1e-12          # same torch seed, same result

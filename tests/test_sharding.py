@@ -276,3 +276,21 @@ def test_calc_probs_many_on_gpu_equals_sequential_calls():
         tg.calc_probs(verbose=0, **kw)
     for m, s in zip(_tables(jobs), _tables(seq)):
         assert np.array_equal(m, s, equal_nan=True)
+
+
+def test_schedule_balances_the_64_toi_batch_over_8_ranks():
+    """BASELINE config 4: 64 TOIs x (9 target calls + 2 nearby calls) = 704 lnZ_* units holding
+    64 x 18 = 1152 scenarios, dealt to 8 ranks by cost"""
+    keys = ["TP", "EB", "PTP", "PEB", "STP", "SEB", "DTP", "DEB", "BTP", "BEB", "NTP", "NEB"]
+    rng = np.random.default_rng(0)
+    costs = []
+    for _ in range(64):
+        w = float(rng.choice([100, 200, 2000])) * 1e6        # n_time x N of that TOI
+        costs += [sharding._COST[k] * w for k in keys[:10]] + [sharding._COST[k] * w for k in keys[10:]]
+    owner = sharding.schedule(costs, 8)
+    assert len(owner) == 64 * 12 and set(owner) == set(range(8))
+    load = np.bincount(owner, weights=costs, minlength=8)
+    assert load.max() / load.mean() < 1.02                   # LPT: within 2 % of perfect balance
+    assert owner == sharding.schedule(costs, 8)               # deterministic: every rank computes the same table
+    # one rank: everything on rank 0
+    assert set(sharding.schedule(costs, 1)) == {0}

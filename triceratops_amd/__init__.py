@@ -15,6 +15,13 @@ def set_sampling(mode):
     _set(mode)
 
 
+def set_precision(mode):
+    """'fp64' (default) or 'fp32' (BASELINE config 5: fp32 flux model, fp64 orbit / chi^2 /
+    log-mean-exp accumulators) for everything evaluated through lnZ_* and calc_probs."""
+    from . import _lib
+    _lib.set_precision(mode)
+
+
 def calc_probs_many(jobs, verbose: int = 0):
     """calc_probs for several targets in one sharded pass (see triceratops.calc_probs_many)."""
     from .triceratops import calc_probs_many as _many

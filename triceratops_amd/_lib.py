@@ -32,6 +32,32 @@ class TrxError(RuntimeError):
     pass
 
 
+# flags OR-ed into every likelihood launch of the lnZ_* / calc_probs layer: set_precision("fp32")
+# puts TRX_FLAG_FP32_MODEL here (BASELINE config 5); the plain wrappers below take explicit flags
+EXTRA_FLAGS = 0
+# work counters of the scenario layer (bench.py reads them): rows and (row, time) cells that
+# went through trx_lnz_scenario since the last reset
+STATS = {"rows": 0, "cells": 0, "launches": 0}
+# measurement hook (bench.py --mode batch): a list that receives, per trx_lnz_scenario launch,
+# (model, flags, n, n_time, start_event, end_event, first rows of the parameter block)
+TRACE = None
+TRACE_SAMPLE_ROWS = 128
+
+
+def reset_stats():
+    for k in STATS:
+        STATS[k] = 0
+
+
+def set_precision(mode):
+    """'fp64' (default) or 'fp32': fp32 Mandel-Agol arithmetic with fp64 orbit, chi^2 and
+    log-mean-exp (TRX_FLAG_FP32_MODEL) for every scenario evaluated through lnZ_* / calc_probs"""
+    global EXTRA_FLAGS
+    if mode not in ("fp64", "fp32"):
+        raise ValueError("precision must be 'fp64' or 'fp32'")
+    EXTRA_FLAGS = FLAG_FP32_MODEL if mode == "fp32" else 0
+
+
 _vp = ctypes.c_void_p
 _lib = None
 
@@ -204,9 +230,17 @@ def lnz_scenario(model, flags, time_d, flux_d, sigma, params_d, exptime, nsample
     require_gpu()
     n = params_d.shape[1]
     device = params_d.device
+    flags |= EXTRA_FLAGS
+    STATS["rows"] += n
+    STATS["cells"] += n * time_d.numel()
+    STATS["launches"] += 1
     h = torch.empty(max(n, 1), dtype=torch.float64, device=device)
     out = torch.empty(1, dtype=torch.float64, device=device)
     ws = workspace(device)
+    ev = None
+    if TRACE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     with torch.cuda.device(device):
         check(lib().trx_lnz_scenario(model, flags, time_d.data_ptr(), flux_d.data_ptr(),
                                      time_d.numel(), float(sigma), params_d.data_ptr(), n,
@@ -214,6 +248,10 @@ def lnz_scenario(model, flags, time_d, flux_d, sigma, params_d, exptime, nsample
                                      lnprior_d.data_ptr() if lnprior_d is not None else None,
                                      int(n_total), float(lnsigma), h.data_ptr(), out.data_ptr(),
                                      ws.data_ptr(), ws.numel() * 8, _stream(params_d)))
+    if ev is not None:
+        ev[1].record()
+        keep = params_d[:, :TRACE_SAMPLE_ROWS].clone() if len(TRACE) < 64 else None
+        TRACE.append((model, flags, n, time_d.numel(), ev[0], ev[1], keep))
     return h[:n], out
 
 

@@ -325,7 +325,13 @@ def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exp
     # the reference's (-lnL).argsort() gives the ties -- so that very call is made on the host.
     if not isinstance(RNG, NumpyStreamRng):
         k = min(N_BEST, n)
-        return (idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx), lnz
+        best = idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx
+        if k < N_BEST:
+            # fewer surviving draws than table rows: the reference fills the rest with whatever
+            # -inf draws its argsort puts next; here the first draws of the block stand in for them
+            pad = torch.arange(N_BEST - k, device=dev) % max(N, 1)
+            best = torch.cat([best, pad])
+        return best, lnz
     best = None
     if n > N_BEST:
         hv, hi = torch.topk(h, N_BEST + 1, largest=False, sorted=True)
@@ -504,8 +510,8 @@ def _companion_host(ctx, M_s, R_s, Teff, Z, mission, molusc_file, teff_cap):
     mc = qc * M_s
     Rc, Tc = stellar_relations(mc, _full(ctx, R_s), _full(ctx, Teff))
     logg = torch.log10(G * (mc * Msun) / (Rc * Rsun) ** 2)
-    # rounded (Teff/250, logg/0.5) lattice at the nearest Z; cells the grid lacks give NaN
-    # coefficients (zero-weight draws) where the reference raises
+    # rounded (Teff/250, logg/0.5) lattice at the nearest Z; a draw in a cell the grid lacks raises
+    # like the reference
     tab = ml._ldc(mission)
     atZ = tab.Zs == tab.Zs[np.abs(tab.Zs - Z).argmin()]
     nT = int((teff_cap - 3500) // 250) + 1
@@ -517,8 +523,14 @@ def _companion_host(ctx, M_s, R_s, Teff, Z, mission, molusc_file, teff_cap):
     lut = torch.as_tensor(lut, dtype=F64, device=ctx["device"])
     ig = torch.clamp(torch.round(logg / 0.5) * 0.5, 3.5, 5.0)
     it = torch.clamp(torch.round(Tc / 250) * 250, 3500.0, float(teff_cap))
-    code = (torch.round((it - 3500) / 250) * 4 + torch.round((ig - 3.5) / 0.5)).long()
-    return qc, mc, Rc, Tc, _flux_share(mc, M_s), lut[0, code], lut[1, code]
+    code = torch.nan_to_num(torch.round((it - 3500) / 250) * 4 + torch.round((ig - 3.5) / 0.5),
+                            nan=0.0).long().clamp_(0, nT * 4 - 1)
+    u1s, u2s = lut[0, code], lut[1, code]
+    if bool(torch.isnan(u1s).any()):
+        # a rounded (Teff, logg) cell the Claret grid lacks (e.g. SEB companions hotter than
+        # 10000 K): the reference's `.item()` on the empty match raises, and so does the host path
+        raise ValueError("can only convert an array of size 1 to a Python scalar")
+    return qc, mc, Rc, Tc, _flux_share(mc, M_s), u1s, u2s
 
 
 def lnZ_STP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",

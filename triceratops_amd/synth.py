@@ -88,3 +88,45 @@ def family_rows(rng, family, n):
 
 def noisy_light_curve(rng, model_curve, sigma=SIGMA):
     return model_curve + rng.normal(0.0, sigma, model_curve.shape)
+
+
+def toi_jobs(n_tois, n_time=200, N=1_000_000, seed=SEED, trilegal_fname=None,
+             contrast_curve_file=None, parallel=True):
+    """BASELINE config 4: a batch of synthetic TOIs for calc_probs_many.  Each TOI is a K/G dwarf
+    with a transiting planet, observed as an `n_time`-point folded light curve, plus ONE nearby star
+    bright enough to host the signal: 15 + 3 = 18 scenarios per TOI.  Returns [(target, kwargs)].
+    The light curves are evaluated on the GPU (likelihoods.simulate_TP_transit)."""
+    from pandas import DataFrame
+    from .likelihoods import simulate_TP_transit
+    from .triceratops import target
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for i in range(n_tois):
+        M_s = rng.uniform(0.6, 1.2)
+        R_s = M_s ** 0.8
+        Teff = 3600.0 + 2300.0 * M_s
+        P = rng.uniform(2.0, 10.0)
+        k = rng.uniform(0.04, 0.12)
+        a = ((G * M_s * Msun) / (4 * np.pi ** 2) * (P * 86400) ** 2) ** (1 / 3)
+        b = rng.uniform(0.0, 0.6)
+        inc = np.degrees(np.arccos(b * R_s * Rsun / a))
+        sigma = rng.uniform(3e-4, 8e-4)
+        t = np.linspace(-0.2, 0.2, n_time)
+        fr_nearby = rng.uniform(0.02, 0.08)
+        curve = simulate_TP_transit(t, k * R_s * Rsun / Rearth, P, inc, a, R_s, 0.45, 0.2, 0.0, 0.0,
+                                    companion_fluxratio=fr_nearby)
+        flux = curve + rng.normal(0.0, sigma, n_time)
+        depth = float(1.0 - curve.min())
+        Tmag = rng.uniform(9.5, 12.0)
+        stars = DataFrame({
+            "ID": [1000 + 2 * i, 1001 + 2 * i], "Tmag": [Tmag, Tmag + 3.0],
+            "Jmag": [Tmag - 0.8, Tmag + 2.1], "Hmag": [Tmag - 1.2, Tmag + 1.6],
+            "Kmag": [Tmag - 1.3, Tmag + 1.5], "ra": [10.0, 10.004], "dec": [-5.0, -5.003],
+            "mass": [M_s, rng.uniform(0.4, 0.9)], "rad": [R_s, rng.uniform(0.4, 0.9)],
+            "Teff": [Teff, rng.uniform(3600.0, 5400.0)], "plx": [rng.uniform(5.0, 20.0), rng.uniform(1.0, 4.0)],
+            "fluxratio": [1.0 - fr_nearby, fr_nearby],
+            "tdepth": [depth / (1.0 - fr_nearby), min(depth / fr_nearby, 0.95)]})
+        tg = target(1000 + 2 * i, np.array([1]), stars=stars, trilegal_fname=trilegal_fname)
+        jobs.append((tg, dict(time=t, flux_0=flux, flux_err_0=sigma, P_orb=float(P),
+                              contrast_curve_file=contrast_curve_file, N=N, parallel=parallel)))
+    return jobs

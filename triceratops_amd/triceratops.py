@@ -308,7 +308,7 @@ class target:
         models = np.ones((len(df), n_model))
         groups = {}
         for k in range(len(df)):
-            if df["M_s"].values[k] == 0.0:
+            if df["M_s"].values[k] == 0.0 or not np.isfinite(df["M_s"].values[k]):
                 continue
             groups.setdefault((k % 3 == 0, bool(star_num[k] != 1)), []).append(k)
         t_d = _lib.dev(model_time)
