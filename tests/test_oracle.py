@@ -203,3 +203,46 @@ def test_kepler_and_orbit_conventions():
                                   [[0.3, 0.2]])[0, 0] for s in range(1, S + 1)])
     got = O.evaluate_pv(tt, [[0.1, 0.0, 3.0, 10.0, 1.55, 0.2, 1.0]], [[0.3, 0.2]], ex, S)[0, 0]
     assert abs(got - sub.mean()) < 1e-15
+
+
+def test_eccentric_supersampled_row_end_to_end_in_arbitrary_precision():
+    """One eccentric, supersampled evaluate_pv row recomputed from first principles in 30-digit
+    arithmetic: Kepler's equation by root finding, the sky-projected separation z(t) from the
+    orbital elements, the limb-darkened flux by quadrature of the occulted disc, and the mean over
+    the S = 20 sub-exposures at t + exptime*((s - 1/2)/S - 1/2).  This pins the CHAIN (not just
+    the disc integral) against an independent evaluation.  What it cannot pin are pytransit's own
+    conventions, which remain recollections: (1) the orbit convention
+    w -> transit at true anomaly f = pi/2 - w with t0 the time of inferior conjunction, (2) the
+    far side of the orbit (sin(w + f) < 0) producing no transit, (3) the sub-exposure offsets."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 30
+    k, t0, per, a, inc, e, w = 0.11, 0.013, 2.7, 7.5, 1.52, 0.37, 1.1
+    u1, u2 = 0.42, 0.23
+    S, ex = 20, 0.02
+    times = np.array([-0.09, -0.0555, -0.02, 0.013, 0.041, 0.0702, 0.1])
+
+    K, T0, P, A, I, E_, W = map(mp.mpf, (k, t0, per, a, inc, e, w))
+    f_tr = mp.pi / 2 - W
+    E_tr = 2 * mp.atan(mp.sqrt((1 - E_) / (1 + E_)) * mp.tan(f_tr / 2))
+    M_tr = E_tr - E_ * mp.sin(E_tr)
+
+    def z_of(t):
+        M = 2 * mp.pi * (mp.mpf(t) - T0) / P + M_tr
+        Ecc = mp.findroot(lambda x: x - E_ * mp.sin(x) - M, M)
+        f = 2 * mp.atan2(mp.sqrt(1 + E_) * mp.sin(Ecc / 2), mp.sqrt(1 - E_) * mp.cos(Ecc / 2))
+        r = A * (1 - E_ ** 2) / (1 + E_ * mp.cos(f))
+        s = mp.sin(W + f)
+        z = r * mp.sqrt(1 - s ** 2 * mp.sin(I) ** 2)
+        return z, s
+
+    want = []
+    for t in times:
+        acc = mp.mpf(0)
+        for s_ in range(1, S + 1):
+            ts = mp.mpf(float(t)) + mp.mpf(ex) * ((mp.mpf(s_) - mp.mpf(1) / 2) / S - mp.mpf(1) / 2)
+            z, side = z_of(ts)
+            acc += mp.mpf(1) if side < 0 else _quadrature_flux(z, K, u1, u2)
+        want.append(float(acc / S))
+    got = O.evaluate_pv(times, [[k, t0, per, a, inc, e, w]], [[u1, u2]], ex, S)[0]
+    assert min(want) < 0.99 and max(want) == 1.0        # the row covers ingress, mid-transit and baseline
+    assert np.max(np.abs(got - np.array(want))) < 2e-13, np.abs(got - np.array(want))
