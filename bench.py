@@ -325,7 +325,7 @@ def run_grid(ctx):
 
     ev = [events() for _ in range(args.steps)]
 
-    def step(evs=None):
+    def step(evs=None, collective=True):
         lnz = []
         for i, (name, model, is_host, has_comp) in enumerate(fams):
             flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0)
@@ -337,9 +337,9 @@ def run_grid(ctx):
                 evs[i][1].record()
             lnz.append(_lib.lnz_from_halfchi2(h_d[i], lnprior_d[i], n_total, lnsigma))
         mine = torch.cat(lnz)
-        if world > 1:
+        if world > 1 and collective:
             gather(lnz_all, mine)          # the single data-path collective (RCCL over xGMI)
-        else:
+        elif world == 1:
             lnz_all.copy_(mine)
         return lnz_all
 
@@ -386,10 +386,10 @@ def run_grid(ctx):
             L_ = _lib.lib()
             L_.trx_set_supersample_tiers(0)
             try:
-                step()
+                step(collective=False)          # rank 0 only from here on: no collective
                 torch.cuda.synchronize(device)
                 e2 = events()
-                step(e2)
+                step(e2, collective=False)
                 torch.cuda.synchronize(device)
             finally:
                 L_.trx_set_supersample_tiers(1)

@@ -140,7 +140,7 @@ int trx_flux_grid_host(int model, int flags,
 int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out);
 
 /* Tuning knob for benchmarks/tests (process-wide, like the diagnostics below): rows staged per
- * wavefront (1,2,4,8,16; 0 = automatic). */
+ * wavefront (1..22, clamped to 16 by the one-row-at-a-time kernel; 0 = automatic). */
 int trx_set_rows_per_wave(int rows);
 
 /* Diagnostics (process-wide switches, default 1 / 1 / 0; no reference counterpart):
@@ -154,6 +154,11 @@ int trx_set_rows_per_wave(int rows);
 int trx_set_supersample_tiers(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
+/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 1024) go through
+ *    the packed-cell kernel (a wave walks the (row, time) cells of ~2048 cells' worth of rows, 64 at
+ *    a time across row boundaries) instead of the one-row-at-a-time kernel; 0 = never.  Model
+ *    values are bit-identical between the two; chi^2 differs by summation order (~1e-16 relative). */
+int trx_set_cell_packing_below(int n_time);
 
 const char* trx_version(void);
 const char* trx_last_error(void);

@@ -1,0 +1,37 @@
+"""Throughput of the likelihood kernel on SHORT light curves (the reference's operating point:
+100-200 binned points), 18 scenario families, one-row-at-a-time kernel vs packed-cell kernel.
+usage: python profiles/short_curves.py [rows_per_family]   (TRX_LIB selects an A/B build)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from triceratops_amd import _lib, synth
+
+n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+L = _lib.lib()
+print("# %s, %d rows per family, 18 families; evals/s = n_time x rows x 18 / time of the 18 launches" % (
+    os.path.basename(_lib.LIB_PATH), n_rows))
+for n_time in (50, 100, 200, 500, 1000, 2000):
+    rng = np.random.default_rng(synth.SEED)
+    t = synth.time_grid(n_time)
+    t_d = _lib.dev(t)
+    curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)
+    f_d = _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy()))
+    nr = n_rows if n_time <= 500 else n_rows // 4
+    blocks = [(_lib.dev(synth.family_rows(rng, fam, nr)), fam) for fam in synth.FAMILIES]
+    out = torch.empty(nr, dtype=torch.float64, device="cuda")
+    line = "n_time %5d:" % n_time
+    for name, below in (("row kernel", 0), ("packed cells", 1 << 30)):
+        L.trx_set_cell_packing_below(below)
+        def step():
+            for r_d, fam in blocks:
+                _lib.lnl_batch(fam[1], _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0, t_d, f_d, synth.SIGMA, r_d,
+                               synth.EXPTIME, 20, out=out)
+        step(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3): step()
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+        line += "  %s %.3f ms = %.3g evals/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
+    L.trx_set_cell_packing_below(1024)
+    print(line)

@@ -73,7 +73,7 @@ def test_two_ranks_control_flow_on_one_device():
     """`python bench.py --gpus 2` with no external launcher: bench.py starts the two ranks itself"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device"]
-                       + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                       + SMALL, capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
     _check_common(d, 2)
@@ -90,7 +90,7 @@ def test_two_ranks_under_an_external_launcher():
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device"] + SMALL,
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                       capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     _check_common(_last_json(p.stdout), 2)
 
@@ -101,7 +101,7 @@ def test_batch_mode_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device",
                         "--mode", "batch", "--tois", "4", "--batch-n", "50000", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                       capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_scenarios"] == 72

@@ -177,6 +177,67 @@ def test_scalar_k_rule_and_edge_rows():
         assert np.isposinf(got[12]) and np.isposinf(got[13])
 
 
+@pytest.mark.parametrize("n_time", [1, 5, 25, 63, 64, 65, 100, 199, 640, 1023])
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_packed_cell_kernel_equals_row_kernel(model, n_time):
+    """The two kernels share every device function: model grids (and secondary depths) must be
+    BIT-identical, chi^2/2 equal to summation order, exclusion pattern identical -- for batches
+    that end mid-chunk, rows shorter than a wave, and a row count that is not a multiple of the
+    rows per wave."""
+    rng = np.random.default_rng(900 + n_time)
+    t = np.sort(rng.uniform(-0.25, 0.25, n_time))
+    n = 1031
+    rows = synth.tp_rows(rng, n, True) if model == 0 else synth.eb_rows(rng, n, model == 2, True)
+    flux = 1.0 + rng.normal(0, synth.SIGMA, n_time)
+    t_d, f_d, r_d = _lib.dev(t), _lib.dev(flux), _lib.dev(rows)
+    L = _lib.lib()
+    res = {}
+    try:
+        for name, below, forced in (("rows", 0, 0), ("cells", 1 << 30, 0), ("cells7", 1 << 30, 7), ("cells1", 1 << 30, 1)):
+            L.trx_set_cell_packing_below(below)
+            L.trx_set_rows_per_wave(forced)
+            g, s = _lib.flux_grid(model, 0, t_d, r_d, synth.EXPTIME, synth.NSAMPLES)
+            h = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, synth.NSAMPLES)
+            res[name] = (g.cpu().numpy(), s.cpu().numpy(), h.cpu().numpy())
+    finally:
+        L.trx_set_cell_packing_below(1024)
+        L.trx_set_rows_per_wave(0)
+    g0, s0, h0 = res["rows"]
+    for name in ("cells", "cells7", "cells1"):
+        g, s, h = res[name]
+        assert np.array_equal(g, g0, equal_nan=True), name
+        assert np.array_equal(s, s0, equal_nan=True), name
+        assert np.array_equal(np.isposinf(h), np.isposinf(h0)), name
+        fin = np.isfinite(h0)
+        assert np.abs(h[fin] - h0[fin]).max() <= 1e-13 * np.abs(h0[fin]).max(), name
+    want = O.lnl_batch(model, t, flux, synth.SIGMA, rows[:, :64].copy())
+    _cmp_h(res["cells"][2][:64], want)
+
+
+def test_packed_cell_kernel_raw_model_and_census():
+    """pytransit-shaped rows through the packed-cell kernel: equals the oracle, and the census knob
+    reports the same plans as the one-row-at-a-time kernel"""
+    rng = np.random.default_rng(77)
+    rows = _raw_stress_rows(rng, 700)
+    rows = np.ascontiguousarray(rows[:, rows[0] <= 1.0][:, :333])
+    t = np.linspace(-0.4, 0.4, 150)
+    L = _lib.lib()
+    got = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), 0.0204, 20, want_secdepth=False)[0].cpu().numpy()
+    want = O.evaluate_pv(t, rows[:7].T, rows[7:].T, 0.0204, 20)
+    assert np.abs(got - want).max() < ATOL_FLUX
+    counts = {}
+    try:
+        L.trx_set_debug_node_counts(1)
+        for below in (0, 1 << 30):
+            L.trx_set_cell_packing_below(below)
+            counts[below] = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), 0.0204, 20,
+                                           want_secdepth=False)[0].cpu().numpy()
+    finally:
+        L.trx_set_debug_node_counts(0)
+        L.trx_set_cell_packing_below(1024)
+    assert np.array_equal(counts[0], counts[1 << 30])
+
+
 def test_empty_and_single():
     rng, t, flux = _lc(50)
     rows = synth.tp_rows(rng, 1)
@@ -328,10 +389,12 @@ def test_mixed_precision_model_tolerance(n_time):
 
 
 def test_large_batches_spot_checked():
-    """3e6 rows x 48 points (4 rows per wave; and 1 row per wave, which walks the grid-stride loop
-    over > 2^20 batches with the XCD-aware batch mapping) and 200 rows x 20000 points: random rows
-    against the oracle, and bitwise equality between the batched launch and the same rows launched
-    alone (no cross-row state)."""
+    """3e6 rows x 48 points (packed-cell kernel, 22 rows per wave; and the one-row-at-a-time kernel
+    with 1 row per wave, which walks the grid-stride loop over > 2^20 batches with the XCD-aware
+    batch mapping) and 200 rows x 20000 points: random rows against the oracle, and no cross-row
+    state: the same rows launched alone give the same chi^2 -- bitwise in the one-row-at-a-time
+    kernel, to summation order (1e-13) in the packed-cell kernel, whose per-row sum is split at
+    the 64-cell chunk boundaries the row happens to straddle."""
     rng, t, flux = _lc(48, seed=9)
     rows = synth.tp_rows(rng, 3_000_000, True)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)
@@ -339,15 +402,19 @@ def test_large_batches_spot_checked():
     pick = rng.choice(rows.shape[1], 300, replace=False)
     _cmp_h(h[pick], O.lnl_batch(0, t, flux, synth.SIGMA, rows[:, pick]))
     alone = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
-    assert np.array_equal(alone, h[pick])
+    assert np.abs(alone / h[pick] - 1).max() < 1e-13
     assert np.isfinite(h).all()
     L = _lib.lib()
     L.trx_set_rows_per_wave(1)
+    L.trx_set_cell_packing_below(0)
     try:
         h1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
+        alone1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
     finally:
         L.trx_set_rows_per_wave(0)
-    assert np.array_equal(h1, h)
+        L.trx_set_cell_packing_below(1024)
+    assert np.array_equal(alone1, h1[pick])
+    assert np.abs(h1 / h - 1).max() < 1e-13
     rng, t, flux = _lc(20000, seed=10)
     rows = synth.eb_rows(rng, 200, True, True)
     h = _lib.lnl_batch(2, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()

@@ -373,6 +373,257 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// cells_kernel: the same model for SHORT light curves (the reference's real operating point is
+// 100-200 binned points, examples/TSCIII_tutorial.ipynb cell 4).  With one row at a time a wave
+// of rows_kernel leaves the lanes past n_time idle (100 points: 64 + 36) and its per-row prologue
+// runs on B of the 64 lanes (a third of the wave's cycles at 100 points,
+// profiles/r01_r_phase_cycles.txt).  Here a wave takes a batch of B <= 22 rows (about 2048
+// cells) and
+//   * the prologue runs with lanes = rows (B lanes busy instead of 1-4), the secondary-eclipse
+//     scan with lanes = (row, point) as before;
+//   * the (row, time) cells of the whole batch form ONE index space, cell = r * n_time + j, which
+//     the lanes walk 64 at a time across row boundaries: every chunk but the last is full;
+//   * a lane's row constants are read from the row blocks in LDS where they are used (two
+//     neighbouring rows per chunk at most for n_time >= 64: broadcast reads), since cells of
+//     different rows share a wave they cannot ride in SGPRs;
+//   * chi^2 is reduced per chunk by a segmented shuffle reduction keyed on the row (fixed order,
+//     deterministic) into one LDS accumulator per row; grid mode stores cell = output offset,
+//     fully coalesced.
+// Plan / stage A / stage B / stage C are those of rows_kernel (same device functions, same node
+// tables), so a cell's model value is bit-identical between the two kernels; only the order of the
+// chi^2 sum differs.
+#ifndef TRX_CELLS_WAVES_PER_EU
+#define TRX_CELLS_WAVES_PER_EU 4
+#endif
+constexpr int kCellsMaxRows = 22;     // B * (18 + 25) doubles of phase 1-3 arrays fit the slab
+
+template <int MODE, bool STEP, bool FP32>
+__global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+{
+    extern __shared__ double lds[];
+    const int B = a.B;
+    RowC* rows = reinterpret_cast<RowC*>(lds);
+    double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 per row
+    double* tier_xw = hacc + B;
+    const int SB = a.SB;
+    const int cap = 64 * SB;
+    double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
+    unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
+    unsigned short* rowof = items + cap;                              // [64] row of each lane's cell
+    RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // phases 1-3 only (overlay)
+    double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
+    if (a.use_tiers && threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
+            tier_xw[i] = a.tiers.x[i];
+            tier_xw[kTiers * kTierMaxNodes + i] = a.tiers.w[i];
+        }
+    }
+    const int lane = threadIdx.x;
+    const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
+    const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
+    const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
+    const long n = a.n;
+    const double s2 = a.s2;
+    const int n_time = a.n_time;
+
+    const long per_xcd = (a.nbatch + 7) / 8;
+    for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
+        const long batch = (v & 7) * per_xcd + (v >> 3);
+        if ((v >> 3) >= per_xcd || batch >= a.nbatch) continue;
+        const long base = batch * B;
+        const int nb = (int)((n - base < B) ? (n - base) : B);
+        double ysec = 0.0;
+
+        // ---- phase 1: per-row constants, lanes = rows ----------------------------------
+        if (lane < nb) {
+            const double* p = a.params + base + lane;
+            RowC& c = rows[lane];
+            double u1, u2;
+            if (a.model == TRX_MODEL_RAW) {
+                u1 = p[7 * n]; u2 = p[8 * n];
+                orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
+                c.xeb = 0.0; c.fdil = 0.0;
+            } else {
+                double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
+                if (a.model == TRX_MODEL_TP) {
+                    const double R_p = p[0];
+                    per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
+                    u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
+                    k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
+                } else {
+                    const double R_EB = p[0], eb_fr = p[1 * n];
+                    per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
+                    u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
+                    feb = eb_fr / (1.0 - eb_fr);                            // :401
+                    k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
+                    ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
+                }
+                const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
+                const double a_R = acm / (R_s * kRsun);                     // :343, :409
+                const double inc_r = inc * (kPi / 180.0);                   // :344, :410
+                const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
+                orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+                if (!eblike) {
+                    c.xeb = 0.0;
+                    c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
+                } else {
+                    RowC& sc = srows[lane];
+                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
+                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                    const Limb L = limb_weights(u1, u2);
+                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
+                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                    if (is_host) {                                          // :427-432
+                        c.xeb = feb / fcomp;
+                        ysec = fcomp / feb;
+                        c.fdil = 1.0 / (fcomp + feb);
+                    } else {                                                // :433-438
+                        c.xeb = feb / 1.0;
+                        ysec = 1.0 / feb;
+                        c.fdil = fcomp / (1.0 + feb);
+                    }
+                }
+            }
+            const Limb L = limb_weights(u1, u2);
+            c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
+            c.excl = 0.0;
+            hacc[lane] = 0.0;
+        }
+        __syncthreads();
+
+        // ---- phases 2+3: secondary eclipse depth (EB families) --------------------------
+        if (eblike) {
+            for (int it = lane; it < nb * kSecPoints; it += 64) {
+                const int r = it / kSecPoints, j = it - r * kSecPoints;
+                const RowC sc = srows[r];
+                const Limb L{sc.cle, sc.cld, sc.ced};
+                double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
+                if (j == kSecPoints - 1) ts = 0.05;
+                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
+            }
+            __syncthreads();
+            if (lane < nb) {
+                double m = INFINITY;
+                bool has_nan = false;
+                for (int j = 0; j < kSecPoints; ++j) {
+                    const double f = sec[lane * kSecPoints + j];
+                    has_nan = has_nan || (f != f);
+                    m = (f < m) ? f : m;
+                }
+                if (has_nan) m = NAN;                                       // np.min propagates NaN
+                const double fd = rows[lane].fdil;
+                m = (m + ysec) / (1.0 + ysec);
+                const double secdepth = 1.0 - (m + fd) / (1.0 + fd);
+                rows[lane].excl = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;   // :535
+                if (MODE == MODE_GRID && a.out_sec) a.out_sec[base + lane] = secdepth;
+            }
+            __syncthreads();
+        }
+
+        // ---- phase 4: the cells of the batch, 64 at a time across row boundaries ---------
+        const int ncell = nb * n_time;
+        int r = 0, j = lane;
+        while (j >= n_time && r < nb) { j -= n_time; ++r; }
+        for (int c0 = 0; c0 < ncell; c0 += 64) {
+            const bool valid = (c0 + lane) < ncell;
+            const int rr = valid ? r : (nb - 1);
+            const RowC& c = rows[rr];
+            const double t = valid ? a.time[j] : 0.0;
+            CellPlan pl;
+            if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+            rowof[lane] = (unsigned short)rr;
+            const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
+            const double* ws = xs + kTiers * kTierMaxNodes;
+            double fsum = 0.0;
+            for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
+                int n_in = 0, n_lb = 0, ns = 0;
+                // stage A
+                const double ck = c.k, opp = 1.0 + ck, opp2 = opp * opp, omk = 1.0 - ck;
+                for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
+                    const int s = s0 + si + 1;
+                    int cls = 0;
+                    double vz = 1.0;
+                    if (s <= pl.n) {
+                        const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
+                        double Y;
+                        const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
+                        if (Y >= 0.0 && z2 < opp2) {
+                            vz = sqrt_fast(z2);
+                            cls = (ck < 1.0 && vz <= omk) ? 1 : 2;
+                        } else if (z2 != z2) {
+                            vz = z2;
+                        }
+                    }
+                    const int idx = si * 64 + lane;
+                    zbuf[idx] = vz;
+                    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+                    if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
+                    if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
+                    n_in += __popcll(m1);
+                    n_lb += __popcll(m2);
+                    ns = si + 1;
+                }
+                __syncthreads();
+                // stage B: an item's row comes with its lane of origin
+                for (int i = lane; i < n_in + n_lb; i += 64) {
+                    const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
+                    const RowC& ic = rows[rowof[idx & 63]];
+                    const Limb L{ic.cle, ic.cld, ic.ced};
+                    zbuf[idx] = disc_flux<FP32>(zbuf[idx], ic.k, L);
+                }
+                __syncthreads();
+                // stage C
+                for (int si = 0; si < ns; ++si) {
+                    const int s = s0 + si + 1;
+                    if (s <= pl.n) {
+                        const double f = zbuf[si * 64 + lane];
+                        fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
+                    }
+                }
+                __syncthreads();
+            }
+            double contrib = 0.0;
+            if (valid) {
+                double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
+                if (eblike) { const double xe = c.xeb; m = (m + xe) / (1.0 + xe); }
+                if (a.model != TRX_MODEL_RAW) { const double fd = c.fdil; m = (m + fd) / (1.0 + fd); }
+                if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
+                if (MODE == MODE_GRID) {
+                    a.out[(size_t)base * n_time + c0 + lane] = m;
+                } else {
+                    const double d = a.flux[j] - m;
+                    contrib = (d * d) / s2;                                 // :486, :537, :586
+                }
+            }
+            if (MODE == MODE_LNL) {
+                // segmented reduction keyed on the row: after the doubling steps the first lane of
+                // every row segment holds that segment's sum (segments are contiguous)
+                const int key = valid ? rr : -1;
+                double vsum = contrib;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double ov = __shfl_down(vsum, o, 64);
+                    const int ok = __shfl_down(key, o, 64);
+                    if (lane + o < 64 && ok == key) vsum += ov;
+                }
+                const int prev = __shfl_up(key, 1, 64);
+                if (valid && (lane == 0 || prev != key)) hacc[rr] += vsum;
+            }
+            j += 64;
+            while (j >= n_time && r < nb) { j -= n_time; ++r; }
+        }
+        __syncthreads();
+        if (MODE == MODE_LNL && lane < nb) {
+            double h = 0.5 * hacc[lane];
+            if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
+            a.out[base + lane] = h;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 0.5 * sum_t (flux_t - model[r][t])^2 / sigma^2, one wavefront per row, 16 B/lane loads.
 __global__ __launch_bounds__(256) void chi2_grid_kernel(const double* __restrict__ flux,
                                                         const double* __restrict__ grid,
@@ -464,6 +715,15 @@ __device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double 
     }
 }
 
+// Loads per lane per trip (16 B each) and whether the next trip's loads are issued before the
+// current trip is folded (profiles/r02_lme_variants.txt)
+#ifndef TRX_LME_LOADS
+#define TRX_LME_LOADS 2
+#endif
+#ifndef TRX_LME_PREFETCH
+#define TRX_LME_PREFETCH 1
+#endif
+
 __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
                                                           const double* __restrict__ h,
                                                           const double* __restrict__ lnprior,
@@ -475,20 +735,24 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
     const long stride = (long)gridDim.x * blockDim.x;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {
-        // 16 B per lane per load, two independent loads in flight per trip
+        // 16 B per lane per load, TRX_LME_LOADS independent loads per trip; the next trip's loads
+        // are in flight while this trip is folded (and while the queues are flushed).
+        // The fold itself leans on IEEE max: fmax ignores a NaN operand, so NaN never reaches the
+        // running maximum, `x - max > -80` is false for NaN and for -inf, and a +inf drives the
+        // maximum to +inf (detected once, after the loop) -- no per-value inf / NaN tests.
+        // Terms within 80 of the running maximum are rare once the maximum has settled (a few
+        // per cent of a broad log-likelihood distribution) but with 64 lanes x 4-8 values per trip
+        // some lane nearly always holds one, and the whole wave would run exp several times per
+        // trip.  So a term that can still count is parked in a per-thread queue in LDS and the
+        // exps run over the queues only when one of them fills.  The parked values are raw, so a
+        // later, larger maximum needs no bookkeeping.
+        constexpr int kL = TRX_LME_LOADS, kV = 2 * kL;
+        constexpr int kQ = (kV > 4) ? 12 : 8;
+        __shared__ double qbuf[kQ][256];
+        int qc = 0;
         const long nv = n >> 1;
         const dvec2* src = reinterpret_cast<const dvec2*>(h ? h : logw);
         const dvec2* pri = reinterpret_cast<const dvec2*>(lnprior);
-        // Terms within 80 of the running maximum are rare once the maximum has settled (a few
-        // per cent of a broad log-likelihood distribution) but with 64 lanes x 4 values per trip
-        // some lane nearly always holds one, and the whole wave would run exp four times per
-        // trip.  So a term that can still count is parked in a per-thread queue in LDS and the
-        // exps run over the queues only when one of them fills.  The parked values are raw, so a
-        // later, larger maximum needs no bookkeeping.  (3.2 GB of U(-3000,-1): 4.8 -> 5.3 TB/s;
-        // a distribution narrower than the cut-off takes the direct branch, 4.2 -> 3.9 TB/s.)
-        constexpr int kQ = 8;
-        __shared__ double qbuf[kQ][256];
-        int qc = 0;
         auto flush = [&]() {
             for (int i = 0; i < kQ; ++i) {
                 if (i < qc) {
@@ -498,58 +762,73 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
             }
             qc = 0;
         };
-        for (long v = tid; v < nv; v += 2 * stride) {
-            const long v2 = v + stride;
-            const bool has2 = v2 < nv;
-            dvec2 a = __builtin_nontemporal_load(&src[v]);
-            dvec2 b = has2 ? __builtin_nontemporal_load(&src[v2]) : dvec2{-INFINITY, -INFINITY};
-            if (h) {
-                a = c0 - a;
-                if (has2) b = c0 - b;
-                if (pri) {
-                    a += __builtin_nontemporal_load(&pri[v]);
-                    if (has2) b += __builtin_nontemporal_load(&pri[v2]);
-                }
-            }
-            double x[4] = {a.x, a.y, b.x, b.y};
-            double cm = -INFINITY;
+        // unconditional loads at clamped indices (a predicated load forces vmcnt(0) at the join);
+        // slots past the end are masked to -inf when the trip is folded
+        auto fetch = [&](long v0, dvec2* a, dvec2* p) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double w = x[u];
-                if (w == INFINITY) { st.pinf = 1; w = -INFINITY; }
-                if (!(w == w)) w = -INFINITY;
-                x[u] = w;
-                cm = fmax(cm, w);
+            for (int u = 0; u < kL; ++u) {
+                long j = v0 + u * stride;
+                j = (j < nv) ? j : (nv - 1);
+                a[u] = __builtin_nontemporal_load(&src[j]);
+                if (pri) p[u] = __builtin_nontemporal_load(&pri[j]);
             }
+        };
+        dvec2 cur[kL], curp[kL], nxt[kL], nxtp[kL];
+        if (tid < nv) fetch(tid, cur, curp);
+        for (long v = tid; v < nv; v += kL * stride) {
+            const long vn = v + kL * stride;
+            if (TRX_LME_PREFETCH && vn < nv) fetch(vn, nxt, nxtp);
+            double x[kV];
+#pragma unroll
+            for (int u = 0; u < kL; ++u) {
+                dvec2 a = cur[u];
+                if (h) {
+                    a = c0 - a;
+                    if (pri) a += curp[u];
+                }
+                const bool ok = v + u * stride < nv;
+                x[2 * u] = ok ? a.x : -INFINITY;
+                x[2 * u + 1] = ok ? a.y : -INFINITY;
+            }
+            double cm = x[0];
+#pragma unroll
+            for (int u = 1; u < kV; ++u) cm = fmax(cm, x[u]);
             if (cm > st.m) {
                 const double d = st.m - cm;
                 st.s = (d > -80.0) ? st.s * exp(d) : 0.0;
                 st.m = cm;
             }
-            bool live[4];
+            bool live[kV];
             int crowd = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kV; ++u) {
                 live[u] = x[u] - st.m > -80.0;
                 crowd += __popcll(__ballot(live[u]));
             }
-            if (crowd > 96) {
+            if (crowd > 24 * kV) {
                 // a narrow distribution: most terms count, nothing to gain from parking them
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kV; ++u)
                     if (live[u]) st.s += exp(x[u] - st.m);
-                continue;
-            }
-            if (__any(qc > kQ - 4)) flush();
+            } else {
+                if (__any(qc > kQ - kV)) flush();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (live[u]) {
-                    qbuf[qc][threadIdx.x] = x[u];
-                    ++qc;
+                for (int u = 0; u < kV; ++u) {
+                    if (live[u]) {
+                        qbuf[qc][threadIdx.x] = x[u];
+                        ++qc;
+                    }
                 }
+            }
+            if (TRX_LME_PREFETCH) {
+#pragma unroll
+                for (int u = 0; u < kL; ++u) { cur[u] = nxt[u]; curp[u] = nxtp[u]; }
+            } else if (vn < nv) {
+                fetch(vn, cur, curp);
             }
         }
         flush();
+        if (st.m == INFINITY) { st.pinf = 1; st.m = -INFINITY; st.s = 0.0; }
         if ((n & 1) && tid == 0) lme_fold4(st, lme_value(logw, h, lnprior, c0, n - 1), -INFINITY, -INFINITY, -INFINITY);
     } else {
         for (long i0 = tid * 4; i0 < n; i0 += stride * 4) {
@@ -742,7 +1021,7 @@ bool fill_tiers(TierTable& T, int S)
 int pick_rows_per_wave(int n_time, long n)
 {
     const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
-    if (forced > 0) return forced;
+    if (forced > 0) return forced > 16 ? 16 : forced;
     // measured (profiles/r01_n_rows_per_wave.txt): rows are processed one after the other by the
     // wave, so more rows per wave only amortise the prologue's idle lanes while making fewer,
     // longer waves.  4 is best up to ~250 points, 2 up to ~1000, 1 at 2000.
@@ -751,9 +1030,46 @@ int pick_rows_per_wave(int n_time, long n)
     return B;
 }
 
+// light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
+std::atomic<int> g_cells_below{1024};
+
+template <int MODE>
+int launch_cells(const RowsArgs& a0, hipStream_t st)
+{
+    RowsArgs a = a0;
+    // about 2048 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays)
+    int B = (2048 + a.n_time - 1) / a.n_time;
+    B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
+    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
+    if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
+    while (B > 1 && a.n / B < 4096) B = (B + 1) / 2;          // few rows: fill the chip first
+    a.B = B;
+    a.s2 = a.sigma * a.sigma;
+    a.dS = (double)a.S;
+    a.rS = 1.0 / a.dS;
+    a.nbatch = (a.n + a.B - 1) / a.B;
+    const long max_grid = 1L << 20;
+    const long want_grid = 8 * ((a.nbatch + 7) / 8);
+    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
+    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
+    a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
+    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short)) + 64 * sizeof(unsigned short);
+    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
+    if (slab < overlay) slab = overlay;
+    const size_t lds = ((size_t)a.B * (kRowDoubles + 1) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
+    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
+    if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
+    else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
+    else            hipLaunchKernelGGL((cells_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
+
 template <int MODE>
 int launch_rows(const RowsArgs& a0, hipStream_t st)
 {
+    if (a0.n_time < g_cells_below.load(std::memory_order_relaxed) && a0.n_time > 0)
+        return launch_cells<MODE>(a0, st);
     RowsArgs a = a0;
     a.B = pick_rows_per_wave(a.n_time, a.n);
     a.s2 = a.sigma * a.sigma;
@@ -959,9 +1275,17 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
 
 int trx_set_rows_per_wave(int rows)
 {
-    if (rows != 0 && rows != 1 && rows != 2 && rows != 4 && rows != 8 && rows != 16)
-        return fail(TRX_ERR_ARG, "rows per wave must be 0,1,2,4,8,16%s (got %ld)", "", (long)rows);
+    if (rows < 0 || rows > kCellsMaxRows)
+        return fail(TRX_ERR_ARG, "rows per wave must be 0 (automatic) .. 22%s (got %ld)", "", (long)rows);
     g_rows_per_wave = rows;
+    return TRX_OK;
+}
+
+/* diagnostics (include/trx.h): light curves with fewer points than this use the packed-cell kernel */
+int trx_set_cell_packing_below(int n_time)
+{
+    if (n_time < 0) return fail(TRX_ERR_ARG, "n_time threshold must be >= 0%s (got %ld)", "", (long)n_time);
+    g_cells_below = n_time;
     return TRX_OK;
 }
 
