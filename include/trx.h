@@ -154,11 +154,95 @@ int trx_set_rows_per_wave(int rows);
 int trx_set_supersample_tiers(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
-/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 1024) go through
+/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 320) go through
  *    the packed-cell kernel (a wave walks the (row, time) cells of ~2048 cells' worth of rows, 64 at
  *    a time across row boundaries) instead of the one-row-at-a-time kernel; 0 = never.  Model
  *    values are bit-identical between the two; chi^2 differs by summation order (~1e-16 relative). */
 int trx_set_cell_packing_below(int n_time);
+
+/* ------------------------------------------------------------------------------------------
+ * The per-draw half of one scenario evidence as ONE kernel (no reference counterpart as a single
+ * function: it is the body of every lnZ_* between its np.random draws and its lnL_*_p call,
+ * marginal_likelihoods.py:67-123 (TTP) ... 2064-2250 (BEB), with the samplers of priors.py:16-383,
+ * the stellar / flux relations of funcs.py:54-140 and the companion priors of priors.py:580-1005).
+ * Input: staged random numbers in the reference's draw order (device generator, or numpy's global
+ * stream copied over); output: the SoA parameter block trx_lnl_batch takes (all N draws, not yet
+ * compacted), the geometry mask(s) and lnprior_companion. */
+
+#define TRX_HOST_TARGET     0   /* T, P, D scenarios: the target star hosts the transit */
+#define TRX_HOST_COMPANION  1   /* S scenarios: an unresolved bound companion hosts it */
+#define TRX_HOST_FIELD      2   /* B scenarios: a background (TRILEGAL) star hosts it */
+#define TRX_COMP_NONE       0
+#define TRX_COMP_BOUND      1   /* P, S: bound companion (mass ratio draw or MOLUSC table) */
+#define TRX_COMP_FIELD      2   /* D, B: background star drawn from the TRILEGAL population */
+#define TRX_PRIOR_NONE      0
+#define TRX_PRIOR_BOUND_TP  1   /* lnprior_bound_TP, priors.py:580-782 */
+#define TRX_PRIOR_BOUND_EB  2   /* lnprior_bound_EB, priors.py:784-984 */
+#define TRX_PRIOR_FIELD     3   /* lnprior_background or its no-contrast-curve constant, :986-1005 */
+
+#define TRX_DRAW_MAX_KNOTS      16
+#define TRX_DRAW_SPLINE_DOUBLES (1 + 5 * TRX_DRAW_MAX_KNOTS)  /* m, knots[16], c0..c3[16] */
+#define TRX_DRAW_N_SPLINES      6
+#define TRX_SPL_R_HOT   0   /* funcs.py:19-51: mass -> radius / Teff, Torres et al. branch */
+#define TRX_SPL_T_HOT   1
+#define TRX_SPL_R_COOL  2   /*                                         cool-dwarf branch   */
+#define TRX_SPL_T_COOL  3
+#define TRX_SPL_F_TESS  4   /* funcs.py:81-119: mass -> log10 flux, TESS band */
+#define TRX_SPL_F_BAND  5   /*                  ... band of the contrast curve */
+#define TRX_DRAW_MAX_CC   256   /* contrast-curve points */
+#define TRX_DRAW_MAX_LUT  160   /* (Teff / 250 K) x (logg / 0.5 dex) cells of the companion LDC table */
+
+/* inverse CDF of a broken power law (sample_rp, sample_q, sample_q_companion); the constants are
+ * computed on the host in the arithmetic of priors.py: segment j covers lo[j] < x <= hi[j] and maps
+ * x to ((x / norm - cum[j]) * p1[j] / amp[j] + base[j]) ** ip[j]   (amp[j] == 0: no division) */
+typedef struct {
+    int nseg, ones;              /* ones: degenerate law (M_s <= 0.1): every draw is 1 */
+    double norm;
+    double hi[3], lo[3], cum[3], p1[3], amp[3], base[3], ip[3];
+} trx_power_law;
+
+typedef struct {
+    long N;
+    int planet;                  /* 1: *TP scenario (10-column block), 0: *EB (11 columns + twin) */
+    int host, comp, prior;       /* TRX_HOST_*, TRX_COMP_*, TRX_PRIOR_* */
+    int parallel;                /* 1: vector-path mask semantics, 0: per-draw-loop semantics */
+    int flat;                    /* flatpriors */
+    int use_cc;                  /* a contrast curve was given */
+    int n_cc, n_lut;
+    double P_lo, P_hi;           /* period range (uP != NULL) or the fixed period in P_lo */
+    double M_s, R_s, Teff, u1, u2;        /* target star and its limb darkening */
+    double ecc_pow;              /* binaries: ecc = uEcc ** ecc_pow (priors.py:152-154) */
+    double teff_cap;             /* companion LDC lookup: 10000 (STP) or 13000 (SEB) */
+    double f0_tess, f0_band;     /* flux_relation(M_s) in the TESS band / contrast-curve band */
+    double dist_pc, kepler_c;    /* 1000 / plx;  4 pi^2 / (G M_ref Msun)        (priors.py:601-640) */
+    double f1, f2, f3, t2, t3, t4, t5;     /* Moe & Di Stefano rate constants for M_ref */
+    double bg_const, bg_amp;     /* ln((N_comp/0.1)(1/3600)^2 2.2^2);  (N_comp/0.1)(1/3600)^2 */
+    trx_power_law law_rp_hi, law_rp_lo, law_q, law_qc;
+    /* tables (device) */
+    const double* splines;       /* [TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES] */
+    const double* cc_seps;       /* [n_cc] separations, */
+    const double* cc_cons;       /* [n_cc] contrasts (increasing) */
+    const double* lut;           /* [2][n_lut] companion limb darkening, NaN = cell absent */
+    /* TRILEGAL population (device), indexed by idx */
+    const double *f_mass, *f_radius, *f_teff, *f_logg, *f_fr, *f_delta, *f_frband, *f_u1, *f_u2;
+    /* staged random numbers (device), [N] each; NULL where the scenario does not draw */
+    const double *uP, *uQc, *uRp, *uInc, *uQ, *uEcc, *uW;
+    const double* ecc_in;        /* planets: Beta(0.867, 3.03) draws */
+    const double* qc_in;         /* MOLUSC mass ratios instead of uQc */
+    const long* idx;             /* field-star index per draw */
+    /* outputs (device) */
+    double* cols;                /* [11][N] planet: R_p P inc a R_s u1 u2 ecc argp comp_fr M_host;
+                                    [14][N] binary: R_EB EB_fr P inc a R_s u1 u2 ecc argp comp_fr
+                                                    a_twin M_EB M_host */
+    unsigned char* mask;         /* [N] geometry mask (binary: the q < 0.95 branch) */
+    unsigned char* mask_twin;    /* [N] binary: the q >= 0.95 branch at 2 P_orb */
+    double* lnprior;             /* [N] or NULL */
+    int* flag;                   /* [1]: bit 0 set when a draw needs a limb-darkening cell the grid
+                                    lacks (the reference raises ValueError) */
+} trx_draw_args;
+
+int trx_draw_scenario(const trx_draw_args* args, void* stream);
+size_t trx_draw_args_size(void);   /* sizeof(trx_draw_args): lets a foreign binding check its layout */
 
 const char* trx_version(void);
 const char* trx_last_error(void);

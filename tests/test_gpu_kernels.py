@@ -180,10 +180,11 @@ def test_scalar_k_rule_and_edge_rows():
 @pytest.mark.parametrize("n_time", [1, 5, 25, 63, 64, 65, 100, 199, 640, 1023])
 @pytest.mark.parametrize("model", [0, 1, 2])
 def test_packed_cell_kernel_equals_row_kernel(model, n_time):
-    """The two kernels share every device function: model grids (and secondary depths) must be
-    BIT-identical, chi^2/2 equal to summation order, exclusion pattern identical -- for batches
-    that end mid-chunk, rows shorter than a wave, and a row count that is not a multiple of the
-    rows per wave."""
+    """The two kernels share every device function: model grids (and secondary depths) agree to
+    rounding (1e-13; the compiler contracts the inlined arithmetic differently in the two
+    kernels), exactly-1 and NaN patterns are identical, chi^2/2 agrees to 1e-11 relative (a 1e-15 model difference on a one-point curve), the
+    exclusion pattern is identical -- for batches that end mid-chunk, rows shorter than a wave, and
+    a row count that is not a multiple of the rows per wave."""
     rng = np.random.default_rng(900 + n_time)
     t = np.sort(rng.uniform(-0.25, 0.25, n_time))
     n = 1031
@@ -200,16 +201,19 @@ def test_packed_cell_kernel_equals_row_kernel(model, n_time):
             h = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, synth.NSAMPLES)
             res[name] = (g.cpu().numpy(), s.cpu().numpy(), h.cpu().numpy())
     finally:
-        L.trx_set_cell_packing_below(1024)
+        L.trx_set_cell_packing_below(320)
         L.trx_set_rows_per_wave(0)
     g0, s0, h0 = res["rows"]
     for name in ("cells", "cells7", "cells1"):
         g, s, h = res[name]
-        assert np.array_equal(g, g0, equal_nan=True), name
-        assert np.array_equal(s, s0, equal_nan=True), name
+        assert np.array_equal(np.isnan(g), np.isnan(g0)), name
+        assert np.array_equal(g == 1.0, g0 == 1.0), name
+        assert np.nanmax(np.abs(g - g0)) < 1e-13, (name, np.nanmax(np.abs(g - g0)))
+        assert np.array_equal(np.isnan(s), np.isnan(s0)) and np.nanmax(np.abs(s - s0), initial=0.0) < 1e-13, name
         assert np.array_equal(np.isposinf(h), np.isposinf(h0)), name
+        assert np.array_equal(np.isnan(h), np.isnan(h0)), name
         fin = np.isfinite(h0)
-        assert np.abs(h[fin] - h0[fin]).max() <= 1e-13 * np.abs(h0[fin]).max(), name
+        assert np.abs(h[fin] / h0[fin] - 1).max() < 1e-11, (name, np.abs(h[fin] / h0[fin] - 1).max())
     want = O.lnl_batch(model, t, flux, synth.SIGMA, rows[:, :64].copy())
     _cmp_h(res["cells"][2][:64], want)
 
@@ -234,8 +238,55 @@ def test_packed_cell_kernel_raw_model_and_census():
                                            want_secdepth=False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
-        L.trx_set_cell_packing_below(1024)
+        L.trx_set_cell_packing_below(320)
     assert np.array_equal(counts[0], counts[1 << 30])
+
+
+def test_second_near_side_passage_on_a_very_eccentric_orbit():
+    """e = 0.9 seen nearly along the major axis: the strip |X| < 1 + k is met a second time, a few
+    hours before conjunction, while the companion is still (just) on the near side -- a grazing
+    passage 6e-5 deep that a transit window built around conjunction alone misses.  Row found by
+    the irregular time stamps of test_packed_cell_kernel_equals_row_kernel; both kernels."""
+    row = np.array([[9.62080439e-01], [2.93357695e-05], [1.23513199e+01], [6.48158862e+01],
+                    [1.59025933e+12], [1.38005527e+00], [1.52880035e-01], [5.74606889e-02],
+                    [9.00000000e-01], [1.05234974e+02], [2.09587868e-01]])
+    t = np.sort(np.concatenate([np.linspace(-0.25, 0.25, 97), [-0.158124, -0.1585, -0.1577]]))
+    want, _ = O.flux_grid(O.MODEL_EB, t, row)
+    assert want.min() < 1 - 1e-5 and (want[0] < 1).sum() >= 2
+    L = _lib.lib()
+    try:
+        for below in (0, 1 << 30):
+            L.trx_set_cell_packing_below(below)
+            got, _ = _lib.flux_grid(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(row), synth.EXPTIME, synth.NSAMPLES)
+            assert np.abs(got.cpu().numpy() - want).max() < ATOL_FLUX, below
+    finally:
+        L.trx_set_cell_packing_below(320)
+
+
+def test_rows_with_a_flat_model_tie_exactly():
+    """draws whose model is exactly 1 over the data window share ONE chi^2 value bit for bit, in
+    both kernels and wherever the row sits in its batch (the reference's argsort then orders the
+    ties; a 1-ulp scatter would scramble the tail of the best-fit table)"""
+    rng, t, flux = _lc(100)
+    rows = synth.tp_rows(rng, 5000, True)
+    rows[2, rng.random(5000) < 0.3] = 20.0     # inc = 20 deg: (almost) never transits
+    t_d, r_d = _lib.dev(t), _lib.dev(rows)
+    grid, _ = _lib.flux_grid(0, 0, t_d, r_d, synth.EXPTIME, synth.NSAMPLES, want_secdepth=False)
+    flat = (grid == 1.0).all(dim=1).cpu().numpy()
+    assert 1000 < flat.sum() < 2500
+    L = _lib.lib()
+    vals = {}
+    try:
+        for below in (0, 1 << 30):
+            L.trx_set_cell_packing_below(below)
+            h = _lib.lnl_batch(0, 0, t_d, _lib.dev(flux), synth.SIGMA, r_d, synth.EXPTIME,
+                               synth.NSAMPLES).cpu().numpy()
+            assert np.unique(h[flat]).size == 1 and np.unique(h[~flat]).size > 3000
+            vals[below] = h[flat][0]
+    finally:
+        L.trx_set_cell_packing_below(320)
+    assert vals[0] == vals[1 << 30]
+    assert abs(vals[0] / (0.5 * np.sum((flux - 1.0) ** 2 / synth.SIGMA ** 2)) - 1) < 1e-13
 
 
 def test_empty_and_single():
@@ -393,7 +444,7 @@ def test_large_batches_spot_checked():
     with 1 row per wave, which walks the grid-stride loop over > 2^20 batches with the XCD-aware
     batch mapping) and 200 rows x 20000 points: random rows against the oracle, and no cross-row
     state: the same rows launched alone give the same chi^2 -- bitwise in the one-row-at-a-time
-    kernel, to summation order (1e-13) in the packed-cell kernel, whose per-row sum is split at
+    kernel, to summation order (1e-11) in the packed-cell kernel, whose per-row sum is split at
     the 64-cell chunk boundaries the row happens to straddle."""
     rng, t, flux = _lc(48, seed=9)
     rows = synth.tp_rows(rng, 3_000_000, True)
@@ -402,7 +453,7 @@ def test_large_batches_spot_checked():
     pick = rng.choice(rows.shape[1], 300, replace=False)
     _cmp_h(h[pick], O.lnl_batch(0, t, flux, synth.SIGMA, rows[:, pick]))
     alone = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
-    assert np.abs(alone / h[pick] - 1).max() < 1e-13
+    assert np.abs(alone / h[pick] - 1).max() < 1e-11, np.abs(alone / h[pick] - 1).max()
     assert np.isfinite(h).all()
     L = _lib.lib()
     L.trx_set_rows_per_wave(1)
@@ -412,9 +463,9 @@ def test_large_batches_spot_checked():
         alone1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
     finally:
         L.trx_set_rows_per_wave(0)
-        L.trx_set_cell_packing_below(1024)
+        L.trx_set_cell_packing_below(320)
     assert np.array_equal(alone1, h1[pick])
-    assert np.abs(h1 / h - 1).max() < 1e-13
+    assert np.abs(h1 / h - 1).max() < 1e-11, np.abs(h1 / h - 1).max()
     rng, t, flux = _lc(20000, seed=10)
     rows = synth.eb_rows(rng, 200, True, True)
     h = _lib.lnl_batch(2, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()

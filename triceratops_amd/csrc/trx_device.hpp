@@ -553,6 +553,26 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
         if (psi >= 0.0) { plo = xhi; phi2 = kTwoPi - xhi; } else { plo = xhi - kTwoPi; phi2 = -xhi; }
     } else {
         if (psi >= 0.0) { plo = xhi; phi2 = xlo; } else { plo = -xlo; phi2 = -xhi; }
+        // The strip |X| < 1+k is met on a second arc, the mirror image about psi = 0.  It normally
+        // lies on the far side of the orbit (Y < 0: no transit), but on a very eccentric orbit seen
+        // nearly along its major axis its end next to psi = 0 can still be on the near side: a
+        // second, grazing passage a few hours from conjunction (e = 0.9: flux deficit 6e-5,
+        // found by tests/test_gpu_kernels.py on irregular time stamps).  Y(E) = Ay cos(E - phy) -
+        // ay e is a sinusoid too: if its maximum over the mirror arc is not negative the window
+        // becomes the hull of the two arcs (the cells in between are evaluated and come out as 1).
+        const double o1 = (psi >= 0.0) ? -xlo : xhi, o2 = (psi >= 0.0) ? -xhi : xlo;
+        const double Ay = sqrt(c.ay * c.ay + c.by * c.by);
+        const double phy = atan2(c.by, c.ay);
+        const double d1 = remainder(Etr + (o1 - psi) - phy, kTwoPi), span = o2 - o1;
+        const bool peak = (d1 <= 0.0 && d1 + span >= 0.0) || (d1 + span >= kTwoPi);
+        double s1, c1, s2, c2;
+        sincos_red(d1, s1, c1);
+        sincos_red(d1 + span, s2, c2);
+        const double cmax = peak ? 1.0 : fmax(c1, c2);
+        if (!(Ay * cmax - c.ay * e < -1e-9 * (Ay + fabs(c.ay * e)))) {
+            plo = fmin(plo, o1);
+            phi2 = fmax(phi2, o2);
+        }
     }
     const double Elo = Etr + (plo - psi), Ehi = Etr + (phi2 - psi);
     double sl, cl, sh, ch;

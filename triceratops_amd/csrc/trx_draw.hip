@@ -1,0 +1,330 @@
+// libtrx.so, part 2: the per-draw half of a scenario evidence as ONE kernel.
+//
+// Every lnZ_* of the reference (marginal_likelihoods.py:39-2362) turns N uniform draws into
+// per-draw stellar and orbital columns, a geometry mask and a companion prior through ~25 length-N
+// numpy temporaries (and, in lnZ_STP / lnZ_SEB, a Python loop over N for the limb-darkening
+// lookup): priors.py:16-383 (inverse-CDF samplers), funcs.py:54-140 (stellar and flux relations),
+// priors.py:580-1005 (bound-companion and background priors), marginal_likelihoods.py:101-123
+// (transit probability, collision and inclination masks).  draw_kernel does all of it for one
+// draw per thread, for any of the ten scenarios, from staged random numbers (torch's Philox
+// generator on the device, or numpy's global stream copied over in the reference's draw order),
+// and writes the SoA parameter block trx_lnl_batch consumes plus the mask(s) and lnprior.  The
+// host prepares nothing per draw: only the constants of the broken power laws, the spline
+// coefficients and the small lookup tables (trx_draw_args, include/trx.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/trx.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double kG = 6.6743e-08, kMsun = 1.988409870698051e+33, kRsun = 69570000000.0,
+                 kRearth = 637810000.0, kAu = 14959787070000.0;
+
+// ---- tables staged in LDS ------------------------------------------------------------------
+struct Tables {
+    double spl[TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES];
+    double cc_sep[TRX_DRAW_MAX_CC], cc_con[TRX_DRAW_MAX_CC];
+    double lut[2][TRX_DRAW_MAX_LUT];
+};
+
+// piecewise cubic: i = (number of knots <= v) - 1 clamped, ((c0 d + c1) d + c2) d + c3
+__device__ __forceinline__ double spline_eval(const double* s, double v)
+{
+    const int m = (int)s[0];
+    const double* x = s + 1;
+    int i = 0;
+    for (int k = 1; k < m; ++k) i += (x[k] <= v) ? 1 : 0;
+    const double d = v - x[i];
+    const double* c = x + TRX_DRAW_MAX_KNOTS;
+    return ((c[i] * d + c[TRX_DRAW_MAX_KNOTS + i]) * d + c[2 * TRX_DRAW_MAX_KNOTS + i]) * d +
+           c[3 * TRX_DRAW_MAX_KNOTS + i];
+}
+
+// funcs.stellar_relations (funcs.py:54-79)
+__device__ __forceinline__ void stellar_relations(const Tables& T, double M, double maxR, double maxT,
+                                                  double& R, double& Te)
+{
+    const bool hot = M > 0.63;
+    R = hot ? spline_eval(T.spl[TRX_SPL_R_HOT], M) : spline_eval(T.spl[TRX_SPL_R_COOL], M);
+    Te = hot ? spline_eval(T.spl[TRX_SPL_T_HOT], M) : spline_eval(T.spl[TRX_SPL_T_COOL], M);
+    if (M != M) { R = 0.0; Te = 0.0; }
+    if (R > maxR) R = maxR;
+    if (Te > maxT) Te = maxT;
+    R = (R < 0.1) ? 0.1 : R;          // NaN caps propagate like torch.clamp_min
+    Te = (Te < 2800.0) ? 2800.0 : Te;
+}
+
+// funcs.flux_relation (funcs.py:121-140): 10 ** spline(M)
+__device__ __forceinline__ double flux_rel(const Tables& T, int which, double M)
+{
+    return pow(10.0, spline_eval(T.spl[which], M));
+}
+
+// inverse CDF of a broken power law (priors.py:16-116, 168-383), constants from the host
+__device__ __forceinline__ double plaw_inv(const trx_power_law& L, double x)
+{
+    if (L.ones) return 1.0;
+    double out = x;
+    const double t0 = x / L.norm;
+    for (int j = 0; j < L.nseg; ++j) {
+        const bool sel = (j == 0) ? (x <= L.hi[j]) : (x > L.lo[j] && x <= L.hi[j]);
+        if (sel) {
+            double t = (t0 - L.cum[j]) * L.p1[j];
+            if (L.amp[j] != 0.0) t = t / L.amp[j];
+            out = pow(t + L.base[j], L.ip[j]);
+        }
+    }
+    return out;
+}
+
+// np.interp for increasing xp, end values held outside
+__device__ __forceinline__ double interp(const double* xp, const double* fp, int n, double x)
+{
+    if (n == 1) return fp[0];
+    if (x != x) return x;
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;               // xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double w = (x - xp[lo]) / (xp[lo + 1] - xp[lo]);
+    return fp[lo] + w * (fp[lo + 1] - fp[lo]);
+}
+
+// ln of the bound-companion rate (priors.py:580-984) at |delta_mag| = dm
+__device__ __forceinline__ double bound_rate(const trx_draw_args& a, const Tables& T, double dm, bool keep_close)
+{
+    const double seps = a.dist_pc * interp(T.cc_con, T.cc_sep, a.n_cc, dm);
+    const double s_au = seps * kAu;
+    const double lp = log10(pow(a.kepler_c * (s_au * s_au * s_au), 0.5) / 86400.0);
+    const double f1 = a.f1, f2 = a.f2, f3 = a.f3;
+    const double alpha = 0.018, dlogP = 0.7;
+    const double k = f2 - f1 - alpha * dlogP;
+    const double t2p = 0.5 * (lp - 1.0) * (2.0 * f1 + k * (lp - 1.0));
+    const double t3p = 0.5 * alpha * (lp * lp - 5.4 * lp + 6.8) + f2 * (lp - 2.0);
+    const double k4 = f3 - f2 - alpha * dlogP;
+    const double t4p = alpha * dlogP * (lp - 3.4) + f2 * (lp - 3.4) +
+                       k4 * (0.238095 * (lp * lp) - 0.952381 * lp + 0.485714);
+    const double t5p = f3 * (3.33333 - 17.3566 * exp(-0.3 * lp));
+    double f;
+    if (keep_close) {
+        f = (lp >= 8.0) ? (a.t2 + a.t3 + a.t4 + a.t5)
+          : (lp >= 5.5) ? (a.t2 + a.t3 + a.t4 + t5p)
+          : (lp >= 3.4) ? (a.t2 + a.t3 + t4p)
+          : (lp >= 2.0) ? (a.t2 + t3p)
+          : (lp >= 1.0) ? t2p : 0.0;
+    } else {
+        f = (lp >= 8.0) ? (a.t4 + a.t5) : (lp >= 5.5) ? (a.t4 + t5p) : (lp >= 3.4) ? t4p : 0.0;
+    }
+    if (lp != lp) f = 0.0;                // torch.where chain: NaN compares false everywhere
+    if (a.M_s < 1.0) {
+        f = 0.65 * f + 0.35 * f * a.M_s;
+        f = (f < 0.0) ? 0.0 : f;
+    }
+    return log(f);
+}
+
+__device__ __forceinline__ double ratio(double f) { return f / (1.0 - f); }
+
+__device__ __forceinline__ double sma(double M_tot, double P_days)
+{
+    const double ps = P_days * 86400.0;
+    return pow((kG * M_tot * kMsun) / (4.0 * kPi * kPi) * (ps * ps), 1.0 / 3.0);
+}
+
+// marginal_likelihoods.py:111-123: inc >= inc_min, inc_min = 90 where Ptra > 1 (vector path);
+// the per-draw loop skips such draws
+__device__ __forceinline__ bool transits(double Ptra, double inc, bool parallel)
+{
+    const bool ok = Ptra <= 1.0;
+    const double c = fmin(fmax(Ptra, -1.0), 1.0);
+    const double inc_min = ok ? acos(c) * 180.0 / kPi : 90.0;
+    const bool hit = inc >= inc_min;
+    return parallel ? hit : (hit && ok);
+}
+
+__global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
+{
+    __shared__ Tables T;
+    {
+        double* dst = reinterpret_cast<double*>(&T);
+        const int nspl = TRX_DRAW_N_SPLINES * TRX_DRAW_SPLINE_DOUBLES;
+        for (int i = threadIdx.x; i < nspl; i += blockDim.x) dst[i] = a.splines[i];
+        for (int i = threadIdx.x; i < a.n_cc; i += blockDim.x) { T.cc_sep[i] = a.cc_seps[i]; T.cc_con[i] = a.cc_cons[i]; }
+        for (int i = threadIdx.x; i < a.n_lut; i += blockDim.x) { T.lut[0][i] = a.lut[i]; T.lut[1][i] = a.lut[a.n_lut + i]; }
+    }
+    __syncthreads();
+    const long N = a.N;
+    const bool parallel = a.parallel != 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+        const double P = a.uP ? (a.P_lo + (a.P_hi - a.P_lo) * a.uP[i]) : a.P_lo;
+        // ---- unresolved companion (bound) or field star ----------------------------------
+        double frc = 0.0, qc = 1.0, mc = 0.0;
+        long k = 0;
+        if (a.comp == TRX_COMP_BOUND) {
+            qc = a.qc_in ? a.qc_in[i] : plaw_inv(a.law_qc, a.uQc[i]);
+            mc = qc * a.M_s;
+            const double f = flux_rel(T, TRX_SPL_F_TESS, mc);
+            frc = f / (f + a.f0_tess);
+        } else if (a.comp == TRX_COMP_FIELD) {
+            k = a.idx[i];
+            frc = a.f_fr[k];
+        }
+        // ---- host star ---------------------------------------------------------------------
+        double Mh = a.M_s, Rh = a.R_s, Th = a.Teff, u1 = a.u1, u2 = a.u2;
+        bool extra = true;
+        if (a.host == TRX_HOST_COMPANION) {
+            Mh = mc;
+            stellar_relations(T, mc, a.R_s, a.Teff, Rh, Th);
+            const double rm = Rh * kRsun;
+            const double logg = log10(kG * (mc * kMsun) / (rm * rm));
+            // rounded (Teff / 250 K, logg / 0.5 dex) lattice at the nearest Z
+            // (marginal_likelihoods.py:945-972; Teff cap 10000 K for STP, 13000 K for SEB :1181)
+            double ig = rint(logg / 0.5) * 0.5;
+            ig = fmin(fmax(ig, 3.5), 5.0);
+            double it = rint(Th / 250.0) * 250.0;
+            it = fmin(fmax(it, 3500.0), a.teff_cap);
+            double code = rint((it - 3500.0) / 250.0) * 4.0 + rint((ig - 3.5) / 0.5);
+            if (code != code) code = 0.0;
+            int ci = (int)code;
+            ci = ci < 0 ? 0 : (ci >= a.n_lut ? a.n_lut - 1 : ci);
+            u1 = T.lut[0][ci];
+            u2 = T.lut[1][ci];
+            if (u1 != u1) atomicOr(a.flag, 1);     // a cell the Claret grid lacks: the reference raises
+        } else if (a.host == TRX_HOST_FIELD) {
+            Mh = a.f_mass[k];
+            Rh = a.f_radius[k];
+            Th = a.f_teff[k];
+            u1 = a.f_u1[k];
+            u2 = a.f_u2[k];
+            extra = (a.f_logg[k] >= 3.5) && (Th <= 10000.0);      // marginal_likelihoods.py:1950, 2212
+        }
+        if (a.comp == TRX_COMP_BOUND) extra = extra && (qc != 0.0);
+
+        const double inc = acos(1.0 - a.uInc[i]) * 180.0 / kPi;              // priors.py:119-132
+        const double w = a.uW[i] * 360.0;                                   // :157-166
+        const double sinw = sin(w * kPi / 180.0);
+        double ecc, lnprior = 0.0, dm = 0.0;
+        bool dm_set = false;
+        double* col = a.cols + i;
+        if (a.planet) {
+            ecc = a.ecc_in[i];                                              // Beta(0.867, 3.03) draws
+            double rp;
+            if (a.flat) rp = a.uRp[i] * 19.5 + 0.5;
+            else rp = (Mh > 0.45) ? plaw_inv(a.law_rp_hi, a.uRp[i]) : plaw_inv(a.law_rp_lo, a.uRp[i]);
+            const double sm = sma(Mh, P);
+            const double size = rp * kRearth + Rh * kRsun;
+            const double Ptra = size / sm * ((1.0 + ecc * sinw) / (1.0 - ecc * ecc));
+            const bool coll = size > sm * (1.0 - ecc);
+            a.mask[i] = (transits(Ptra, inc, parallel) && !coll && extra) ? 1 : 0;
+            col[0 * N] = rp; col[1 * N] = P; col[2 * N] = inc; col[3 * N] = sm; col[4 * N] = Rh;
+            col[5 * N] = u1; col[6 * N] = u2; col[7 * N] = ecc; col[8 * N] = w; col[9 * N] = frc;
+            col[10 * N] = Mh;
+            // ---- prior: flux term of the companion / field star ---------------------------
+            if (a.prior == TRX_PRIOR_BOUND_TP) {
+                double fr = ratio(frc);
+                if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); fr = ratio(f / (f + a.f0_band)); }
+                dm = 2.5 * log10(fr);
+                dm_set = true;
+                lnprior = bound_rate(a, T, fabs(dm), false);
+            }
+        } else {
+            ecc = pow(a.uEcc[i], a.ecc_pow);                                // priors.py:146-155
+            const double q = plaw_inv(a.law_q, a.uQ[i]);
+            const double m = q * Mh;
+            double r, tdummy;
+            stellar_relations(T, m, Rh, Th, r, tdummy);
+            const double fm = flux_rel(T, TRX_SPL_F_TESS, m);
+            double fr = fm / (fm + a.f0_tess);
+            double fh_band_share = 0.0;
+            if (a.host == TRX_HOST_FIELD) {
+                // the background star sits at another distance: rescale the pair's flux share
+                const double fh = flux_rel(T, TRX_SPL_F_TESS, Mh);
+                fr = fr * (frc / (fh / (fh + a.f0_tess)));                  // marginal_likelihoods.py:2147-2159
+                if (a.use_cc) { const double fb = flux_rel(T, TRX_SPL_F_BAND, Mh); fh_band_share = fb / (fb + a.f0_band); }
+            }
+            const double mt = Mh + m;
+            const double sm = sma(mt, P), sm2 = sma(mt, 2.0 * P);
+            const double e_corr = (1.0 + ecc * sinw) / (1.0 - ecc * ecc);
+            const double size = r * kRsun + Rh * kRsun;
+            const double Ptra = size / sm * e_corr, Ptra2 = size / sm2 * e_corr;
+            const bool coll = size > sm * (1.0 - ecc);
+            const bool coll2 = (2.0 * Rh * kRsun) > sm2 * (1.0 - ecc);
+            bool m1 = transits(Ptra, inc, parallel) && !coll && (q < 0.95) && extra;
+            bool m2 = transits(Ptra2, inc, parallel) && !coll2 && (q >= 0.95) && extra;
+            if (!parallel) m2 = m2 && (Ptra <= 1.0);      // the loop `continue`s before the twin test
+            a.mask[i] = m1 ? 1 : 0;
+            a.mask_twin[i] = m2 ? 1 : 0;
+            col[0 * N] = r; col[1 * N] = fr; col[2 * N] = P; col[3 * N] = inc; col[4 * N] = sm;
+            col[5 * N] = Rh; col[6 * N] = u1; col[7 * N] = u2; col[8 * N] = ecc; col[9 * N] = w;
+            col[10 * N] = frc; col[11 * N] = sm2; col[12 * N] = m; col[13 * N] = Mh;
+            if (a.prior == TRX_PRIOR_BOUND_EB) {
+                double term = ratio(frc);
+                if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); term = ratio(f / (f + a.f0_band)); }
+                if (a.host == TRX_HOST_COMPANION) {
+                    // lnZ_SEB: the companion AND its EB count (marginal_likelihoods.py:1202-1205)
+                    double fe = fr;
+                    if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, m); fe = f / (f + a.f0_band); }
+                    term = term + ratio(fe);
+                }
+                dm = 2.5 * log10(term);
+                dm_set = true;
+                lnprior = bound_rate(a, T, fabs(dm), true);
+            } else if (a.prior == TRX_PRIOR_FIELD && a.host == TRX_HOST_FIELD) {
+                // lnZ_BEB: background star + its EB (marginal_likelihoods.py:2161-2208)
+                double term;
+                if (a.use_cc) {
+                    const double frc_cc = a.f_frband[k];
+                    const double fmb = flux_rel(T, TRX_SPL_F_BAND, m);
+                    const double fr_cc = (fmb / (fmb + a.f0_band)) * (frc_cc / fh_band_share);
+                    term = ratio(frc_cc) + ratio(fr_cc);
+                } else {
+                    term = ratio(frc) + ratio(fr);
+                }
+                dm = 2.5 * log10(term);
+                dm_set = true;
+            }
+        }
+        if (a.prior == TRX_PRIOR_FIELD) {
+            if (!dm_set) {
+                // D scenarios and lnZ_BTP: the field star alone
+                dm = a.use_cc ? a.f_delta[k] : 2.5 * log10(ratio(frc));
+            }
+            if (a.use_cc) {
+                const double s = interp(T.cc_con, T.cc_sep, a.n_cc, fabs(dm));
+                lnprior = log(a.bg_amp * (s * s));
+            } else {
+                lnprior = a.bg_const;
+            }
+        }
+        if (a.prior == TRX_PRIOR_BOUND_TP || a.prior == TRX_PRIOR_BOUND_EB || a.prior == TRX_PRIOR_FIELD) {
+            lnprior = (lnprior > 0.0) ? 0.0 : lnprior;     // clamp_max: NaN stays NaN
+            if (dm > 0.0) lnprior = -INFINITY;
+        }
+        if (a.lnprior) a.lnprior[i] = lnprior;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t trx_draw_args_size(void) { return sizeof(trx_draw_args); }
+
+extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
+{
+    if (!args || args->N < 0) return TRX_ERR_ARG;
+    if (args->N == 0) return TRX_OK;
+    const trx_draw_args& a = *args;
+    if (!a.cols || !a.mask || !a.uInc || !a.uW || !a.splines || !a.flag) return TRX_ERR_ARG;
+    if (a.planet ? (!a.ecc_in || !a.uRp) : (!a.uEcc || !a.uQ || !a.mask_twin)) return TRX_ERR_ARG;
+    if (a.comp == TRX_COMP_BOUND && !a.qc_in && !a.uQc) return TRX_ERR_ARG;
+    if ((a.comp == TRX_COMP_FIELD || a.host == TRX_HOST_FIELD) && (!a.idx || !a.f_fr)) return TRX_ERR_ARG;
+    if (a.n_cc < 0 || a.n_cc > TRX_DRAW_MAX_CC || a.n_lut < 0 || a.n_lut > TRX_DRAW_MAX_LUT) return TRX_ERR_ARG;
+    long blocks = (a.N + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
+}

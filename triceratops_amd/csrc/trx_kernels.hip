@@ -160,7 +160,8 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     // takes batch (v % 8) * ceil(nbatch / 8) + v / 8: each XCD works through one contiguous
     // eighth of the rows and its L2 sees each parameter line once (FETCH_SIZE 34 -> 7 MB).
 #ifdef TRX_PHASE_TIMERS
-    unsigned long long tm[5] = {0, 0, 0, 0, 0};
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TRX_TICK(t_all);
 #endif
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -365,37 +366,64 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
         __syncthreads();
     }
 #ifdef TRX_PHASE_TIMERS
+    TRX_TOCK(7, t_all);
     if (lane == 0) {
         tm[4] -= tm[2] + tm[3];              // "rest" brackets the staged loop
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
     }
 #endif
 }
 
 // ---------------------------------------------------------------------------------------
 // cells_kernel: the same model for SHORT light curves (the reference's real operating point is
-// 100-200 binned points, examples/TSCIII_tutorial.ipynb cell 4).  With one row at a time a wave
-// of rows_kernel leaves the lanes past n_time idle (100 points: 64 + 36) and its per-row prologue
-// runs on B of the 64 lanes (a third of the wave's cycles at 100 points,
-// profiles/r01_r_phase_cycles.txt).  Here a wave takes a batch of B <= 22 rows (about 2048
-// cells) and
-//   * the prologue runs with lanes = rows (B lanes busy instead of 1-4), the secondary-eclipse
-//     scan with lanes = (row, point) as before;
-//   * the (row, time) cells of the whole batch form ONE index space, cell = r * n_time + j, which
-//     the lanes walk 64 at a time across row boundaries: every chunk but the last is full;
-//   * a lane's row constants are read from the row blocks in LDS where they are used (two
-//     neighbouring rows per chunk at most for n_time >= 64: broadcast reads), since cells of
-//     different rows share a wave they cannot ride in SGPRs;
-//   * chi^2 is reduced per chunk by a segmented shuffle reduction keyed on the row (fixed order,
-//     deterministic) into one LDS accumulator per row; grid mode stores cell = output offset,
-//     fully coalesced.
-// Plan / stage A / stage B / stage C are those of rows_kernel (same device functions, same node
-// tables), so a cell's model value is bit-identical between the two kernels; only the order of the
-// chi^2 sum differs.
+// 100-200 binned points, examples/TSCIII_tutorial.ipynb cell 4).  rows_kernel loses lanes there
+// three ways: the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at
+// 100 points, profiles/r01_r_phase_cycles.txt), a 100-point row fills 64 + 36 lanes, and -- the
+// largest loss -- a 64-cell chunk of a coarse time grid spans 0.3 d, so in- and out-of-transit
+// cells share every chunk and the lanes of the out-of-window cells idle through the plan and the
+// orbit stage (a 2000-point chunk spans 0.016 d and is all in or all out).  Here a wave takes a
+// batch of B <= 22 rows and
+//   * the prologue runs with lanes = rows (B lanes busy), the secondary-eclipse scan with lanes =
+//     (row, point) as before;
+//   * the (row, time) cells of the batch form ONE index space, cell = r * n_time + j, walked in
+//     windows of 1024 cells: pass 1 applies the transit-window test to 64 cells at a time across
+//     row boundaries, settles the out-of-window cells (model exactly 1) and files the in-window
+//     ones, in order, in a list in LDS; pass 2 runs plan / stage A / stage B / stage C of
+//     rows_kernel over that list, 64 in-window cells at a time: full lanes in every stage;
+//   * a lane's row constants come from the row blocks in LDS (cells of different rows share a
+//     wave, so they cannot ride in SGPRs);
+//   * chi^2 of a row = chi^2 of the flat model (every cell exactly 1: one number per launch, summed
+//     in rows_kernel's order) + the corrections ((f-m)^2 - (f-1)^2)/sigma^2 of its in-window
+//     cells, reduced per chunk by a segmented shuffle reduction keyed on the row (fixed order,
+//     deterministic) into one LDS accumulator per row.  The window pass therefore touches no
+//     flux, and draws whose model is flat over the data tie EXACTLY (the reference's argsort
+//     orders such ties in the best-fit table); grid mode stores cell = output offset.
+// The device functions and node tables are those of rows_kernel; the two kernels agree to
+// rounding in the model (the compiler contracts the inlined arithmetic differently) and to
+// summation order in chi^2.
 #ifndef TRX_CELLS_WAVES_PER_EU
-#define TRX_CELLS_WAVES_PER_EU 4
+#define TRX_CELLS_WAVES_PER_EU 3
 #endif
-constexpr int kCellsMaxRows = 22;     // B * (18 + 25) doubles of phase 1-3 arrays fit the slab
+#ifndef TRX_CELLS_NODES_PER_PASS
+#define TRX_CELLS_NODES_PER_PASS 8
+#endif
+constexpr int kCellsMaxRows = 22;      // B * (18 + 25) doubles of phase 1-3 arrays fit the slab
+constexpr int kCellsWindow = 1024;     // cells per window pass (in-window list: 2 KB of LDS)
+constexpr int kCellsNodesPerPass = TRX_CELLS_NODES_PER_PASS;
+
+// first lane of every run of equal keys receives the run's sum (runs are contiguous)
+__device__ __forceinline__ double segment_sum(double v, int key, int lane, bool& head)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ov = __shfl_down(v, o, 64);
+        const int ok = __shfl_down(key, o, 64);
+        if (lane + o < 64 && ok == key) v += ov;
+    }
+    const int prev = __shfl_up(key, 1, 64);
+    head = (lane == 0) || (prev != key);
+    return v;
+}
 
 template <int MODE, bool STEP, bool FP32>
 __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
@@ -404,12 +432,14 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     const int B = a.B;
     RowC* rows = reinterpret_cast<RowC*>(lds);
     double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 per row
-    double* tier_xw = hacc + B;
+    double* hmout = hacc + B;                                         // [B] diluted model of an unocculted cell: 1, or NaN
+    double* tier_xw = hmout + B;
     const int SB = a.SB;
     const int cap = 64 * SB;
     double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
     unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
     unsigned short* rowof = items + cap;                              // [64] row of each lane's cell
+    unsigned short* winlist = rowof + 64;                             // [kCellsWindow] in-window cells
     RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // phases 1-3 only (overlay)
     double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
     if (a.use_tiers && threadIdx.x == 0) {
@@ -426,6 +456,21 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     const long n = a.n;
     const double s2 = a.s2;
     const int n_time = a.n_time;
+    const float inv_nt = 1.0f / (float)n_time;
+#ifdef TRX_PHASE_TIMERS
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TRX_TICK(t_all);
+#endif
+    // chi^2 of the flat model (every cell exactly 1), in ONE fixed order -- that of rows_kernel
+    double flat_sum = 0.0;
+    if (MODE == MODE_LNL) {
+        double acc = 0.0;
+        for (int j = lane; j < n_time; j += 64) {
+            const double d = a.flux[j] - 1.0;
+            acc += (d * d) / s2;
+        }
+        flat_sum = wave_sum(acc);
+    }
 
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -434,6 +479,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         const long base = batch * B;
         const int nb = (int)((n - base < B) ? (n - base) : B);
         double ysec = 0.0;
+        TRX_TICK(t_pro);
 
         // ---- phase 1: per-row constants, lanes = rows ----------------------------------
         if (lane < nb) {
@@ -489,6 +535,11 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
             c.excl = 0.0;
             hacc[lane] = 0.0;
+            // an unocculted cell: 1 diluted is 1 (or NaN for a degenerate flux ratio)
+            double m1 = 1.0;
+            if (eblike) m1 = (m1 + c.xeb) / (1.0 + c.xeb);
+            if (a.model != TRX_MODEL_RAW) m1 = (m1 + c.fdil) / (1.0 + c.fdil);
+            hmout[lane] = m1;
         }
         __syncthreads();
 
@@ -521,106 +572,163 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             __syncthreads();
         }
 
-        // ---- phase 4: the cells of the batch, 64 at a time across row boundaries ---------
+        // ---- phase 4: the cells of the batch ---------------------------------------------
+        TRX_TOCK(0, t_pro);
         const int ncell = nb * n_time;
-        int r = 0, j = lane;
-        while (j >= n_time && r < nb) { j -= n_time; ++r; }
-        for (int c0 = 0; c0 < ncell; c0 += 64) {
-            const bool valid = (c0 + lane) < ncell;
-            const int rr = valid ? r : (nb - 1);
-            const RowC& c = rows[rr];
-            const double t = valid ? a.time[j] : 0.0;
-            CellPlan pl;
-            if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
-            rowof[lane] = (unsigned short)rr;
-            const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
-            const double* ws = xs + kTiers * kTierMaxNodes;
-            double fsum = 0.0;
-            for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
-                int n_in = 0, n_lb = 0, ns = 0;
-                // stage A
-                const double ck = c.k, opp = 1.0 + ck, opp2 = opp * opp, omk = 1.0 - ck;
-                for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
-                    const int s = s0 + si + 1;
-                    int cls = 0;
-                    double vz = 1.0;
-                    if (s <= pl.n) {
-                        const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
-                        double Y;
-                        const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
-                        if (Y >= 0.0 && z2 < opp2) {
-                            vz = sqrt_fast(z2);
-                            cls = (ck < 1.0 && vz <= omk) ? 1 : 2;
-                        } else if (z2 != z2) {
-                            vz = z2;
+        for (int win0 = 0; win0 < ncell; win0 += kCellsWindow) {
+            const int win1 = (win0 + kCellsWindow < ncell) ? (win0 + kCellsWindow) : ncell;
+            // pass 1: window test, 64 cells at a time across row boundaries
+            TRX_TICK(t_p1);
+            int nw = 0;
+            for (int c0 = win0; c0 < win1; c0 += 64) {
+                const int cell = c0 + lane;
+                const bool valid = cell < win1;
+                int rr = valid ? (int)(((float)cell + 0.5f) * inv_nt) : (nb - 1);
+                rr = rr < nb ? rr : nb - 1;
+                const int j = valid ? (cell - rr * n_time) : 0;
+                bool inw = false;
+                if (valid) {
+                    const RowC& c = rows[rr];
+                    const double phase = c.nmot * (a.time[j] - c.t0);
+                    const double dMc = reduce_2pi(phase);
+                    const double slack = 1e-15 * fabs(phase);
+                    inw = in_window(c.wlo - slack, c.whi + slack, dMc);
+                    // no occultation anywhere in the exposure: the model is 1, diluted
+                    if (MODE == MODE_GRID && !inw)
+                        a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
+                }
+                const unsigned long long mw = __ballot(inw);
+                if (inw) winlist[nw + lanes_below(mw)] = (unsigned short)(cell - win0);
+                nw += __popcll(mw);
+            }
+            __syncthreads();
+            TRX_TOCK(1, t_p1);
+            // pass 2: the in-window cells, 64 at a time.  A cell next to a limb contact evaluates
+            // all S sub-exposures, the others 3-9 nodes; the node loop of stage A runs to the
+            // largest count in the wave, and on a coarse time grid nearly every 64-cell chunk would
+            // hold a contact cell.  So the first sweep only files those cells (back into the list,
+            // behind the read cursor) and a second sweep takes them 64 at a time.
+            int nheavy = 0;
+            for (int sweep = 0; sweep < 2; ++sweep) {
+            const int count = sweep ? nheavy : nw;
+            for (int w0 = 0; w0 < count; w0 += 64) {
+                TRX_TICK(t_plan);
+                const bool listed = (w0 + lane) < count;
+                bool valid = listed;
+                const int rel = (int)winlist[listed ? (w0 + lane) : (count - 1)];
+                const int cell = win0 + rel;
+                int rr = (int)(((float)cell + 0.5f) * inv_nt);
+                rr = rr < nb ? rr : nb - 1;
+                const int j = cell - rr * n_time;
+#ifdef TRX_CELLS_ROW_BY_REF
+                const RowC& c = rows[rr];
+#else
+                const RowC c = rows[rr];
+#endif
+                const double t = a.time[j];
+                CellPlan pl;
+                if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                if (sweep == 0 && a.use_tiers) {
+                    const bool heavy = valid && pl.tier < 0 && pl.n > 0;
+                    const unsigned long long mh = __ballot(heavy);
+                    if (heavy) { winlist[nheavy + lanes_below(mh)] = (unsigned short)rel; pl.n = 0; valid = false; }
+                    nheavy += __popcll(mh);
+                }
+                rowof[lane] = (unsigned short)rr;
+                TRX_TOCK(2, t_plan);
+                TRX_TICK(t_rest);
+                const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
+                const double* ws = xs + kTiers * kTierMaxNodes;
+                const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
+                double fsum = 0.0;
+                for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
+                    int n_in = 0, n_lb = 0, ns = 0;
+                    TRX_TICK(t_a);
+                    // stage A
+                    for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
+                        const int s = s0 + si + 1;
+                        int cls = 0;
+                        double vz = 1.0;
+                        if (s <= pl.n) {
+                            const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
+                            double Y;
+                            const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
+                            if (Y >= 0.0 && z2 < opp2) {
+                                vz = sqrt_fast(z2);
+                                cls = (c.k < 1.0 && vz <= omk) ? 1 : 2;
+                            } else if (z2 != z2) {
+                                vz = z2;
+                            }
+                        }
+                        const int idx = si * 64 + lane;
+                        zbuf[idx] = vz;
+                        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+                        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
+                        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
+                        n_in += __popcll(m1);
+                        n_lb += __popcll(m2);
+                        ns = si + 1;
+                    }
+                    __syncthreads();
+                    TRX_TOCK(3, t_a);
+                    TRX_TICK(t_b);
+                    // stage B: an item's row comes with its lane of origin
+                    for (int i = lane; i < n_in + n_lb; i += 64) {
+                        const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
+                        const RowC& ic = rows[rowof[idx & 63]];
+                        const Limb L{ic.cle, ic.cld, ic.ced};
+                        zbuf[idx] = disc_flux<FP32>(zbuf[idx], ic.k, L);
+                    }
+                    __syncthreads();
+                    TRX_TOCK(4, t_b);
+                    // stage C
+                    for (int si = 0; si < ns; ++si) {
+                        const int s = s0 + si + 1;
+                        if (s <= pl.n) {
+                            const double f = zbuf[si * 64 + lane];
+                            fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
                         }
                     }
-                    const int idx = si * 64 + lane;
-                    zbuf[idx] = vz;
-                    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-                    if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
-                    if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
-                    n_in += __popcll(m1);
-                    n_lb += __popcll(m2);
-                    ns = si + 1;
+                    __syncthreads();
                 }
-                __syncthreads();
-                // stage B: an item's row comes with its lane of origin
-                for (int i = lane; i < n_in + n_lb; i += 64) {
-                    const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
-                    const RowC& ic = rows[rowof[idx & 63]];
-                    const Limb L{ic.cle, ic.cld, ic.ced};
-                    zbuf[idx] = disc_flux<FP32>(zbuf[idx], ic.k, L);
-                }
-                __syncthreads();
-                // stage C
-                for (int si = 0; si < ns; ++si) {
-                    const int s = s0 + si + 1;
-                    if (s <= pl.n) {
-                        const double f = zbuf[si * 64 + lane];
-                        fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
+                double contrib = 0.0;
+                if (valid) {
+                    double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
+                    if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
+                    if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
+                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
+                    if (MODE == MODE_GRID) {
+                        a.out[(size_t)base * n_time + cell] = m;
+                    } else {
+                        // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1          :486, :537, :586
+                        contrib = ((1.0 - m) * ((a.flux[j] - m) + (a.flux[j] - 1.0))) / s2;
                     }
                 }
-                __syncthreads();
-            }
-            double contrib = 0.0;
-            if (valid) {
-                double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
-                if (eblike) { const double xe = c.xeb; m = (m + xe) / (1.0 + xe); }
-                if (a.model != TRX_MODEL_RAW) { const double fd = c.fdil; m = (m + fd) / (1.0 + fd); }
-                if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
-                if (MODE == MODE_GRID) {
-                    a.out[(size_t)base * n_time + c0 + lane] = m;
-                } else {
-                    const double d = a.flux[j] - m;
-                    contrib = (d * d) / s2;                                 // :486, :537, :586
+                if (MODE == MODE_LNL) {
+                    // a deferred cell stays in its row's run (with a zero) so that runs stay contiguous
+                    bool head;
+                    const double ssum = segment_sum(contrib, listed ? rr : -1, lane, head);
+                    if (listed && head) hacc[rr] += ssum;
                 }
+                TRX_TOCK(5, t_rest);
             }
-            if (MODE == MODE_LNL) {
-                // segmented reduction keyed on the row: after the doubling steps the first lane of
-                // every row segment holds that segment's sum (segments are contiguous)
-                const int key = valid ? rr : -1;
-                double vsum = contrib;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const double ov = __shfl_down(vsum, o, 64);
-                    const int ok = __shfl_down(key, o, 64);
-                    if (lane + o < 64 && ok == key) vsum += ov;
-                }
-                const int prev = __shfl_up(key, 1, 64);
-                if (valid && (lane == 0 || prev != key)) hacc[rr] += vsum;
             }
-            j += 64;
-            while (j >= n_time && r < nb) { j -= n_time; ++r; }
+            __syncthreads();
         }
-        __syncthreads();
         if (MODE == MODE_LNL && lane < nb) {
-            double h = 0.5 * hacc[lane];
+            double h = (hmout[lane] == 1.0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
             if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
             a.out[base + lane] = h;
         }
         __syncthreads();
     }
+#ifdef TRX_PHASE_TIMERS
+    TRX_TOCK(7, t_all);
+    if (lane == 0) {
+        tm[5] -= tm[3] + tm[4];              // "rest" brackets the staged loop
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -721,7 +829,11 @@ __device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double 
 #define TRX_LME_LOADS 2
 #endif
 #ifndef TRX_LME_PREFETCH
-#define TRX_LME_PREFETCH 1
+#define TRX_LME_PREFETCH 0
+#endif
+// slots of the per-thread queue of terms that can still count
+#ifndef TRX_LME_QUEUE
+#define TRX_LME_QUEUE 8
 #endif
 
 __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
@@ -735,8 +847,8 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
     const long stride = (long)gridDim.x * blockDim.x;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {
-        // 16 B per lane per load, TRX_LME_LOADS independent loads per trip; the next trip's loads
-        // are in flight while this trip is folded (and while the queues are flushed).
+        // 16 B per lane per load, TRX_LME_LOADS independent loads per trip (issuing the next
+        // trip's loads before the fold, TRX_LME_PREFETCH, measured slower: profiles/r02_lme_variants.txt).
         // The fold itself leans on IEEE max: fmax ignores a NaN operand, so NaN never reaches the
         // running maximum, `x - max > -80` is false for NaN and for -inf, and a +inf drives the
         // maximum to +inf (detected once, after the loop) -- no per-value inf / NaN tests.
@@ -747,12 +859,12 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         // exps run over the queues only when one of them fills.  The parked values are raw, so a
         // later, larger maximum needs no bookkeeping.
         constexpr int kL = TRX_LME_LOADS, kV = 2 * kL;
-        constexpr int kQ = (kV > 4) ? 12 : 8;
-        __shared__ double qbuf[kQ][256];
-        int qc = 0;
         const long nv = n >> 1;
         const dvec2* src = reinterpret_cast<const dvec2*>(h ? h : logw);
         const dvec2* pri = reinterpret_cast<const dvec2*>(lnprior);
+        constexpr int kQ = (kV > 4 && TRX_LME_QUEUE < 12) ? 12 : TRX_LME_QUEUE;
+        __shared__ double qbuf[kQ][256];
+        int qc = 0;
         auto flush = [&]() {
             for (int i = 0; i < kQ; ++i) {
                 if (i < qc) {
@@ -1031,7 +1143,7 @@ int pick_rows_per_wave(int n_time, long n)
 }
 
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{1024};
+std::atomic<int> g_cells_below{320};
 
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st)
@@ -1042,7 +1154,23 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
     B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
     const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
     if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
-    while (B > 1 && a.n / B < 4096) B = (B + 1) / 2;          // few rows: fill the chip first
+    if (forced <= 0) {
+        // Batches of equal size run in rounds over the wave slots of the chip (256 CUs x 4 SIMDs x
+        // TRX_CELLS_WAVES_PER_EU): 4762 batches of 21 rows took two rounds, 1.5x the time of an even
+        // fill.  Larger batches pack better (prologue lanes, full chunks, a fuller deferred sweep),
+        // so take the size with the best (fill of the last round) x (packing) estimate.
+        const double slots = 256.0 * 4 * TRX_CELLS_WAVES_PER_EU;
+        double best = -1.0;
+        int bestB = B;
+        for (int b = B; b >= 1; --b) {
+            const double rounds = (double)((a.n + b - 1) / b) / slots;
+            const double fill = rounds / ceil(rounds);
+            const double pack = 1.0 - 1.5 / (b + 1.5);
+            const double score = (rounds >= 1.0 ? fill : rounds) * pack;
+            if (score > best) { best = score; bestB = b; }
+        }
+        B = bestB;
+    }
     a.B = B;
     a.s2 = a.sigma * a.sigma;
     a.dS = (double)a.S;
@@ -1052,11 +1180,13 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
     const long want_grid = 8 * ((a.nbatch + 7) / 8);
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
-    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short)) + 64 * sizeof(unsigned short);
+    a.SB = a.S < kCellsNodesPerPass ? a.S : kCellsNodesPerPass;
+    // zbuf + items + rowof + winlist; the phase 1-3 arrays overlay zbuf (+ what follows it)
+    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short))
+                + (64 + kCellsWindow) * sizeof(unsigned short);
     const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
     if (slab < overlay) slab = overlay;
-    const size_t lds = ((size_t)a.B * (kRowDoubles + 1) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
+    const size_t lds = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);

@@ -70,6 +70,9 @@ class NumpyStreamRng:
 
 
 RNG = TorchRng()
+# True: the lnZ_* of the "device" / "numpy-device" sampling modes run on the fused per-draw kernel
+# (fused.py); False: on the elementwise torch expression below (same chain, ~360 launches)
+FUSED = True
 
 
 # ---------------------------------------------------------------------------------------

@@ -1,0 +1,549 @@
+"""The ten lnZ_* of calc_probs on the fused per-draw kernel (trx_draw_scenario, include/trx.h).
+
+device_pipeline.py expresses a scenario as ~350 elementwise torch launches (samplers, splines,
+priors, masks); here the whole draw -> derive -> mask -> prior chain of a scenario is ONE HIP
+kernel over the N draws, fed with staged random numbers in the reference's draw order (the RNG
+classes of device_pipeline: torch's device generator, or numpy's global stream), followed by the
+compaction (nonzero + one index_select), the likelihood / log-mean-exp kernels and the best-fit
+table.  About 15 launches per scenario branch instead of ~360.
+
+Host work per call: the constants of the broken power laws (priors.py:16-383), the Moe &
+Di Stefano rate constants (priors.py:601-660) and table pointers -- nothing per draw.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, funcs
+from . import device_pipeline as dp
+from . import marginal_likelihoods as ml
+from ._lib import FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, MODEL_EB, MODEL_EB_TWIN, MODEL_TP
+from .constants import G, Msun, Rsun, pi
+
+F64 = torch.float64
+N_BEST = ml.N_BEST
+HOST_TARGET, HOST_COMPANION, HOST_FIELD = 0, 1, 2
+COMP_NONE, COMP_BOUND, COMP_FIELD = 0, 1, 2
+PRIOR_NONE, PRIOR_BOUND_TP, PRIOR_BOUND_EB, PRIOR_FIELD = 0, 1, 2, 3
+MAX_KNOTS, N_SPLINES, MAX_CC, MAX_LUT = 16, 6, 256, 160
+SPLINE_DOUBLES = 1 + 5 * MAX_KNOTS
+
+_d3 = ctypes.c_double * 3
+_vp = ctypes.c_void_p
+
+
+class PowerLaw(ctypes.Structure):
+    _fields_ = [("nseg", ctypes.c_int), ("ones", ctypes.c_int), ("norm", ctypes.c_double),
+                ("hi", _d3), ("lo", _d3), ("cum", _d3), ("p1", _d3), ("amp", _d3), ("base", _d3),
+                ("ip", _d3)]
+
+
+class DrawArgs(ctypes.Structure):
+    _fields_ = ([("N", ctypes.c_long)]
+                + [(k, ctypes.c_int) for k in ("planet", "host", "comp", "prior", "parallel", "flat",
+                                               "use_cc", "n_cc", "n_lut")]
+                + [(k, ctypes.c_double) for k in ("P_lo", "P_hi", "M_s", "R_s", "Teff", "u1", "u2",
+                                                  "ecc_pow", "teff_cap", "f0_tess", "f0_band",
+                                                  "dist_pc", "kepler_c", "f1", "f2", "f3", "t2", "t3",
+                                                  "t4", "t5", "bg_const", "bg_amp")]
+                + [(k, PowerLaw) for k in ("law_rp_hi", "law_rp_lo", "law_q", "law_qc")]
+                + [(k, _vp) for k in ("splines", "cc_seps", "cc_cons", "lut", "f_mass", "f_radius",
+                                      "f_teff", "f_logg", "f_fr", "f_delta", "f_frband", "f_u1", "f_u2",
+                                      "uP", "uQc", "uRp", "uInc", "uQ", "uEcc", "uW", "ecc_in", "qc_in",
+                                      "idx", "cols", "mask", "mask_twin", "lnprior", "flag")])
+
+
+_bound = False
+
+
+def _fn():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        L.trx_draw_scenario.restype = ctypes.c_int
+        L.trx_draw_scenario.argtypes = [ctypes.POINTER(DrawArgs), _vp]
+        L.trx_draw_args_size.restype = ctypes.c_size_t
+        if L.trx_draw_args_size() != ctypes.sizeof(DrawArgs):
+            raise _lib.TrxError("trx_draw_args layout mismatch: library %d bytes, binding %d"
+                                % (L.trx_draw_args_size(), ctypes.sizeof(DrawArgs)))
+        _bound = True
+    return L.trx_draw_scenario
+
+
+# ---------------------------------------------------------------------------------------
+# host constants
+def _law(edges, powers, amps_int, amps_inv):
+    """constants of device_pipeline._invert, same Python-float arithmetic"""
+    law = PowerLaw()
+    ints = []
+    for j, p in enumerate(powers):
+        span = edges[j + 1] ** (p + 1) - edges[j] ** (p + 1)
+        ints.append(span / (p + 1) if amps_int[j] is None else amps_int[j] * span / (p + 1))
+    norm = 1 / sum(ints)
+    law.nseg, law.ones, law.norm = len(powers), 0, norm
+    cum = 0.0
+    for j, p in enumerate(powers):
+        upper = cum + ints[j]
+        law.lo[j], law.hi[j], law.cum[j] = norm * cum, norm * upper, cum
+        law.p1[j] = p + 1
+        law.amp[j] = 0.0 if amps_inv[j] is None else amps_inv[j]
+        law.base[j] = edges[j] ** (p + 1)
+        law.ip[j] = 1 / (p + 1)
+        cum = upper
+    return law
+
+
+def _rp_laws():
+    edges = (0.5, 3.0, 6.0, 20.0)
+    out = []
+    for powers in ((0.0, -4.0, -0.5), (0.0, -7.0, -0.5)):
+        p1, p2, p3 = powers
+        A1 = edges[1] ** p1 / edges[1] ** p2
+        A2 = edges[2] ** p2 / edges[2] ** p3
+        out.append(_law(edges, powers, (None, A1, A2 * A1), (None, A1, A1 * A2)))
+    return out
+
+
+def _q_law(M_s, p_hi, F_twin):
+    """device_pipeline._mass_ratio (priors.py:168-383)"""
+    if M_s <= 0.1:
+        law = PowerLaw()
+        law.ones = 1
+        return law
+    p1, p2 = 0.3, p_hi
+
+    def twin_amp(lo):
+        return (1 + F_twin / (1 - F_twin) * ((1.0 - lo ** (p2 + 1)) / (p2 + 1))
+                / ((1.0 - 0.95 ** (p2 + 1)) / (p2 + 1)))
+
+    if M_s >= 0.3:
+        q_min = 0.1 if M_s >= 1.0 else 0.1 / M_s
+        A1 = (0.3 ** p1) / (0.3 ** p2)
+        A2 = twin_amp(0.3)
+        return _law((q_min, 0.3, 0.95, 1.0), (p1, p2, p2), (None, A1, A2 * A1), (None, A1, A1 * A2))
+    q_min = 0.1 / M_s
+    A2 = twin_amp(q_min)
+    return _law((q_min, 0.95, 1.0), (p2, p2), (None, A2), (None, A2))
+
+
+_RP = None
+_tab_cache = {}
+
+
+def _spline_table(device, band):
+    """the six piecewise cubics the kernel stages in LDS, [6][1 + 5 * 16] doubles"""
+    key = (device.type, device.index, band)
+    if key not in _tab_cache:
+        from scipy.interpolate import PPoly
+        tab = np.zeros((N_SPLINES, SPLINE_DOUBLES))
+        fb = funcs._flux_spl[band if band in funcs._flux_spl else "TESS"]
+        for i, spl in enumerate((funcs._spl["R_hot"], funcs._spl["T_hot"], funcs._spl["R_cool"],
+                                 funcs._spl["T_cool"], funcs._flux_spl["TESS"], fb)):
+            pp = PPoly.from_spline(spl._eval_args)
+            keep = np.diff(pp.x) > 0
+            x, c = pp.x[:-1][keep], pp.c[:, keep]
+            m = x.size
+            assert m <= MAX_KNOTS
+            tab[i, 0] = m
+            tab[i, 1:1 + m] = x
+            for r in range(4):
+                tab[i, 1 + MAX_KNOTS * (r + 1):1 + MAX_KNOTS * (r + 1) + m] = c[r]
+        _tab_cache[key] = _lib.dev(tab.ravel(), device)
+    return _tab_cache[key]
+
+
+def _flux0(M_s, band):
+    """flux_relation(M_s) as device_pipeline._flux_share forms it"""
+    return float(10 ** funcs._flux_spl[band](np.array([M_s]))[0])
+
+
+_cc_cache = {}
+
+
+def _contrast_curve(cc_file, device):
+    key = (cc_file, device.type, device.index)
+    if key not in _cc_cache:
+        if cc_file is None:
+            seps, cons = np.array([2.2]), np.array([1.0])
+        else:
+            seps, cons = funcs.file_to_contrast_curve(cc_file)
+        if cons.size > MAX_CC:
+            raise ValueError("contrast curve has more than %d points" % MAX_CC)
+        _cc_cache[key] = (_lib.dev(seps, device), _lib.dev(cons, device), int(cons.size))
+    return _cc_cache[key]
+
+
+_lut_cache = {}
+_field_cache = {}      # TRILEGAL populations on the device, by (file, target magnitudes, mission, ldc, device)
+
+
+def _companion_lut(mission, Z, teff_cap, device):
+    key = (mission, float(Z), teff_cap, device.type, device.index)
+    if key not in _lut_cache:
+        tab = ml._ldc(mission)
+        atZ = tab.Zs == tab.Zs[np.abs(tab.Zs - Z).argmin()]
+        nT = int((teff_cap - 3500) // 250) + 1
+        lut = np.full((2, nT * 4), np.nan)
+        for tz, gz, a1, a2 in zip(tab.Teffs[atZ], tab.loggs[atZ], tab.u1s[atZ], tab.u2s[atZ]):
+            it, ig = (tz - 3500) / 250, (gz - 3.5) / 0.5
+            if 0 <= it < nT and it == int(it) and 0 <= ig < 4 and ig == int(ig):
+                lut[:, int(it) * 4 + int(ig)] = (a1, a2)
+        assert nT * 4 <= MAX_LUT
+        _lut_cache[key] = (_lib.dev(lut.ravel(), device), nT * 4)
+    return _lut_cache[key]
+
+
+def _bound_constants(a, M_s, plx):
+    """constants of device_pipeline._bound_rate (priors.py:601-660)"""
+    if np.isnan(plx):
+        plx = 0.1
+    M_ref = M_s if M_s >= 1.0 else 1.0
+    lm = np.log10(M_ref)
+    f1 = 0.020 + 0.04 * lm + 0.07 * lm ** 2
+    f2 = 0.039 + 0.07 * lm + 0.01 * lm ** 2
+    f3 = 0.078 - 0.05 * lm + 0.04 * lm ** 2
+    alpha, dlogP = 0.018, 0.7
+    k = f2 - f1 - alpha * dlogP
+    k4 = f3 - f2 - alpha * dlogP
+    a.dist_pc = 1000 / plx
+    a.kepler_c = (4 * pi ** 2) / (G * M_ref * Msun)
+    a.f1, a.f2, a.f3 = f1, f2, f3
+    a.t2 = 0.5 * (2.0 * f1 + k)
+    a.t3 = 0.5 * alpha * (3.4 ** 2 - 5.4 * 3.4 + 6.8) + f2 * (3.4 - 2.0)
+    a.t4 = alpha * dlogP * (5.5 - 3.4) + f2 * (5.5 - 3.4) + k4 * (0.238095 * 5.5 ** 2 - 0.952381 * 5.5 + 0.485714)
+    a.t5 = f3 * (3.33333 - 17.3566 * np.exp(-0.3 * 8.0))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------
+class _Scenario:
+    """one lnZ_* call: draws, the fused kernel, the branch evidences and tables"""
+
+    def __init__(self, time, flux, sigma, N, parallel, exptime, nsamples, mission, flatpriors):
+        self.dev = _lib.compute_device()
+        self.time, self.flux = _lib.dev(time, self.dev), _lib.dev(flux, self.dev)
+        self.sigma, self.N = float(sigma), int(N)
+        self.parallel, self.exptime, self.nsamples = bool(parallel), exptime, nsamples
+        self.mission, self.flat = mission, bool(flatpriors)
+        self.keep = []                       # tensors the kernel reads: alive until it has run
+        a = self.a = DrawArgs()
+        a.N, a.parallel, a.flat = self.N, int(self.parallel), int(self.flat)
+        global _RP
+        if _RP is None:
+            _RP = _rp_laws()
+        a.law_rp_hi, a.law_rp_lo = _RP
+
+    def u(self):
+        t = dp.RNG.uniform(self.N, self.dev).contiguous()
+        self.keep.append(t)
+        return t
+
+    def period(self, P_orb):
+        a = self.a
+        if type(P_orb) not in [float, int]:
+            a.P_lo, a.P_hi = float(P_orb[0]), float(P_orb[-1])
+            t = self.u()
+            a.uP = t.data_ptr()
+            # sample_ecc is handed np.mean(P_orb) of the drawn periods (e.g. marginal_likelihoods.py:103)
+            return float((a.P_lo + (a.P_hi - a.P_lo) * t).mean())
+        a.P_lo = a.P_hi = float(P_orb)
+        return float(P_orb)
+
+    def target(self, M_s, R_s, Teff, Z):
+        a = self.a
+        a.M_s, a.R_s, a.Teff = float(M_s), float(R_s), float(Teff)
+        if Z is not None:
+            a.u1, a.u2 = ml._ldc(self.mission).star(Z, Teff, ml._logg(M_s, R_s))
+        a.f0_tess = _flux0(M_s, "TESS")
+        a.law_q = _q_law(M_s, -0.5, 0.30)
+
+    def planet_draws(self, P_mean):
+        a = self.a
+        a.planet = 1
+        a.uRp, a.uInc = self.u().data_ptr(), self.u().data_ptr()
+        dp.RNG.discard(self.N)
+        # torch's Beta sampler returns a strided view of a Dirichlet sample: the kernel reads [N] doubles
+        e = dp.RNG.beta(self.N, 0.867, 3.030, self.dev).to(F64).contiguous()
+        self.keep.append(e)
+        a.ecc_in = e.data_ptr()
+        a.uW = self.u().data_ptr()
+
+    def binary_draws(self, P_mean):
+        a = self.a
+        a.planet = 0
+        a.uInc, a.uQ = self.u().data_ptr(), self.u().data_ptr()
+        dp.RNG.discard(self.N)
+        a.uEcc = self.u().data_ptr()
+        a.ecc_pow = 1.0 / (0.2 if P_mean <= 10 else 0.6)
+        a.uW = self.u().data_ptr()
+
+    def bound_companion(self, M_s, molusc_file):
+        a = self.a
+        a.comp = COMP_BOUND
+        a.law_qc = _q_law(M_s, -0.95, 0.05)
+        if molusc_file is None:
+            a.uQc = self.u().data_ptr()
+        else:
+            q = _lib.dev(ml._bound_companions(M_s, self.N, molusc_file), self.dev).contiguous()
+            self.keep.append(q)
+            a.qc_in = q.data_ptr()
+
+    def bound_prior(self, kind, M_s, plx, cc_file, filt, molusc_file):
+        a = self.a
+        if molusc_file is not None:
+            a.prior = PRIOR_NONE
+            self.want_prior = True          # lnprior = zeros
+            return
+        a.prior = kind
+        self.want_prior = True
+        _bound_constants(a, M_s, plx)
+        self._cc(cc_file, filt, M_s)
+
+    def _cc(self, cc_file, filt, M_s):
+        a = self.a
+        seps, cons, n = _contrast_curve(cc_file, self.dev)
+        a.cc_seps, a.cc_cons, a.n_cc = seps.data_ptr(), cons.data_ptr(), n
+        a.use_cc = int(cc_file is not None)
+        self.band = filt if (cc_file is not None and filt in ("J", "H", "K")) else "TESS"
+        a.f0_band = _flux0(M_s, self.band)
+
+    def field(self, trilegal_fname, mags, need_ldc, cc_file, filt, M_s, hi_offset):
+        """TRILEGAL population + the index draw; hi_offset = -1 for the D scenarios (sic)"""
+        a = self.a
+        key = (trilegal_fname, tuple(float(m) for m in mags), self.mission, bool(need_ldc), self.dev.index)
+        f = _field_cache.get(key)
+        if f is None:
+            if len(_field_cache) > 64:
+                _field_cache.clear()
+            f = _field_cache[key] = dp._Field({"device": self.dev}, trilegal_fname, *mags, self.mission, need_ldc)
+        self.keep.append(f)
+        a.comp = COMP_FIELD
+        a.f_mass, a.f_radius, a.f_teff, a.f_logg = (f.masses.data_ptr(), f.radii.data_ptr(),
+                                                    f.Teffs.data_ptr(), f.loggs.data_ptr())
+        a.f_fr = f.fluxratios.data_ptr()
+        if need_ldc:
+            a.f_u1, a.f_u2 = f.u1.data_ptr(), f.u2.data_ptr()
+        self._cc(cc_file, filt, M_s)
+        band = filt if cc_file is not None else "T"
+        delta = f.band_delta(band).contiguous()
+        frband = f.band_fluxratio(band).contiguous()
+        self.keep += [delta, frband]
+        a.f_delta, a.f_frband = delta.data_ptr(), frband.data_ptr()
+        a.prior = PRIOR_FIELD
+        self.want_prior = True
+        a.bg_amp = (f.N_comp / 0.1) * (1 / 3600) ** 2
+        a.bg_const = float(np.log(a.bg_amp * 2.2 ** 2))
+        self.n_field, self.hi_offset = f.N_comp, hi_offset
+
+    def field_index(self):
+        idx = dp.RNG.randint(self.n_field + self.hi_offset, self.N, self.dev).to(torch.int64).contiguous()
+        self.keep.append(idx)
+        self.a.idx = idx.data_ptr()
+
+    want_prior = False
+    band = "TESS"
+
+    # -----------------------------------------------------------------------------------
+    def run(self, is_host):
+        a, N, dev = self.a, self.N, self.dev
+        tab = _spline_table(dev, self.band)
+        a.splines = tab.data_ptr()
+        ncol = 11 if a.planet else 14
+        cols = torch.empty((ncol, N), dtype=F64, device=dev)
+        mask = torch.empty(N, dtype=torch.uint8, device=dev)
+        mask2 = torch.empty(N, dtype=torch.uint8, device=dev) if not a.planet else None
+        lnprior = torch.empty(N, dtype=F64, device=dev) if self.want_prior else None
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        a.cols, a.mask, a.mask_twin, a.lnprior, a.flag = (cols.data_ptr(), mask.data_ptr(), _ptr(mask2),
+                                                          _ptr(lnprior), flag.data_ptr())
+        with torch.cuda.device(dev):
+            rc = _fn()(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.TrxError("trx_draw_scenario failed with status %d" % rc)
+        self.keep = []
+        out = []
+        flags = (FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if self.parallel else FLAG_SCALAR_K)
+        branches = ((MODEL_TP, mask, False),) if a.planet else ((MODEL_EB, mask, False), (MODEL_EB_TWIN, mask2, True))
+        for model, m, twin in branches:
+            idx = torch.nonzero(m, as_tuple=False).flatten()
+            n = int(idx.numel())
+            nblk = 10 if a.planet else 11
+            block = cols[:nblk].index_select(1, idx)
+            if twin:
+                block[2] *= 2.0                                  # 2 P_orb
+                block[4] = cols[11].index_select(0, idx)         # a at 2 P_orb
+            lp = None if lnprior is None else lnprior.index_select(0, idx)
+            h, lnz = _lib.lnz_scenario(model, flags, self.time, self.flux, self.sigma, block, self.exptime,
+                                       self.nsamples, lp, N, float(np.log(self.sigma)))
+            best = self._best(h, idx, n)
+            out.append((best, lnz, twin))
+        # one device -> host copy per branch: the N_BEST x ncol table, lnZ and (once) the flag
+        res = []
+        for best, lnz, twin in out:
+            tabl = torch.cat([cols.index_select(1, best).reshape(-1), lnz, flag.to(F64)]).cpu().numpy()
+            if tabl[-1] != 0.0:
+                raise ValueError("can only convert an array of size 1 to a Python scalar")
+            res.append(self._table(tabl[:-2].reshape(ncol, -1), float(tabl[-2]), twin))
+        return res[0] if a.planet else (res[0], res[1])
+
+    def _best(self, h, idx, n):
+        """indices of the N_BEST best draws (see device_pipeline._evidence for the tie rules)"""
+        dev, N = self.dev, self.N
+        if not isinstance(dp.RNG, dp.NumpyStreamRng):
+            k = min(N_BEST, n)
+            best = idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx
+            if k < N_BEST:
+                best = torch.cat([best, torch.arange(N_BEST - k, device=dev) % max(N, 1)])
+            return best
+        best = None
+        if n > N_BEST:
+            hv, hi = torch.topk(h, N_BEST + 1, largest=False, sorted=True)
+            if bool(torch.isfinite(hv[-1]) & (hv[1:] > hv[:-1]).all()):
+                best = idx[hi[:N_BEST]]
+        if best is None:
+            lnL = np.full(N, -np.inf)
+            lnL[idx.cpu().numpy()] = -0.5 * np.log(2 * pi) - np.log(self.sigma) - h.cpu().numpy()
+            best = torch.as_tensor((-lnL).argsort()[:N_BEST]).to(dev)
+        return best
+
+    def _table(self, t, lnZ, twin):
+        """the reference's result dict from the gathered columns (marginal_likelihoods.py:152-171)"""
+        z = np.zeros(t.shape[1])
+        if self.a.planet:
+            rp, P, inc, sm, Rh, u1, u2, ecc, w, frc, Mh = t
+            b = sm * (1 - ecc ** 2) / (1 + ecc * np.sin(w * pi / 180)) * np.cos(inc * pi / 180) / (Rh * Rsun)
+            return {"M_s": Mh, "R_s": Rh, "u1": u1, "u2": u2, "P_orb": P, "inc": inc, "b": b, "R_p": rp,
+                    "ecc": ecc, "argp": w, "M_EB": z, "R_EB": z.copy(), "fluxratio_EB": z.copy(),
+                    "fluxratio_comp": frc, "lnZ": lnZ}
+        r, fr, P, inc, sm, Rh, u1, u2, ecc, w, frc, sm2, m, Mh = t
+        if twin:
+            P, sm = 2 * P, sm2
+        b = sm * (1 - ecc ** 2) / (1 + ecc * np.sin(w * pi / 180)) * np.cos(inc * pi / 180) / (Rh * Rsun)
+        return {"M_s": Mh, "R_s": Rh, "u1": u1, "u2": u2, "P_orb": P, "inc": inc, "b": b, "R_p": z,
+                "ecc": ecc, "argp": w, "M_EB": m, "R_EB": r, "fluxratio_EB": fr, "fluxratio_comp": frc,
+                "lnZ": lnZ}
+
+
+# ---------------------------------------------------------------------------------------
+# the ten scenarios: random numbers are drawn in the reference's order (App. B of SURVEY.md)
+def _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples):
+    s = _Scenario(time, flux, sigma, N, parallel, exptime, nsamples, mission, flatpriors)
+    P_mean = s.period(P_orb)
+    s.target(M_s, R_s, Teff, Z)
+    return s, P_mean
+
+
+def lnZ_TTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.planet_draws(Pm)
+    return s.run(False)
+
+
+def lnZ_TEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.binary_draws(Pm)
+    return s.run(False)
+
+
+def lnZ_PTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
+            N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
+            nsamples=20, molusc_file=None):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.bound_companion(M_s, molusc_file)
+    s.bound_prior(PRIOR_BOUND_TP, M_s, plx, contrast_curve_file, filt, molusc_file)
+    s.planet_draws(Pm)
+    return s.run(False)
+
+
+def lnZ_PEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
+            N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
+            nsamples=20, molusc_file=None):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.binary_draws(Pm)
+    s.bound_companion(M_s, molusc_file)
+    s.bound_prior(PRIOR_BOUND_EB, M_s, plx, contrast_curve_file, filt, molusc_file)
+    return s.run(False)
+
+
+def _companion_host(s, Z, teff_cap):
+    a = s.a
+    a.host = HOST_COMPANION
+    lut, n = _companion_lut(s.mission, Z, teff_cap, s.dev)
+    a.lut, a.n_lut, a.teff_cap = lut.data_ptr(), n, float(teff_cap)
+
+
+def lnZ_STP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
+            N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
+            nsamples=20, molusc_file=None):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, None, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.bound_companion(M_s, molusc_file)
+    _companion_host(s, Z, 10000)
+    s.bound_prior(PRIOR_BOUND_TP, M_s, plx, contrast_curve_file, filt, molusc_file)
+    s.planet_draws(Pm)
+    return s.run(True)
+
+
+def lnZ_SEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, plx, contrast_curve_file=None, filt="TESS",
+            N=1000000, parallel=False, mission="TESS", flatpriors=False, exptime=0.00139,
+            nsamples=20, molusc_file=None):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, None, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.binary_draws(Pm)
+    s.bound_companion(M_s, molusc_file)
+    _companion_host(s, Z, 13000)
+    s.bound_prior(PRIOR_BOUND_EB, M_s, plx, contrast_curve_file, filt, molusc_file)
+    return s.run(True)
+
+
+def lnZ_DTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.field(trilegal_fname, (Tmag, Jmag, Hmag, Kmag), False, contrast_curve_file, filt, M_s, -1)
+    s.field_index()
+    s.planet_draws(Pm)
+    return s.run(False)
+
+
+def lnZ_DEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, Z, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.binary_draws(Pm)
+    s.field(trilegal_fname, (Tmag, Jmag, Hmag, Kmag), False, contrast_curve_file, filt, M_s, -1)
+    s.field_index()
+    return s.run(False)
+
+
+def lnZ_BTP(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, None, N, parallel, mission, flatpriors, exptime, nsamples)
+    s.field(trilegal_fname, (Tmag, Jmag, Hmag, Kmag), True, contrast_curve_file, filt, M_s, 0)
+    s.a.host = HOST_FIELD
+    s.field_index()
+    s.planet_draws(Pm)
+    return s.run(True)
+
+
+def lnZ_BEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, trilegal_fname,
+            contrast_curve_file=None, filt="TESS", N=1000000, parallel=False, mission="TESS",
+            flatpriors=False, exptime=0.00139, nsamples=20):
+    s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, None, N, parallel, mission, flatpriors, exptime, nsamples)
+    a = s.a
+    a.planet = 0
+    a.uInc, a.uQ = s.u().data_ptr(), s.u().data_ptr()
+    dp.RNG.discard(s.N)                 # companion mass ratios: drawn and unused (:2089)
+    dp.RNG.discard(s.N)                 # sample_ecc's own uniforms
+    a.uEcc = s.u().data_ptr()
+    a.ecc_pow = 1.0 / (0.2 if Pm <= 10 else 0.6)
+    a.uW = s.u().data_ptr()
+    s.field(trilegal_fname, (Tmag, Jmag, Hmag, Kmag), True, contrast_curve_file, filt, M_s, 0)
+    a.host = HOST_FIELD
+    s.field_index()
+    return s.run(True)
