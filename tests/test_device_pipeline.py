@@ -123,8 +123,11 @@ def test_device_pipeline_reproduces_reference_when_fed_the_numpy_stream(case, mo
 def test_sampling_switch(monkeypatch):
     import triceratops_amd
     from triceratops_amd import marginal_likelihoods as ml
+    from triceratops_amd import fused
     calls = []
     monkeypatch.setattr(dp, "lnZ_TTP", lambda *a, **k: calls.append(a) or {"lnZ": 0.0})
+    monkeypatch.setattr(fused, "lnZ_TTP", lambda *a, **k: calls.append(a) or {"lnZ": 0.0})
+    assert dp.FUSED is True                  # the fused per-draw kernel is the default device path
     triceratops_amd.set_sampling("device")
     try:
         assert ml.lnZ_TTP(1, 2, 3)["lnZ"] == 0.0 and calls
