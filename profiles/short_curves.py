@@ -33,5 +33,5 @@ for n_time in (50, 100, 200, 500, 1000, 2000):
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 3
         line += "  %s %.3f ms = %.3g evals/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
-    L.trx_set_cell_packing_below(320)
+    L.trx_set_cell_packing_below(160)
     print(line)

@@ -87,7 +87,7 @@ def _raw_stress_rows(rng, n):
 def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfolded):
     """The kernel averages the model over a few Gauss nodes where the exposure is far from the
     limb contacts (trx_device.hpp TierTable).  Against the same kernel evaluating all S
-    sub-exposures: flux within 2e-13 everywhere, bit-identical where no tier applies (S < 8) and
+    sub-exposures: flux within 3e-13 everywhere, bit-identical where no tier applies (S < 8) and
     exactly 1 out of transit; and against the oracle within the usual 5e-13."""
     rng = np.random.default_rng(100 + S)
     rows = _raw_stress_rows(rng, 1500)
@@ -102,7 +102,7 @@ def test_reduced_node_exposure_average_equals_all_subexposures(exptime, S, unfol
     finally:
         L.trx_set_supersample_tiers(1)
     d = np.abs(g[1] - g[0])
-    assert np.nanmax(d) < 2e-13, np.nanmax(d)
+    assert np.nanmax(d) < 3e-13, np.nanmax(d)
     assert np.array_equal(np.isnan(g[1]), np.isnan(g[0]))
     assert np.array_equal(g[1] == 1.0, g[0] == 1.0)                # out of transit stays exactly 1
     if S < 8:
@@ -201,7 +201,7 @@ def test_packed_cell_kernel_equals_row_kernel(model, n_time):
             h = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, synth.NSAMPLES)
             res[name] = (g.cpu().numpy(), s.cpu().numpy(), h.cpu().numpy())
     finally:
-        L.trx_set_cell_packing_below(320)
+        L.trx_set_cell_packing_below(160)
         L.trx_set_rows_per_wave(0)
     g0, s0, h0 = res["rows"]
     for name in ("cells", "cells7", "cells1"):
@@ -238,7 +238,7 @@ def test_packed_cell_kernel_raw_model_and_census():
                                            want_secdepth=False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
-        L.trx_set_cell_packing_below(320)
+        L.trx_set_cell_packing_below(160)
     assert np.array_equal(counts[0], counts[1 << 30])
 
 
@@ -260,7 +260,7 @@ def test_second_near_side_passage_on_a_very_eccentric_orbit():
             got, _ = _lib.flux_grid(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(row), synth.EXPTIME, synth.NSAMPLES)
             assert np.abs(got.cpu().numpy() - want).max() < ATOL_FLUX, below
     finally:
-        L.trx_set_cell_packing_below(320)
+        L.trx_set_cell_packing_below(160)
 
 
 def test_rows_with_a_flat_model_tie_exactly():
@@ -284,7 +284,7 @@ def test_rows_with_a_flat_model_tie_exactly():
             assert np.unique(h[flat]).size == 1 and np.unique(h[~flat]).size > 3000
             vals[below] = h[flat][0]
     finally:
-        L.trx_set_cell_packing_below(320)
+        L.trx_set_cell_packing_below(160)
     assert vals[0] == vals[1 << 30]
     assert abs(vals[0] / (0.5 * np.sum((flux - 1.0) ** 2 / synth.SIGMA ** 2)) - 1) < 1e-13
 
@@ -463,7 +463,7 @@ def test_large_batches_spot_checked():
         alone1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
     finally:
         L.trx_set_rows_per_wave(0)
-        L.trx_set_cell_packing_below(320)
+        L.trx_set_cell_packing_below(160)
     assert np.array_equal(alone1, h1[pick])
     assert np.abs(h1 / h - 1).max() < 1e-11, np.abs(h1 / h - 1).max()
     rng, t, flux = _lc(20000, seed=10)

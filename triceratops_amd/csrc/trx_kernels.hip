@@ -71,12 +71,12 @@ struct RowsArgs {
     double s2, dS, rS;
 };
 
-// nodes of a 64-cell chunk staged in LDS per pass: 12 x 64 x (8 + 2) B = 7.5 KB per wave, so that
-// LDS never limits the 16 waves per CU the register budget allows; 12 covers every reduced
-// node set in one pass, the all-sub-exposure cells near the contacts take two
+// nodes of a 64-cell chunk staged in LDS per pass: 10 x 64 x (8 + 2) B = 6.3 KB per wave (+ 1.6 KB
+// of contact-cell state), so that LDS never limits the 16 waves per CU the register budget allows;
+// 10 covers every reduced node set (3-9 nodes) in one pass, the all-sub-exposure cells take two
 // (profiles/r01_k_ab_pack.txt: 20 -> 11.70 ms, 12 -> 11.24, 10 -> 11.26, 8 -> 11.41 at 3 waves/SIMD)
 #ifndef TRX_NODES_PER_PASS
-#define TRX_NODES_PER_PASS 12
+#define TRX_NODES_PER_PASS 10
 #endif
 constexpr int kMaxNodesPerPass = TRX_NODES_PER_PASS;
 
@@ -124,6 +124,70 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 #define TRX_WAVES_PER_EU 4
 #endif
 
+// Centre state of the contact cells of a chunk, staged in LDS for the flattened stage A below.
+struct HeavyState {
+    double sE[64], cE[64], t[64];
+    unsigned char lane[64], row[64];
+};
+
+// Stage A for the cells next to a limb contact ("heavy": all S sub-exposures are evaluated).
+// A lane that walks its own S sub-exposures keeps the wave in the node loop for S trips while the
+// cells with 3-9 Gauss nodes idle; a chunk at ingress or egress holds ~10 such cells, so more than
+// half of stage A was spent in chunks running at a third of their lanes.  Here the (cell, sub-
+// exposure) pairs of the chunk's heavy cells are dealt to ALL lanes: every pair steps the orbit
+// from its cell's exposure-centre solution (|dM| <= half an exposure) and files its z like the
+// per-lane loop does, into zbuf[si * 64 + lane of the cell].
+//   rowc(r): orbit constants of row r (wave-uniform in rows_kernel, per-lane in cells_kernel)
+template <bool STEP, class RowFn>
+__device__ __forceinline__ void heavy_stage_a(const HeavyState& hs, int nh, int s0, int ns_pass,
+                                              const RowsArgs& a, RowFn rowc, double* zbuf,
+                                              unsigned short* items, int cap, int lane, int& n_in,
+                                              int& n_lb)
+{
+    const int total = nh * ns_pass;
+    const float inv = 1.0f / (float)ns_pass;
+    for (int w0 = 0; w0 < total; w0 += 64) {
+        const int w = w0 + lane;
+        const bool on = w < total;
+        int h = on ? (int)(((float)w + 0.5f) * inv) : 0;
+        h = h < nh ? h : nh - 1;
+        const int si = on ? (w - h * ns_pass) : 0;
+        const RowC& c = rowc((int)hs.row[h]);
+        int cls = 0;
+        double vz = 1.0;
+        int idx = 0;
+        if (on) {
+            const double t = hs.t[h];
+            const double frac = fma((double)(s0 + si + 1) - 0.5, a.rS, -0.5);
+            const double Mc = c.nmot * (t - c.t0) + c.Mtr;
+            const double M = c.nmot * ((t + a.exptime * frac) - c.t0) + c.Mtr;
+            double sE = hs.sE[h], cE = hs.cE[h];
+            bool have = false;
+            if (STEP) have = kepler_step(M - Mc, c.e, sE, cE);
+            if (!have) kepler_full(M, c.e, sE, cE);
+            const double ce = cE - c.e;
+            const double X = fma(c.ax, ce, c.bx * sE);
+            const double Y = fma(c.ay, ce, c.by * sE);
+            const double yc = Y * c.cosi;
+            const double z2 = fma(X, X, yc * yc);
+            const double opp = 1.0 + c.k, omk = 1.0 - c.k;
+            if (Y >= 0.0 && z2 < opp * opp) {
+                vz = sqrt_fast(z2);
+                cls = (c.k < 1.0 && vz <= omk) ? 1 : 2;
+            } else if (z2 != z2) {
+                vz = z2;
+            }
+            idx = si * 64 + (int)hs.lane[h];
+            zbuf[idx] = vz;
+        }
+        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
+        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
+        n_in += __popcll(m1);
+        n_lb += __popcll(m2);
+    }
+}
+
 template <int MODE, bool STEP, bool FP32>
 __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 {
@@ -135,6 +199,7 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
     const int cap = 64 * SB;
     double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
     unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
+    HeavyState& hs = *reinterpret_cast<HeavyState*>(items + cap);     // contact cells of the chunk (8-byte aligned: cap is a multiple of 64)
     // the secondary-eclipse orbit blocks and scan values live only through phases 1-3: they
     // overlay the slab, which only the time loop uses (so rows per wave cost 144 B of LDS each)
     RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // [B] secondary-eclipse orbits
@@ -294,15 +359,26 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                 const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
                 const double* ws = xs + kTiers * kTierMaxNodes;
                 double fsum = 0.0;
+                // contact cells (all S sub-exposures) are taken out of the per-lane node loop and
+                // their (cell, sub-exposure) pairs dealt to all lanes (heavy_stage_a)
+                const bool heavy = valid && pl.tier < 0 && pl.n > 0 && pl.anchored;
+                const unsigned long long mheavy = __ballot(heavy);
+                const int nh = __popcll(mheavy);
+                const int n_loop = heavy ? 0 : pl.n;
+                if (heavy) {
+                    const int o = lanes_below(mheavy);
+                    hs.sE[o] = pl.sE; hs.cE[o] = pl.cE; hs.t[o] = t;
+                    hs.lane[o] = (unsigned char)lane; hs.row[o] = 0;
+                }
                 for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
                     int n_in = 0, n_lb = 0, ns = 0;
                     TRX_TICK(t_a);
                     // stage A
-                    for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
+                    for (int si = 0; si < SB && __any(s0 + si < n_loop); ++si) {
                         const int s = s0 + si + 1;
                         int cls = 0;
                         double v = 1.0;
-                        if (s <= pl.n) {
+                        if (s <= n_loop) {
                             const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
                             double Y;
                             const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
@@ -321,6 +397,13 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
                         n_in += __popcll(m1);
                         n_lb += __popcll(m2);
                         ns = si + 1;
+                    }
+                    if (nh > 0 && s0 < a.S) {
+                        const int ns_pass = (a.S - s0 < SB) ? (a.S - s0) : SB;
+                        __syncthreads();
+                        heavy_stage_a<STEP>(hs, nh, s0, ns_pass, a, [&](int) -> const RowC& { return c; }, zbuf,
+                                            items, cap, lane, n_in, n_lb);
+                        ns = ns > ns_pass ? ns : ns_pass;
                     }
                     __syncthreads();
                     TRX_TOCK(2, t_a);
@@ -389,7 +472,11 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 //     windows of 1024 cells: pass 1 applies the transit-window test to 64 cells at a time across
 //     row boundaries, settles the out-of-window cells (model exactly 1) and files the in-window
 //     ones, in order, in a list in LDS; pass 2 runs plan / stage A / stage B / stage C of
-//     rows_kernel over that list, 64 in-window cells at a time: full lanes in every stage;
+//     rows_kernel over that list, 64 in-window cells at a time: full lanes in every stage.  The
+//     contact cells (all S sub-exposures) are filed again and take a sweep of their own, so the
+//     node loop of a chunk runs 3-9 trips or S trips, never S trips for a handful of lanes
+//     (measured better here than dealing their sub-exposures to all lanes as rows_kernel does:
+//     profiles/r02_b_short_curves.txt);
 //   * a lane's row constants come from the row blocks in LDS (cells of different rows share a
 //     wave, so they cannot ride in SGPRs);
 //   * chi^2 of a row = chi^2 of the flat model (every cell exactly 1: one number per launch, summed
@@ -915,7 +1002,9 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
 #pragma unroll
             for (int u = 0; u < kV; ++u) {
                 live[u] = x[u] - st.m > -80.0;
+#ifndef TRX_LME_NOCROWD
                 crowd += __popcll(__ballot(live[u]));
+#endif
             }
             if (crowd > 24 * kV) {
                 // a narrow distribution: most terms count, nothing to gain from parking them
@@ -1143,7 +1232,7 @@ int pick_rows_per_wave(int n_time, long n)
 }
 
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{320};
+std::atomic<int> g_cells_below{160};
 
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st)
@@ -1211,7 +1300,7 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
-    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short));
+    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short)) + sizeof(HeavyState);
     const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
     if (slab < overlay) slab = overlay;
     const size_t lds = ((size_t)a.B * kRowDoubles + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
