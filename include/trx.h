@@ -154,7 +154,7 @@ int trx_set_rows_per_wave(int rows);
 int trx_set_supersample_tiers(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
-/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 160) go through
+/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 224) go through
  *    the packed-cell kernel (a wave walks the (row, time) cells of ~2048 cells' worth of rows, 64 at
  *    a time across row boundaries) instead of the one-row-at-a-time kernel; 0 = never.  Model
  *    values are bit-identical between the two; chi^2 differs by summation order (~1e-16 relative). */

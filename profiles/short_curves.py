@@ -10,7 +10,7 @@ n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 L = _lib.lib()
 print("# %s, %d rows per family, 18 families; evals/s = n_time x rows x 18 / time of the 18 launches" % (
     os.path.basename(_lib.LIB_PATH), n_rows))
-for n_time in (50, 100, 200, 500, 1000, 2000):
+for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
     rng = np.random.default_rng(synth.SEED)
     t = synth.time_grid(n_time)
     t_d = _lib.dev(t)
@@ -33,5 +33,5 @@ for n_time in (50, 100, 200, 500, 1000, 2000):
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 3
         line += "  %s %.3f ms = %.3g evals/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
-    L.trx_set_cell_packing_below(160)
+    L.trx_set_cell_packing_below(224)
     print(line)

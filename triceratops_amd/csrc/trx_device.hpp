@@ -617,15 +617,18 @@ struct CellPlan {
     bool anchored = false;                       // state holds a solution (at the exposure centre)
 };
 
+template <bool CHECK_WINDOW = true>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
                                               const TierTable& tt, bool use_tiers)
 {
     CellPlan p;
     const double phase = c.nmot * (t - c.t0);
-    const double dMc = reduce_2pi(phase);
-    // the reduction is good to ~1e-16 |phase|: widen the window by that much
-    const double slack = 1e-15 * fabs(phase);
-    if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return p;
+    if (CHECK_WINDOW) {       // cells_kernel has filed the in-window cells already
+        const double dMc = reduce_2pi(phase);
+        // the reduction is good to ~1e-16 |phase|: widen the window by that much
+        const double slack = 1e-15 * fabs(phase);
+        if (!in_window(c.wlo - slack, c.whi + slack, dMc)) return p;
+    }
     p.n = S;
     if (!use_tiers) return p;
     // orbit at the exposure centre: position, velocity and the quadratic model of z^2(t)

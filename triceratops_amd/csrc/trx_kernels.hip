@@ -65,6 +65,7 @@ struct RowsArgs {
     int B;
     long nbatch;
     int use_tiers, SB, debug_nodes;
+    int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -527,6 +528,11 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
     unsigned short* rowof = items + cap;                              // [64] row of each lane's cell
     unsigned short* winlist = rowof + 64;                             // [kCellsWindow] in-window cells
+    // the light curve itself (<= 160 points by default: 2.5 KB): every chunk reads time stamps and
+    // fluxes of arbitrary cells, and a global load right before its use costs more than the chunk's
+    // other "rest" work at 3 waves per SIMD
+    double* tl = lds + a.tl_off;                                      // [n_time], behind slab and overlay
+    double* fl = tl + a.n_time;                                       // [n_time] (MODE_LNL)
     RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // phases 1-3 only (overlay)
     double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
     if (a.use_tiers && threadIdx.x == 0) {
@@ -550,13 +556,18 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
 #endif
     // chi^2 of the flat model (every cell exactly 1), in ONE fixed order -- that of rows_kernel
     double flat_sum = 0.0;
-    if (MODE == MODE_LNL) {
+    {
         double acc = 0.0;
         for (int j = lane; j < n_time; j += 64) {
-            const double d = a.flux[j] - 1.0;
-            acc += (d * d) / s2;
+            tl[j] = a.time[j];
+            if (MODE == MODE_LNL) {
+                const double f = a.flux[j];
+                fl[j] = f;
+                const double d = f - 1.0;
+                acc += (d * d) / s2;
+            }
         }
-        flat_sum = wave_sum(acc);
+        if (MODE == MODE_LNL) flat_sum = wave_sum(acc);
     }
 
     const long per_xcd = (a.nbatch + 7) / 8;
@@ -676,7 +687,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 bool inw = false;
                 if (valid) {
                     const RowC& c = rows[rr];
-                    const double phase = c.nmot * (a.time[j] - c.t0);
+                    const double phase = c.nmot * (tl[j] - c.t0);
                     const double dMc = reduce_2pi(phase);
                     const double slack = 1e-15 * fabs(phase);
                     inw = in_window(c.wlo - slack, c.whi + slack, dMc);
@@ -712,9 +723,9 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
 #else
                 const RowC c = rows[rr];
 #endif
-                const double t = a.time[j];
+                const double t = tl[j];
                 CellPlan pl;
-                if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                if (valid) pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
                 if (sweep == 0 && a.use_tiers) {
                     const bool heavy = valid && pl.tier < 0 && pl.n > 0;
                     const unsigned long long mh = __ballot(heavy);
@@ -788,14 +799,23 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
                         // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1          :486, :537, :586
-                        contrib = ((1.0 - m) * ((a.flux[j] - m) + (a.flux[j] - 1.0))) / s2;
+                        contrib = ((1.0 - m) * ((fl[j] - m) + (fl[j] - 1.0))) / s2;
                     }
                 }
                 if (MODE == MODE_LNL) {
+#ifdef TRX_CELLS_SEGMENT_SUM
                     // a deferred cell stays in its row's run (with a zero) so that runs stay contiguous
                     bool head;
                     const double ssum = segment_sum(contrib, listed ? rr : -1, lane, head);
                     if (listed && head) hacc[rr] += ssum;
+#else
+                    // one LDS atomic per cell with a non-unit model (ds_add_f64): the wave's lanes
+                    // meet on 2-3 accumulators and the LDS unit serialises them in a fixed order,
+                    // so results repeat bit for bit from run to run; a six-step shuffle reduction
+                    // per chunk costs ten times the latency (profiles/r02_d_cells_variants.txt)
+                    if (valid && contrib != 0.0)
+                        __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 }
                 TRX_TOCK(5, t_rest);
             }
@@ -1231,64 +1251,9 @@ int pick_rows_per_wave(int n_time, long n)
     return B;
 }
 
-// light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{160};
-
 template <int MODE>
-int launch_cells(const RowsArgs& a0, hipStream_t st)
+int launch_rows_kernel(const RowsArgs& a0, hipStream_t st)
 {
-    RowsArgs a = a0;
-    // about 2048 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays)
-    int B = (2048 + a.n_time - 1) / a.n_time;
-    B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
-    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
-    if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
-    if (forced <= 0) {
-        // Batches of equal size run in rounds over the wave slots of the chip (256 CUs x 4 SIMDs x
-        // TRX_CELLS_WAVES_PER_EU): 4762 batches of 21 rows took two rounds, 1.5x the time of an even
-        // fill.  Larger batches pack better (prologue lanes, full chunks, a fuller deferred sweep),
-        // so take the size with the best (fill of the last round) x (packing) estimate.
-        const double slots = 256.0 * 4 * TRX_CELLS_WAVES_PER_EU;
-        double best = -1.0;
-        int bestB = B;
-        for (int b = B; b >= 1; --b) {
-            const double rounds = (double)((a.n + b - 1) / b) / slots;
-            const double fill = rounds / ceil(rounds);
-            const double pack = 1.0 - 1.5 / (b + 1.5);
-            const double score = (rounds >= 1.0 ? fill : rounds) * pack;
-            if (score > best) { best = score; bestB = b; }
-        }
-        B = bestB;
-    }
-    a.B = B;
-    a.s2 = a.sigma * a.sigma;
-    a.dS = (double)a.S;
-    a.rS = 1.0 / a.dS;
-    a.nbatch = (a.n + a.B - 1) / a.B;
-    const long max_grid = 1L << 20;
-    const long want_grid = 8 * ((a.nbatch + 7) / 8);
-    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
-    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.SB = a.S < kCellsNodesPerPass ? a.S : kCellsNodesPerPass;
-    // zbuf + items + rowof + winlist; the phase 1-3 arrays overlay zbuf (+ what follows it)
-    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short))
-                + (64 + kCellsWindow) * sizeof(unsigned short);
-    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
-    if (slab < overlay) slab = overlay;
-    const size_t lds = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
-    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
-    else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
-    else            hipLaunchKernelGGL((cells_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
-    TRX_HIP(hipGetLastError());
-    return TRX_OK;
-}
-
-template <int MODE>
-int launch_rows(const RowsArgs& a0, hipStream_t st)
-{
-    if (a0.n_time < g_cells_below.load(std::memory_order_relaxed) && a0.n_time > 0)
-        return launch_cells<MODE>(a0, st);
     RowsArgs a = a0;
     a.B = pick_rows_per_wave(a.n_time, a.n);
     a.s2 = a.sigma * a.sigma;
@@ -1310,6 +1275,59 @@ int launch_rows(const RowsArgs& a0, hipStream_t st)
     else            hipLaunchKernelGGL((rows_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
     TRX_HIP(hipGetLastError());
     return TRX_OK;
+}
+
+// light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
+std::atomic<int> g_cells_below{224};
+
+template <int MODE>
+int launch_cells(const RowsArgs& a0, hipStream_t st)
+{
+    RowsArgs a = a0;
+    // about 800 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays).
+    // Measured (profiles/r02_d_cells_batch_sweep.txt): the best batch is 11-16 rows at 50 points, 8 at
+    // 100, 4 at 200, whatever the row count -- larger batches fill the prologue lanes and the chunks
+    // better, but the batches of a launch differ in work (rows with long transits), and with fewer,
+    // longer waves the last round over the chip's ~3000 wave slots leaves more of them idle.
+    int B = (800 + a.n_time / 2) / a.n_time;
+    B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
+    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
+    if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
+    else while (B > 1 && a.n / B < 4096) B = (B + 1) / 2;     // few rows: fill the chip first
+    a.B = B;
+    a.s2 = a.sigma * a.sigma;
+    a.dS = (double)a.S;
+    a.rS = 1.0 / a.dS;
+    a.nbatch = (a.n + a.B - 1) / a.B;
+    const long max_grid = 1L << 20;
+    const long want_grid = 8 * ((a.nbatch + 7) / 8);
+    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
+    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
+    a.SB = a.S < kCellsNodesPerPass ? a.S : kCellsNodesPerPass;
+    // zbuf + items + rowof + winlist; the phase 1-3 arrays overlay zbuf (+ what follows it)
+    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short))
+                + (64 + kCellsWindow) * sizeof(unsigned short);
+    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
+    // the staged light curve sits behind the slab: the overlay must not reach it (it is filled first)
+    if (slab < overlay) slab = (overlay + 7) & ~(size_t)7;
+    const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
+    a.tl_off = (int)(head / sizeof(double));
+    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double);
+    if (lds > 64 * 1024) return launch_rows_kernel<MODE>(a0, st);      // very long curves forced here by a test knob
+    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
+    if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
+    else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
+    else            hipLaunchKernelGGL((cells_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
+
+template <int MODE>
+int launch_rows(const RowsArgs& a0, hipStream_t st)
+{
+    if (a0.n_time < g_cells_below.load(std::memory_order_relaxed) && a0.n_time > 0)
+        return launch_cells<MODE>(a0, st);
+    return launch_rows_kernel<MODE>(a0, st);
 }
 
 int launch_lme(const double* logw, const double* h, const double* lnprior, double c0, long n,
@@ -1353,7 +1371,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1365,7 +1383,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
