@@ -9,8 +9,10 @@ Every function packs its per-sample arguments into one SoA parameter block, runs
 current CUDA device and returns numpy arrays.  lnL_* return +chi^2/2 (a negative log-likelihood
 without the Gaussian constant); +inf marks an EB draw whose secondary eclipse is deeper than
 1.5 sigma.  Differences from the reference, on purpose: the caller's `inc` array is not
-converted to radians in place (likelihoods.py:344, 410), and there is no module-level mutable
-model object (likelihoods.py:24-25), so the functions are re-entrant.
+converted to radians in place (likelihoods.py:344, 410), and the functions do not go through
+shared mutable model objects, so they are re-entrant.  The module-level names `tm` and `tm_sec`
+(likelihoods.py:24-25) exist for code that imports them, but nothing here calls `set_data` on
+them.
 """
 import numpy as np
 
