@@ -1560,7 +1560,7 @@ int trx_debug_phase_cycles(unsigned long long* out8)
 }
 #endif
 
-const char* trx_version(void) { return "triceratops_amd libtrx 0.1.0 (gfx950)"; }
+const char* trx_version(void) { return "triceratops_amd libtrx 0.2.0 (gfx950)"; }
 const char* trx_last_error(void) { return g_err; }
 
 int trx_device_count(void)
