@@ -41,8 +41,11 @@ class TorchRng:
         return torch.rand(n, dtype=F64, device=device)
 
     def beta(self, n, a, b, device):
-        return torch.distributions.Beta(torch.tensor(a, dtype=F64, device=device),
-                                        torch.tensor(b, dtype=F64, device=device)).sample((n,))
+        # X / (X + Y) with X ~ Gamma(a), Y ~ Gamma(b): what torch.distributions.Beta computes
+        # through a Dirichlet, without building distribution objects on every call
+        x = torch._standard_gamma(torch.full((n,), a, dtype=F64, device=device))
+        y = torch._standard_gamma(torch.full((n,), b, dtype=F64, device=device))
+        return x / (x + y)
 
     def randint(self, hi, n, device):
         return torch.randint(0, hi, (n,), device=device)

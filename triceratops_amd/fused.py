@@ -23,6 +23,11 @@ from .constants import G, Msun, Rsun, pi
 
 F64 = torch.float64
 N_BEST = ml.N_BEST
+# rows of the best-fit table a call returns.  The reference's lnZ_* return the 100 best draws but
+# calc_probs reads only the best one (triceratops.py:809-823); run_units asks for 1 row while it
+# evaluates the units of a calc_probs with the device generator, which turns the top-101 selection
+# (a device sort, ~15 launches per branch) into one argmin.  Direct lnZ_* calls keep 100.
+TABLE_ROWS = N_BEST
 HOST_TARGET, HOST_COMPANION, HOST_FIELD = 0, 1, 2
 COMP_NONE, COMP_BOUND, COMP_FIELD = 0, 1, 2
 PRIOR_NONE, PRIOR_BOUND_TP, PRIOR_BOUND_EB, PRIOR_FIELD = 0, 1, 2, 3
@@ -219,13 +224,31 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_lc_cache = {}
+
+
+def _on_device(a, device):
+    """device copy of a light-curve array; the ~10 lnZ_* calls of one star pass the same arrays, so
+    the last few are kept (keyed by content: 100-2000 doubles hash in microseconds)"""
+    if isinstance(a, torch.Tensor):
+        return _lib.dev(a, device)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    key = (a.shape, hash(a.tobytes()), device.index)
+    t = _lc_cache.get(key)
+    if t is None:
+        if len(_lc_cache) > 32:
+            _lc_cache.clear()
+        t = _lc_cache[key] = _lib.dev(a, device)
+    return t
+
+
 # ---------------------------------------------------------------------------------------
 class _Scenario:
     """one lnZ_* call: draws, the fused kernel, the branch evidences and tables"""
 
     def __init__(self, time, flux, sigma, N, parallel, exptime, nsamples, mission, flatpriors):
         self.dev = _lib.compute_device()
-        self.time, self.flux = _lib.dev(time, self.dev), _lib.dev(flux, self.dev)
+        self.time, self.flux = _on_device(time, self.dev), _on_device(flux, self.dev)
         self.sigma, self.N = float(sigma), int(N)
         self.parallel, self.exptime, self.nsamples = bool(parallel), exptime, nsamples
         self.mission, self.flat = mission, bool(flatpriors)
@@ -394,10 +417,13 @@ class _Scenario:
         """indices of the N_BEST best draws (see device_pipeline._evidence for the tie rules)"""
         dev, N = self.dev, self.N
         if not isinstance(dp.RNG, dp.NumpyStreamRng):
-            k = min(N_BEST, n)
+            rows = TABLE_ROWS
+            if rows == 1 and n > 0:
+                return idx[torch.argmin(h).reshape(1)]
+            k = min(rows, n)
             best = idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx
-            if k < N_BEST:
-                best = torch.cat([best, torch.arange(N_BEST - k, device=dev) % max(N, 1)])
+            if k < rows:
+                best = torch.cat([best, torch.arange(rows - k, device=dev) % max(N, 1)])
             return best
         best = None
         if n > N_BEST:

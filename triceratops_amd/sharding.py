@@ -92,6 +92,17 @@ def run_units(units, verbose=0):
     elif per_unit_seed:
         base = int(np.random.randint(0, 2 ** 31 - 1))
 
+    # calc_probs keeps the best draw of every scenario only: with the device generator the fused
+    # path then selects it with one argmin instead of a top-100 sort (fused.TABLE_ROWS)
+    from . import fused as _fused
+    _fused.TABLE_ROWS = 1
+    try:
+        return _run_units(units, live, owner, base, dist, world, rank, verbose)
+    finally:
+        _fused.TABLE_ROWS = _fused.N_BEST
+
+
+def _run_units(units, live, owner, base, dist, world, rank, verbose):
     rows = {k: len(units[k][1]) for k in live}
     offs, total = {}, 0
     for k in live:
