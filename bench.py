@@ -370,12 +370,11 @@ def run_grid(ctx):
     kernels = {}
     if ctx["extras"]:
         evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d)
-        if args.all_subexposures:
-            evals_per_cell_timed = None        # census knob reports plans; with tiers off every in-window cell runs S
         flop_exec = evals_per_cell * (F_ORBIT + F_MA)
         achieved = flop_exec * cells_per_launch / mean_launch_s / 1e12
         plain_flop = synth.NSAMPLES * (F_ORBIT + p_in * F_MA)
         plain_tf = plain_flop * cells_per_launch / mean_launch_s / 1e12
+        assert 0.0 < achieved < FP64_VALU_PEAK_TF, "roofline.frac must be a fraction (got %g TFLOP/s)" % achieved
         roof.update({"achieved": achieved, "frac": achieved / FP64_VALU_PEAK_TF,
                      "model_evaluations_per_cell": evals_per_cell, "flop_per_model_evaluation": F_ORBIT + F_MA,
                      "p_in": p_in, "plain_algorithm_flop_per_cell": plain_flop,
