@@ -533,6 +533,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     // other "rest" work at 3 waves per SIMD
     double* tl = lds + a.tl_off;                                      // [n_time], behind slab and overlay
     double* fl = tl + a.n_time;                                       // [n_time] (MODE_LNL)
+    HeavyState& hs = *reinterpret_cast<HeavyState*>(fl + a.n_time);   // contact cells of a sweep-2 chunk
     RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // phases 1-3 only (overlay)
     double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
     if (a.use_tiers && threadIdx.x == 0) {
@@ -739,15 +740,27 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 const double* ws = xs + kTiers * kTierMaxNodes;
                 const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
                 double fsum = 0.0;
+                // second sweep: every cell of the chunk evaluates all S sub-exposures, but a batch
+                // holds only a dozen such cells -- their (cell, sub-exposure) pairs are dealt to all
+                // 64 lanes (heavy_stage_a) instead of 12 lanes walking S trips each
+                const bool flat = (sweep == 1) && a.use_tiers;
+                const unsigned long long mflat = __ballot(flat && valid && pl.n > 0 && pl.anchored);
+                const int nh = __popcll(mflat);
+                if (flat && valid && pl.n > 0 && pl.anchored) {
+                    const int o = lanes_below(mflat);
+                    hs.sE[o] = pl.sE; hs.cE[o] = pl.cE; hs.t[o] = t;
+                    hs.lane[o] = (unsigned char)lane; hs.row[o] = (unsigned char)rr;
+                }
+                const int n_loop = (flat && pl.anchored) ? 0 : pl.n;
                 for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
                     int n_in = 0, n_lb = 0, ns = 0;
                     TRX_TICK(t_a);
                     // stage A
-                    for (int si = 0; si < SB && __any(s0 + si < pl.n); ++si) {
+                    for (int si = 0; si < SB && __any(s0 + si < n_loop); ++si) {
                         const int s = s0 + si + 1;
                         int cls = 0;
                         double vz = 1.0;
-                        if (s <= pl.n) {
+                        if (s <= n_loop) {
                             const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
                             double Y;
                             const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
@@ -766,6 +779,13 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         n_in += __popcll(m1);
                         n_lb += __popcll(m2);
                         ns = si + 1;
+                    }
+                    if (nh > 0 && s0 < a.S) {
+                        const int ns_pass = (a.S - s0 < SB) ? (a.S - s0) : SB;
+                        __syncthreads();
+                        heavy_stage_a<STEP>(hs, nh, s0, ns_pass, a, [&](int q) -> const RowC& { return rows[q]; },
+                                            zbuf, items, cap, lane, n_in, n_lb);
+                        ns = ns > ns_pass ? ns : ns_pass;
                     }
                     __syncthreads();
                     TRX_TOCK(3, t_a);
@@ -1284,12 +1304,12 @@ template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st)
 {
     RowsArgs a = a0;
-    // about 800 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays).
+    // about 700 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays).
     // Measured (profiles/r02_d_cells_batch_sweep.txt): the best batch is 11-16 rows at 50 points, 8 at
     // 100, 4 at 200, whatever the row count -- larger batches fill the prologue lanes and the chunks
     // better, but the batches of a launch differ in work (rows with long transits), and with fewer,
     // longer waves the last round over the chip's ~3000 wave slots leaves more of them idle.
-    int B = (800 + a.n_time / 2) / a.n_time;
+    int B = (700 + a.n_time / 2) / a.n_time;
     B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
     const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
     if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
@@ -1312,7 +1332,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
     if (slab < overlay) slab = (overlay + 7) & ~(size_t)7;
     const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
     a.tl_off = (int)(head / sizeof(double));
-    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double);
+    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double) + sizeof(HeavyState);
     if (lds > 64 * 1024) return launch_rows_kernel<MODE>(a0, st);      // very long curves forced here by a test knob
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
