@@ -91,8 +91,14 @@ def test_fused_kernel_with_a_molusc_table(name):
 
 @pytest.mark.parametrize("name", NAMES)
 def test_fused_kernel_equals_torch_pipeline_on_the_device_generator(name):
-    """torch's Philox stream, consumed in the same order by both paths (incl. the strided Beta sample)"""
-    a, b = _both(name, "device", 77, P=3.3, N=200000, parallel=True, cc=CC, filt="J")
+    """torch's device generator staged for both paths and consumed in the same order (fused.PHILOX
+    off: with it on the kernel draws its own numbers, tested further down)"""
+    from triceratops_amd import fused
+    fused.PHILOX = False
+    try:
+        a, b = _both(name, "device", 77, P=3.3, N=200000, parallel=True, cc=CC, filt="J")
+    finally:
+        fused.PHILOX = True
     _same(a, b, 1e-9, 100)
 
 
@@ -112,3 +118,121 @@ def test_missing_limb_darkening_cell_raises_like_the_reference():
     finally:
         dp.FUSED = True
         triceratops_amd.set_sampling("numpy")
+
+
+# ---------------------------------------------------------------------------------------------
+# the kernel's own random numbers (Philox4x32-10, set_sampling("device"))
+class _Replay:
+    """hands the draw kernel's dumped random numbers back, as staged arrays, in the order a
+    scenario consumes them (device_pipeline.TorchRng interface)"""
+
+    def __init__(self, dump, order):
+        self.dump, self.order = dump, list(order)
+
+    def uniform(self, n, device):
+        return self.dump[self.order.pop(0)].clone()
+
+    def beta(self, n, a, b, device):
+        return self.dump[8].clone()
+
+    def randint(self, hi, n, device):
+        return self.dump[7].to(torch.int64)
+
+    def discard(self, n):
+        pass
+
+
+_ORDER = {"TTP": [2, 3, 6], "PTP": [1, 2, 3, 6], "STP": [1, 2, 3, 6], "DTP": [2, 3, 6], "BTP": [2, 3, 6],
+          "TEB": [3, 4, 5, 6], "PEB": [3, 4, 5, 6, 1], "SEB": [3, 4, 5, 6, 1], "DEB": [3, 4, 5, 6], "BEB": [3, 4, 5, 6]}
+
+
+@pytest.mark.parametrize("P", [3.3, [2.5, 4.0]], ids=["fixed", "range"])
+@pytest.mark.parametrize("name", NAMES)
+def test_in_kernel_random_numbers_equal_the_staged_path_on_the_same_numbers(name, P):
+    """device mode: the kernel draws its own numbers; dumped and fed back through the staged path
+    (the one pinned to the reference) they give the same evidence and tables"""
+    import triceratops_amd
+    from triceratops_amd import device_pipeline as dp
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    kw = dict(P=P, N=60000, parallel=True, cc=CC, filt="J")
+    triceratops_amd.set_sampling("device")
+    fused.DUMP = []
+    try:
+        torch.manual_seed(123)
+        a = _call(ml, name, **kw)
+        rec = fused.DUMP[0]
+        order = ([0] if isinstance(P, list) else []) + _ORDER[name]
+        fused.DUMP = None
+        fused.PHILOX = False
+        saved = dp.RNG
+        dp.RNG = _Replay(rec["dump"], order)
+        try:
+            b = _call(ml, name, **kw)
+        finally:
+            dp.RNG = saved
+    finally:
+        fused.DUMP, fused.PHILOX = None, True
+        triceratops_amd.set_sampling("numpy")
+    if isinstance(P, list):
+        # the staged path hands sample_ecc the SAMPLE mean of the periods, the kernel path the expectation:
+        # the same side of the 10-day switch of the binaries' eccentricity law in this test
+        pass
+    _same(a, b, 1e-10, 100)
+
+
+def test_in_kernel_random_numbers_statistics():
+    """uniformity, independence between slots and draws, the index draw and the Beta(0.867, 3.030)
+    eccentricities (Marsaglia-Tsang gammas) against scipy"""
+    from scipy import stats
+    import triceratops_amd
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    N = 400000
+    triceratops_amd.set_sampling("device")
+    fused.DUMP = []
+    try:
+        torch.manual_seed(9)
+        _call(ml, "BTP", P=[2.5, 4.0], N=N, parallel=True, cc=None, filt="TESS")     # P, index, R_p, inc, beta, argp
+        _call(ml, "PEB", P=3.3, N=N, parallel=True, cc=None, filt="TESS")            # inc, q, ecc, argp, q_c
+        d1, d2 = (r["dump"].cpu().numpy() for r in fused.DUMP)
+    finally:
+        fused.DUMP = None
+        triceratops_amd.set_sampling("numpy")
+    streams = {"P": d1[0], "Rp": d1[2], "inc": d1[3], "w": d1[6], "inc2": d2[3], "q": d2[4], "ecc": d2[5],
+               "w2": d2[6], "qc": d2[1]}
+    for k, u in streams.items():
+        assert u.min() >= 0.0 and u.max() < 1.0, k
+        assert abs(u.mean() - 0.5) < 5 * np.sqrt(1 / 12 / N) and abs(u.var() - 1 / 12) < 5e-4, k
+        assert stats.kstest(u, "uniform").pvalue > 1e-4, k
+        assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(N), k          # draw i vs draw i + 1
+    keys = list(streams)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            assert abs(np.corrcoef(streams[keys[i]], streams[keys[j]])[0, 1]) < 5 / np.sqrt(N), (keys[i], keys[j])
+    idx = d1[7]
+    n_field = int(idx.max()) + 1
+    counts = np.bincount(idx.astype(int), minlength=n_field)
+    assert stats.chisquare(counts).pvalue > 1e-4 and n_field > 100
+    ecc = d1[8]
+    assert stats.kstest(ecc, stats.beta(0.867, 3.030).cdf).pvalue > 1e-4
+    assert abs(ecc.mean() - 0.867 / (0.867 + 3.030)) < 5 * stats.beta(0.867, 3.030).std() / np.sqrt(N)
+
+
+def test_in_kernel_random_numbers_depend_on_seed_and_draw_index_only():
+    import triceratops_amd
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    triceratops_amd.set_sampling("device")
+    out = []
+    try:
+        for seed, N in ((5, 3000), (5, 7000), (6, 3000)):
+            fused.DUMP = []
+            torch.manual_seed(seed)
+            _call(ml, "TTP", P=3.3, N=N, parallel=True, cc=None, filt="TESS")
+            out.append(fused.DUMP[0]["dump"].cpu().numpy())
+    finally:
+        fused.DUMP = None
+        triceratops_amd.set_sampling("numpy")
+    assert np.array_equal(out[0], out[1][:, :3000])          # same seed: the first draws do not depend on N
+    assert not np.array_equal(out[0][2], out[2][2])           # another seed: other numbers

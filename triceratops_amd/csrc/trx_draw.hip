@@ -22,6 +22,63 @@ constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr double kG = 6.6743e-08, kMsun = 1.988409870698051e+33, kRsun = 69570000000.0,
                  kRearth = 637810000.0, kAu = 14959787070000.0;
 
+// ---- counter-based random numbers ------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011): ten rounds of two 32x32 -> 64 multiplies.
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        const U4 n{(unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0};
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// two uniforms in [0, 1) with 53 random bits each (numpy's construction: (a >> 5) 2^26 + (b >> 6))
+__device__ __forceinline__ void philox_uniform2(unsigned long long seed, long i, unsigned slot, unsigned sub,
+                                                double& u0, double& u1)
+{
+    const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), slot, sub},
+                               (unsigned)seed, (unsigned)(seed >> 32));
+    u0 = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) * (1.0 / 9007199254740992.0);
+    u1 = ((double)(r.z >> 5) * 67108864.0 + (double)(r.w >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ double philox_uniform(unsigned long long seed, long i, unsigned slot)
+{
+    double u0, u1;
+    philox_uniform2(seed, i, slot, 0u, u0, u1);
+    return u0;
+}
+
+// Gamma(alpha, 1) by Marsaglia & Tsang (2000); alpha < 1 through Gamma(alpha + 1) U^(1/alpha).
+// Each attempt takes two counter blocks (a Box-Muller normal + the acceptance uniform).
+__device__ __forceinline__ double philox_gamma(unsigned long long seed, long i, unsigned slot, double alpha)
+{
+    const double a1 = (alpha < 1.0) ? alpha + 1.0 : alpha;
+    const double d = a1 - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (unsigned att = 0; att < 64u; ++att) {
+        double u0, u1, u2, u3;
+        philox_uniform2(seed, i, slot, 2u * att + 1u, u0, u1);
+        philox_uniform2(seed, i, slot, 2u * att + 2u, u2, u3);
+        const double x = sqrt(-2.0 * log(1.0 - u0)) * cos(2.0 * kPi * u1);
+        const double t = 1.0 + c * x;
+        if (t <= 0.0) continue;
+        const double v = t * t * t, x2 = x * x;
+        const double lu = log(1.0 - u2);              // log of a uniform in (0, 1]
+        if (lu < 0.5 * x2 + d * (1.0 - v + log(v))) { g = d * v; break; }
+    }
+    if (alpha < 1.0) g *= pow(1.0 - philox_uniform(seed, i, slot), 1.0 / alpha);   // sub-draw 0: the boost uniform
+    return g;
+}
+
 // ---- tables staged in LDS ------------------------------------------------------------------
 struct Tables {
     double spl[TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES];
@@ -161,17 +218,29 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
     const long N = a.N;
     const bool parallel = a.parallel != 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
-        const double P = a.uP ? (a.P_lo + (a.P_hi - a.P_lo) * a.uP[i]) : a.P_lo;
+        // a random input: the staged array, or the kernel's own Philox stream
+        auto rnd = [&](const double* staged, unsigned slot) -> double {
+            return staged ? staged[i] : philox_uniform(a.seed, i, slot);
+        };
+        double dP = 0.0, dQc = 0.0, dRp = 0.0, dQ = 0.0, dEcc = 0.0, dIdx = 0.0, dBeta = 0.0;
+        double P = a.P_lo;
+        if (a.uP || a.range_P) { dP = rnd(a.uP, 0u); P = a.P_lo + (a.P_hi - a.P_lo) * dP; }
         // ---- unresolved companion (bound) or field star ----------------------------------
         double frc = 0.0, qc = 1.0, mc = 0.0;
         long k = 0;
         if (a.comp == TRX_COMP_BOUND) {
-            qc = a.qc_in ? a.qc_in[i] : plaw_inv(a.law_qc, a.uQc[i]);
+            if (a.qc_in) qc = a.qc_in[i];
+            else { dQc = rnd(a.uQc, 1u); qc = plaw_inv(a.law_qc, dQc); }
             mc = qc * a.M_s;
             const double f = flux_rel(T, TRX_SPL_F_TESS, mc);
             frc = f / (f + a.f0_tess);
         } else if (a.comp == TRX_COMP_FIELD) {
-            k = a.idx[i];
+            if (a.idx) k = a.idx[i];
+            else {
+                dIdx = philox_uniform(a.seed, i, 7u);
+                k = (long)(dIdx * (double)a.n_field_draw);
+                k = k < a.n_field_draw ? k : a.n_field_draw - 1;
+            }
             frc = a.f_fr[k];
         }
         // ---- host star ---------------------------------------------------------------------
@@ -205,17 +274,24 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
         }
         if (a.comp == TRX_COMP_BOUND) extra = extra && (qc != 0.0);
 
-        const double inc = acos(1.0 - a.uInc[i]) * 180.0 / kPi;              // priors.py:119-132
-        const double w = a.uW[i] * 360.0;                                   // :157-166
+        const double dInc = rnd(a.uInc, 3u), dW = rnd(a.uW, 6u);
+        const double inc = acos(1.0 - dInc) * 180.0 / kPi;                  // priors.py:119-132
+        const double w = dW * 360.0;                                        // :157-166
         const double sinw = sin(w * kPi / 180.0);
         double ecc, lnprior = 0.0, dm = 0.0;
         bool dm_set = false;
         double* col = a.cols + i;
         if (a.planet) {
-            ecc = a.ecc_in[i];                                              // Beta(0.867, 3.03) draws
+            if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
+            else {
+                const double gx = philox_gamma(a.seed, i, 8u, 0.867), gy = philox_gamma(a.seed, i, 9u, 3.030);
+                ecc = gx / (gx + gy);
+            }
+            dBeta = ecc;
+            dRp = rnd(a.uRp, 2u);
             double rp;
-            if (a.flat) rp = a.uRp[i] * 19.5 + 0.5;
-            else rp = (Mh > 0.45) ? plaw_inv(a.law_rp_hi, a.uRp[i]) : plaw_inv(a.law_rp_lo, a.uRp[i]);
+            if (a.flat) rp = dRp * 19.5 + 0.5;
+            else rp = (Mh > 0.45) ? plaw_inv(a.law_rp_hi, dRp) : plaw_inv(a.law_rp_lo, dRp);
             const double sm = sma(Mh, P);
             const double size = rp * kRearth + Rh * kRsun;
             const double Ptra = size / sm * ((1.0 + ecc * sinw) / (1.0 - ecc * ecc));
@@ -233,8 +309,10 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
                 lnprior = bound_rate(a, T, fabs(dm), false);
             }
         } else {
-            ecc = pow(a.uEcc[i], a.ecc_pow);                                // priors.py:146-155
-            const double q = plaw_inv(a.law_q, a.uQ[i]);
+            dEcc = rnd(a.uEcc, 5u);
+            ecc = pow(dEcc, a.ecc_pow);                                     // priors.py:146-155
+            dQ = rnd(a.uQ, 4u);
+            const double q = plaw_inv(a.law_q, dQ);
             const double m = q * Mh;
             double r, tdummy;
             stellar_relations(T, m, Rh, Th, r, tdummy);
@@ -306,6 +384,11 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
             if (dm > 0.0) lnprior = -INFINITY;
         }
         if (a.lnprior) a.lnprior[i] = lnprior;
+        if (a.dump) {
+            double* dd = a.dump + i;
+            dd[0 * N] = dP; dd[1 * N] = dQc; dd[2 * N] = dRp; dd[3 * N] = dInc; dd[4 * N] = dQ;
+            dd[5 * N] = dEcc; dd[6 * N] = dW; dd[7 * N] = (double)k; dd[8 * N] = dBeta;
+        }
     }
 }
 
@@ -318,10 +401,16 @@ extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
     if (!args || args->N < 0) return TRX_ERR_ARG;
     if (args->N == 0) return TRX_OK;
     const trx_draw_args& a = *args;
-    if (!a.cols || !a.mask || !a.uInc || !a.uW || !a.splines || !a.flag) return TRX_ERR_ARG;
-    if (a.planet ? (!a.ecc_in || !a.uRp) : (!a.uEcc || !a.uQ || !a.mask_twin)) return TRX_ERR_ARG;
-    if (a.comp == TRX_COMP_BOUND && !a.qc_in && !a.uQc) return TRX_ERR_ARG;
-    if ((a.comp == TRX_COMP_FIELD || a.host == TRX_HOST_FIELD) && (!a.idx || !a.f_fr)) return TRX_ERR_ARG;
+    if (!a.cols || !a.mask || !a.splines || !a.flag) return TRX_ERR_ARG;
+    if (!a.planet && !a.mask_twin) return TRX_ERR_ARG;
+    if (!a.use_philox) {         // every random input the scenario consumes must be staged
+        if (!a.uInc || !a.uW) return TRX_ERR_ARG;
+        if (a.planet ? (!a.ecc_in || !a.uRp) : (!a.uEcc || !a.uQ)) return TRX_ERR_ARG;
+        if (a.comp == TRX_COMP_BOUND && !a.qc_in && !a.uQc) return TRX_ERR_ARG;
+        if ((a.comp == TRX_COMP_FIELD || a.host == TRX_HOST_FIELD) && !a.idx) return TRX_ERR_ARG;
+        if (a.range_P && !a.uP) return TRX_ERR_ARG;
+    }
+    if ((a.comp == TRX_COMP_FIELD || a.host == TRX_HOST_FIELD) && (!a.f_fr || (!a.idx && a.n_field_draw < 1))) return TRX_ERR_ARG;
     if (a.n_cc < 0 || a.n_cc > TRX_DRAW_MAX_CC || a.n_lut < 0 || a.n_lut > TRX_DRAW_MAX_LUT) return TRX_ERR_ARG;
     long blocks = (a.N + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;

@@ -1305,7 +1305,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
 {
     RowsArgs a = a0;
     // about 700 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays).
-    // Measured (profiles/r02_d_cells_batch_sweep.txt): the best batch is 11-16 rows at 50 points, 8 at
+    // Measured (profiles/r02_d_cells_batch_sweep.txt): the best batch is 11 rows at 50 points, 6-8 at
     // 100, 4 at 200, whatever the row count -- larger batches fill the prologue lanes and the chunks
     // better, but the batches of a launch differ in work (rows with long transits), and with fewer,
     // longer waves the last round over the chip's ~3000 wave slots leaves more of them idle.

@@ -28,6 +28,11 @@ N_BEST = ml.N_BEST
 # evaluates the units of a calc_probs with the device generator, which turns the top-101 selection
 # (a device sort, ~15 launches per branch) into one argmin.  Direct lnZ_* calls keep 100.
 TABLE_ROWS = N_BEST
+# True: with the device generator (set_sampling("device")) the random numbers are made inside the
+# draw kernel (Philox4x32-10 keyed by one 62-bit seed per call taken from torch's CPU generator, so
+# torch.manual_seed reproduces a run); False: torch's device generator fills staged arrays
+PHILOX = True
+DUMP = None        # tests: a list that receives the [9][N] tensor of random numbers every call used
 HOST_TARGET, HOST_COMPANION, HOST_FIELD = 0, 1, 2
 COMP_NONE, COMP_BOUND, COMP_FIELD = 0, 1, 2
 PRIOR_NONE, PRIOR_BOUND_TP, PRIOR_BOUND_EB, PRIOR_FIELD = 0, 1, 2, 3
@@ -56,7 +61,9 @@ class DrawArgs(ctypes.Structure):
                 + [(k, _vp) for k in ("splines", "cc_seps", "cc_cons", "lut", "f_mass", "f_radius",
                                       "f_teff", "f_logg", "f_fr", "f_delta", "f_frband", "f_u1", "f_u2",
                                       "uP", "uQc", "uRp", "uInc", "uQ", "uEcc", "uW", "ecc_in", "qc_in",
-                                      "idx", "cols", "mask", "mask_twin", "lnprior", "flag")])
+                                      "idx", "cols", "mask", "mask_twin", "lnprior", "flag")]
+                + [("use_philox", ctypes.c_int), ("range_P", ctypes.c_int), ("n_field_draw", ctypes.c_long),
+                   ("seed", ctypes.c_ulonglong), ("dump", _vp)])
 
 
 _bound = False
@@ -255,21 +262,32 @@ class _Scenario:
         self.keep = []                       # tensors the kernel reads: alive until it has run
         a = self.a = DrawArgs()
         a.N, a.parallel, a.flat = self.N, int(self.parallel), int(self.flat)
+        self.philox = PHILOX and isinstance(dp.RNG, dp.TorchRng)
+        if self.philox:
+            a.use_philox = 1
+            a.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         global _RP
         if _RP is None:
             _RP = _rp_laws()
         a.law_rp_hi, a.law_rp_lo = _RP
 
     def u(self):
+        """pointer to one staged array of N uniforms -- or None: the kernel draws them itself"""
+        if self.philox:
+            return None
         t = dp.RNG.uniform(self.N, self.dev).contiguous()
         self.keep.append(t)
-        return t
+        return t.data_ptr()
 
     def period(self, P_orb):
         a = self.a
         if type(P_orb) not in [float, int]:
             a.P_lo, a.P_hi = float(P_orb[0]), float(P_orb[-1])
-            t = self.u()
+            a.range_P = 1
+            if self.philox:
+                return 0.5 * (a.P_lo + a.P_hi)          # the expectation of the mean below
+            t = dp.RNG.uniform(self.N, self.dev).contiguous()
+            self.keep.append(t)
             a.uP = t.data_ptr()
             # sample_ecc is handed np.mean(P_orb) of the drawn periods (e.g. marginal_likelihoods.py:103)
             return float((a.P_lo + (a.P_hi - a.P_lo) * t).mean())
@@ -287,29 +305,30 @@ class _Scenario:
     def planet_draws(self, P_mean):
         a = self.a
         a.planet = 1
-        a.uRp, a.uInc = self.u().data_ptr(), self.u().data_ptr()
-        dp.RNG.discard(self.N)
-        # torch's Beta sampler returns a strided view of a Dirichlet sample: the kernel reads [N] doubles
-        e = dp.RNG.beta(self.N, 0.867, 3.030, self.dev).to(F64).contiguous()
-        self.keep.append(e)
-        a.ecc_in = e.data_ptr()
-        a.uW = self.u().data_ptr()
+        a.uRp, a.uInc = self.u(), self.u()
+        if not self.philox:
+            dp.RNG.discard(self.N)
+            # a sampler may return a strided view (torch's Beta does): the kernel reads [N] doubles
+            e = dp.RNG.beta(self.N, 0.867, 3.030, self.dev).to(F64).contiguous()
+            self.keep.append(e)
+            a.ecc_in = e.data_ptr()
+        a.uW = self.u()
 
     def binary_draws(self, P_mean):
         a = self.a
         a.planet = 0
-        a.uInc, a.uQ = self.u().data_ptr(), self.u().data_ptr()
+        a.uInc, a.uQ = self.u(), self.u()
         dp.RNG.discard(self.N)
-        a.uEcc = self.u().data_ptr()
+        a.uEcc = self.u()
         a.ecc_pow = 1.0 / (0.2 if P_mean <= 10 else 0.6)
-        a.uW = self.u().data_ptr()
+        a.uW = self.u()
 
     def bound_companion(self, M_s, molusc_file):
         a = self.a
         a.comp = COMP_BOUND
         a.law_qc = _q_law(M_s, -0.95, 0.05)
         if molusc_file is None:
-            a.uQc = self.u().data_ptr()
+            a.uQc = self.u()
         else:
             q = _lib.dev(ml._bound_companions(M_s, self.N, molusc_file), self.dev).contiguous()
             self.keep.append(q)
@@ -363,6 +382,9 @@ class _Scenario:
         self.n_field, self.hi_offset = f.N_comp, hi_offset
 
     def field_index(self):
+        self.a.n_field_draw = self.n_field + self.hi_offset
+        if self.philox:
+            return
         idx = dp.RNG.randint(self.n_field + self.hi_offset, self.N, self.dev).to(torch.int64).contiguous()
         self.keep.append(idx)
         self.a.idx = idx.data_ptr()
@@ -383,6 +405,10 @@ class _Scenario:
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         a.cols, a.mask, a.mask_twin, a.lnprior, a.flag = (cols.data_ptr(), mask.data_ptr(), _ptr(mask2),
                                                           _ptr(lnprior), flag.data_ptr())
+        if DUMP is not None:
+            dump = torch.zeros((9, N), dtype=F64, device=dev)
+            a.dump = dump.data_ptr()
+            DUMP.append({"dump": dump, "cols": cols, "mask": mask, "mask_twin": mask2, "lnprior": lnprior})
         with torch.cuda.device(dev):
             rc = _fn()(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
         if rc:
@@ -563,12 +589,12 @@ def lnZ_BEB(time, flux, sigma, P_orb, M_s, R_s, Teff, Tmag, Jmag, Hmag, Kmag, tr
     s, Pm = _start(time, flux, sigma, P_orb, M_s, R_s, Teff, None, N, parallel, mission, flatpriors, exptime, nsamples)
     a = s.a
     a.planet = 0
-    a.uInc, a.uQ = s.u().data_ptr(), s.u().data_ptr()
+    a.uInc, a.uQ = s.u(), s.u()
     dp.RNG.discard(s.N)                 # companion mass ratios: drawn and unused (:2089)
     dp.RNG.discard(s.N)                 # sample_ecc's own uniforms
-    a.uEcc = s.u().data_ptr()
+    a.uEcc = s.u()
     a.ecc_pow = 1.0 / (0.2 if Pm <= 10 else 0.6)
-    a.uW = s.u().data_ptr()
+    a.uW = s.u()
     s.field(trilegal_fname, (Tmag, Jmag, Hmag, Kmag), True, contrast_curve_file, filt, M_s, 0)
     a.host = HOST_FIELD
     s.field_index()
