@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--n-time", type=int, default=None, help="light-curve points (grid: 2000, batch: 200)")
     ap.add_argument("--tois", type=int, default=64, help="batch mode: number of synthetic TOIs")
     ap.add_argument("--batch-n", type=int, default=1_000_000, help="batch mode: Monte-Carlo draws per scenario")
+    ap.add_argument("--threads", type=int, default=None,
+                    help="host threads (one HIP stream each) evaluating scenarios side by side: batch mode "
+                         "(default 6) and the threaded e2e leg (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each of the three CPU legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel, census and e2e legs")
@@ -418,7 +421,7 @@ def run_grid(ctx):
         cpu = cpu_baseline(t, flux, rows_h, fams, args.cpu_seconds)
     e2e = None
     if ctx["extras"] and not args.no_e2e and world == 1:
-        e2e = e2e_calc_probs()
+        e2e = e2e_calc_probs(args.threads or 4)
 
     return {
         "metric": "light-curve-point x sample evals/sec", "value": value,
@@ -446,6 +449,9 @@ def run_batch(ctx):
     from triceratops_amd import _lib, synth
     args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
     triceratops_amd.set_sampling("device")
+    if args.threads is None:
+        args.threads = 6
+    triceratops_amd.set_threads(args.threads)
     if args.fp32_model:
         triceratops_amd.set_precision("fp32")
     if ctx["debug_one"]:
@@ -511,9 +517,9 @@ def run_batch(ctx):
         "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
-                               "light curves, calc_probs_many with device-side sampling; value counts the "
-                               "(draw, time) cells that pass the geometry mask and reach the model"
-                               % (args.tois, args.batch_n, args.n_time),
+                               "light curves, calc_probs_many with device-side sampling, %d host threads per rank; "
+                               "value counts the (draw, time) cells that pass the geometry mask and reach the model"
+                               % (args.tois, args.batch_n, args.n_time, args.threads),
                    "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
                    "evaluated_cells_per_step": float(cells[0]) / args.steps,
                    "evaluated_rows_per_step": float(cells[1]) / args.steps,
@@ -522,9 +528,10 @@ def run_batch(ctx):
                    "parallelism": "lnZ_* units dealt to %d ranks by cost (LPT), one all_gather of the tables" % world},
         "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VALU_PEAK_TF, "traffic": None,
-                     "kernel_seconds_rank0": kern_s, "kernel_share_of_step": kern_s / elapsed,
+                     "kernel_seconds_rank0": kern_s, "kernel_seconds_over_wall": kern_s / elapsed,
                      "model_evaluations_per_cell": evals_per_cell,
-                     "note": "likelihood + log-mean-exp launches of rank 0 (events around trx_lnz_scenario); the "
+                     "note": "likelihood + log-mean-exp launches of rank 0 (events around trx_lnz_scenario, summed "
+                             "over the host threads' streams: they overlap, so the sum can exceed the wall-clock); the "
                              "rest of the step is the device-side draw / derive / mask / compact chain"},
         "cpu_baseline": None,
         "fpp_mean": float(np.mean(fpps)), "fpp_checksum": float(np.sum(fpps)),
@@ -537,7 +544,7 @@ def jobs_time(jobs, device):
 
 
 # ---------------------------------------------------------------------------------------------
-def e2e_calc_probs():
+def e2e_calc_probs(threads=3):
     """end-to-end calc_probs() wall-clock on TOI-465.01 (BASELINE configs[2]): the reference's example
     light curve (100 binned points) + contrast curve, target + 20 neighbours (75 scenarios), N = 1e6,
     parallel=True, in the three sampling modes; plus the 15-scenario run of the notebook's own star table."""
@@ -554,11 +561,13 @@ def e2e_calc_probs():
                        "TOI465_01_contrastcurve.csv, P_orb = 3.836169 d, N = 1e6 draws per scenario, parallel=True; "
                        "synthetic TRILEGAL table; reference notebook (unstated laptop): ~61 s per 15-scenario run",
            "seconds": {}, "FPP": {}}
-    for tag, modes in (("blend", ("device", "numpy-device", "numpy")), ("real", ("device", "numpy-device"))):
+    for tag, modes in (("blend", ("device", "device-threads", "numpy-device", "numpy")),
+                       ("real", ("device", "device-threads", "numpy-device"))):
         st = pd.DataFrame({c: g["%s_stars_%s" % (tag, c)] for c in cols})
         st["ID"] = st["ID"].astype(np.int64)
         for mode in modes:
-            triceratops_amd.set_sampling(mode)
+            triceratops_amd.set_sampling(mode.split("-threads")[0])
+            triceratops_amd.set_threads(threads if mode.endswith("-threads") else 1)
             try:
                 best = None
                 for rep in range(2 if mode != "numpy" else 1):
@@ -584,6 +593,8 @@ def e2e_calc_probs():
                 res["FPP"][key] = float(tg.FPP)
             finally:
                 triceratops_amd.set_sampling("numpy")
+                triceratops_amd.set_threads(1)
+    res["threads"] = threads
     return res
 
 

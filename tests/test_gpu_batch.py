@@ -115,3 +115,31 @@ def test_config4_shard_device_sampling():
     for x, y in zip(out, out2):
         assert x.FPP_degenerate is False and -1e-9 <= x.FPP <= 1.0 + 1e-9 and len(x.lnZ) == 18
         assert abs(x.FPP - y.FPP) < 1e-12          # same torch seed, same result
+
+
+def test_threaded_units_give_the_same_results_as_one_thread():
+    """set_threads(n): the scenarios of calc_probs_many evaluated side by side on n host threads /
+    HIP streams; per-unit Philox keys make the result independent of n (bit for bit) and repeatable"""
+    import triceratops_amd
+    from triceratops_amd import sharding
+    res = {}
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    try:
+        for n_thr in (1, 3, 3):
+            triceratops_amd.set_threads(n_thr)
+            np.random.seed(21)
+            torch.manual_seed(21)
+            t0 = time.perf_counter()
+            out = triceratops_amd.calc_probs_many(_jobs(6, 300_000))
+            torch.cuda.synchronize()
+            res.setdefault(n_thr, []).append((np.array([tg.lnZ for tg in out]), np.array([tg.FPP for tg in out]),
+                                              time.perf_counter() - t0))
+    finally:
+        triceratops_amd.set_threads(1)
+        sharding.per_unit_seed = False
+        triceratops_amd.set_sampling("numpy")
+    one, thr_a, thr_b = res[1][0], res[3][0], res[3][1]
+    print("6 TOIs x 18 x N=3e5: 1 thread %.3f s, 3 threads %.3f s" % (one[2], thr_b[2]))
+    assert np.array_equal(one[0], thr_a[0], equal_nan=True) and np.array_equal(one[1], thr_a[1])
+    assert np.array_equal(thr_a[0], thr_b[0], equal_nan=True)

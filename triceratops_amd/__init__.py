@@ -22,6 +22,16 @@ def set_precision(mode):
     _lib.set_precision(mode)
 
 
+def set_threads(n):
+    """Host threads (each with its own HIP stream) that evaluate the scenarios of calc_probs /
+    calc_probs_many side by side; effective with set_sampling("device") only.  Implies per-unit
+    seeding: results do not depend on n."""
+    from . import sharding
+    if int(n) < 1:
+        raise ValueError("threads must be >= 1")
+    sharding.threads = int(n)
+
+
 def calc_probs_many(jobs, verbose: int = 0):
     """calc_probs for several targets in one sharded pass (see triceratops.calc_probs_many)."""
     from .triceratops import calc_probs_many as _many

@@ -11,6 +11,7 @@ Host work per call: the constants of the broken power laws (priors.py:16-383), t
 Di Stefano rate constants (priors.py:601-660) and table pointers -- nothing per draw.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -32,6 +33,30 @@ TABLE_ROWS = N_BEST
 # draw kernel (Philox4x32-10 keyed by one 62-bit seed per call taken from torch's CPU generator, so
 # torch.manual_seed reproduces a run); False: torch's device generator fills staged arrays
 PHILOX = True
+_tls = threading.local()
+
+
+def set_thread_seed(seed):
+    """key of the calls this thread makes next (sharding.run_units: one seed per work unit, so a
+    unit's draws do not depend on which rank or thread evaluates it); None = take the key from
+    torch's CPU generator"""
+    _tls.seed, _tls.count = seed, 0
+
+
+def threadable():
+    """True when lnZ_* calls may run side by side on several host threads: device sampling with
+    the kernel's own random numbers (no global generator is consumed)"""
+    return ml._sampling["mode"] == "device" and PHILOX and isinstance(dp.RNG, dp.TorchRng)
+
+
+def _mix(seed, count):
+    """splitmix64 of (seed, count): a 62-bit Philox key"""
+    z = (seed * 0x9E3779B97F4A7C15 + count * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) >> 2
+
+
 DUMP = None        # tests: a list that receives the [9][N] tensor of random numbers every call used
 HOST_TARGET, HOST_COMPANION, HOST_FIELD = 0, 1, 2
 COMP_NONE, COMP_BOUND, COMP_FIELD = 0, 1, 2
@@ -265,7 +290,12 @@ class _Scenario:
         self.philox = PHILOX and isinstance(dp.RNG, dp.TorchRng)
         if self.philox:
             a.use_philox = 1
-            a.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            ts = getattr(_tls, "seed", None)
+            if ts is None:
+                a.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            else:
+                a.seed = _mix(int(ts), _tls.count)
+                _tls.count += 1
         global _RP
         if _RP is None:
             _RP = _rp_laws()

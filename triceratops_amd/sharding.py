@@ -21,6 +21,12 @@ import numpy as np
 RECORD_COLS = ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
                "R_EB", "fluxratio_EB", "fluxratio_comp", "lnZ")
 per_unit_seed = False
+# Host threads that evaluate this rank's units side by side, each on its own HIP stream
+# (set_sampling("device") with the kernel's own random numbers only).  A lnZ_* call is ~25 small
+# launches and two host syncs around one or two large kernels; a second and third call in flight
+# fill the GPU while the first waits for Python.  Implies per-unit seeding (the numbers a unit draws
+# depend on its seed only, so the result does not depend on the number of threads).
+threads = 1
 
 # relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
 # secondary-eclipse scan; companion/background hosts add per-draw stellar relations
@@ -89,7 +95,7 @@ def run_units(units, verbose=0):
         own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
                         for k in live], world)
         owner = {k: own[i] for i, k in enumerate(live)}
-    elif per_unit_seed:
+    elif per_unit_seed or threads > 1:
         base = int(np.random.randint(0, 2 ** 31 - 1))
 
     # calc_probs keeps the best draw of every scenario only: with the device generator the fused
@@ -109,9 +115,10 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         offs[k] = total
         total += rows[k]
     table = np.full((total, len(RECORD_COLS)), np.nan)
-    for k in live:
-        if owner[k] != rank:
-            continue
+    from . import fused as _fused
+    mine_k = [k for k in live if owner[k] == rank]
+
+    def one(k):
         j0, names, snum, ID, fn, key = units[k][:6]
         if verbose == 1:
             print("Calculating " + ", ".join(names) + " scenario probabilit"
@@ -119,10 +126,54 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                   + (" [rank %d]" % rank if dist else "") + ".")
         if base is not None:
             unit_seed = (base + 7919 * (k + 1)) % (2 ** 32)
-            np.random.seed(unit_seed)
-            import torch
-            torch.manual_seed(unit_seed)             # device-side sampling (set_sampling("device"))
-        table[offs[k]:offs[k] + rows[k]] = _record(fn())
+            _fused.set_thread_seed(unit_seed)        # the draw kernel's Philox key (thread-local)
+            if n_threads == 1:
+                np.random.seed(unit_seed)            # the numpy sampling modes
+                import torch
+                torch.manual_seed(unit_seed)         # staged draws from torch's generator
+        try:
+            table[offs[k]:offs[k] + rows[k]] = _record(fn())
+        finally:
+            _fused.set_thread_seed(None)
+
+    n_threads = min(threads, len(mine_k)) if (base is not None and _fused.threadable()) else 1
+    if n_threads <= 1:
+        for k in mine_k:
+            one(k)
+    else:
+        import queue
+        import threading
+        import torch
+        device = torch.cuda.current_device()
+        todo = queue.SimpleQueue()
+        cost = {k: _COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0) for k in mine_k}
+        for k in sorted(mine_k, key=lambda k: (-cost[k], k)):
+            todo.put(k)
+        errors = []
+
+        def worker():
+            try:
+                torch.cuda.set_device(device)        # the current device is thread-local
+                stream = torch.cuda.Stream(device)
+                with torch.cuda.stream(stream):
+                    while True:
+                        try:
+                            k = todo.get_nowait()
+                        except queue.Empty:
+                            break
+                        one(k)
+                stream.synchronize()
+            except BaseException as exc:              # re-raised in the caller's thread
+                errors.append(exc)
+
+        torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
+        pool = [threading.Thread(target=worker) for _ in range(n_threads)]
+        for t in pool:
+            t.start()
+        for t in pool:
+            t.join()
+        if errors:
+            raise errors[0]
 
     if dist:
         import torch
