@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <cstddef>
 #include <mutex>
 
 #include "../../include/trx.h"
@@ -66,6 +67,7 @@ struct RowsArgs {
     long nbatch;
     int use_tiers, SB, debug_nodes;
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
+    double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -459,58 +461,177 @@ __global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
-// cells_kernel: the same model for SHORT light curves (the reference's real operating point is
-// 100-200 binned points, examples/TSCIII_tutorial.ipynb cell 4).  rows_kernel loses lanes there
-// three ways: the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at
-// 100 points, profiles/r01_r_phase_cycles.txt), a 100-point row fills 64 + 36 lanes, and -- the
-// largest loss -- a 64-cell chunk of a coarse time grid spans 0.3 d, so in- and out-of-transit
-// cells share every chunk and the lanes of the out-of-window cells idle through the plan and the
-// orbit stage (a 2000-point chunk spans 0.016 d and is all in or all out).  Here a wave takes a
-// batch of B <= 22 rows and
-//   * the prologue runs with lanes = rows (B lanes busy), the secondary-eclipse scan with lanes =
-//     (row, point) as before;
-//   * the (row, time) cells of the batch form ONE index space, cell = r * n_time + j, walked in
-//     windows of 1024 cells: pass 1 applies the transit-window test to 64 cells at a time across
-//     row boundaries, settles the out-of-window cells (model exactly 1) and files the in-window
-//     ones, in order, in a list in LDS; pass 2 runs plan / stage A / stage B / stage C of
-//     rows_kernel over that list, 64 in-window cells at a time: full lanes in every stage.  The
-//     contact cells (all S sub-exposures) are filed again and take a sweep of their own, so the
-//     node loop of a chunk runs 3-9 trips or S trips, never S trips for a handful of lanes
-//     (measured better here than dealing their sub-exposures to all lanes as rows_kernel does:
-//     profiles/r02_b_short_curves.txt);
+// Short light curves (the reference's real operating point is 100-200 binned points,
+// examples/TSCIII_tutorial.ipynb cell 4): rowc_kernel + cells_kernel.  rows_kernel loses lanes there
+// four ways: the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at 100
+// points, profiles/r01_r_phase_cycles.txt), a 100-point row fills 64 + 36 lanes, a 64-cell chunk of
+// a coarse time grid spans 0.3 d, so in- and out-of-transit cells share every chunk and the lanes
+// of the out-of-window cells idle through the plan and the orbit stage (a 2000-point chunk spans
+// 0.016 d and is all in or all out), and the in-window cells of such a chunk have unrelated node
+// counts (3-9 Gauss nodes, S next to a contact), so a per-lane node loop runs to the largest.
+//   * rowc_kernel derives the row constants of 64 rows per wave -- lanes = rows, then lanes =
+//     (row, point) for the secondary-eclipse scan -- and stores the 18-double blocks in device
+//     scratch (144 B per row, stream-ordered allocation inside the call);
+//   * cells_kernel takes a batch of B <= 22 rows per wave and loads their blocks into LDS.  The
+//     (row, time) cells of the batch form ONE index space, cell = r * n_time + j, walked in windows
+//     of kCellsWindow cells: pass 1 applies the transit-window test to 64 cells at a time across row
+//     boundaries, settles the out-of-window cells (model exactly 1) and files the in-window ones,
+//     in order, in a list in LDS; pass 2 takes that list 64 cells at a time: each lane plans its
+//     cell (Kepler solve at the exposure centre + node count), then the (cell, node) PAIRS of the
+//     chunk are dealt to all 64 lanes: stage A steps each pair's orbit from its cell's centre
+//     solution and files its z by case, stage B runs the Mandel-Agol flux over the case lists,
+//     stage C has each cell sum its own pairs in node order.  Every stage runs full lanes whatever
+//     the mix of node counts.  Cells next to a limb contact (all S sub-exposures) are filed again
+//     and take a second sweep, 64 of them at a time, so that their S pairs per cell do not dilute
+//     the case lists of the first sweep's chunks;
 //   * a lane's row constants come from the row blocks in LDS (cells of different rows share a
 //     wave, so they cannot ride in SGPRs);
 //   * chi^2 of a row = chi^2 of the flat model (every cell exactly 1: one number per launch, summed
 //     in rows_kernel's order) + the corrections ((f-m)^2 - (f-1)^2)/sigma^2 of its in-window
-//     cells, reduced per chunk by a segmented shuffle reduction keyed on the row (fixed order,
-//     deterministic) into one LDS accumulator per row.  The window pass therefore touches no
-//     flux, and draws whose model is flat over the data tie EXACTLY (the reference's argsort
-//     orders such ties in the best-fit table); grid mode stores cell = output offset.
+//     cells, added to one LDS accumulator per row.  The window pass therefore touches no flux, and
+//     draws whose model is flat over the data tie EXACTLY (the reference's argsort orders such
+//     ties in the best-fit table); grid mode stores cell = output offset.
 // The device functions and node tables are those of rows_kernel; the two kernels agree to
-// rounding in the model (the compiler contracts the inlined arithmetic differently) and to
-// summation order in chi^2.
+// rounding in the model (a node is reached from the exposure centre here, from the previous node
+// there) and to summation order in chi^2.
 #ifndef TRX_CELLS_WAVES_PER_EU
-#define TRX_CELLS_WAVES_PER_EU 3
+#define TRX_CELLS_WAVES_PER_EU 4
 #endif
-#ifndef TRX_CELLS_NODES_PER_PASS
-#define TRX_CELLS_NODES_PER_PASS 8
+#ifndef TRX_CELLS_PAIRS
+#define TRX_CELLS_PAIRS 640
 #endif
-constexpr int kCellsMaxRows = 22;      // B * (18 + 25) doubles of phase 1-3 arrays fit the slab
-constexpr int kCellsWindow = 1024;     // cells per window pass (in-window list: 2 KB of LDS)
-constexpr int kCellsNodesPerPass = TRX_CELLS_NODES_PER_PASS;
+#ifndef TRX_CELLS_WINDOW
+#define TRX_CELLS_WINDOW 1024
+#endif
+constexpr int kCellsMaxRows = 22;
+constexpr int kCellsWindow = TRX_CELLS_WINDOW;     // cells per window pass (in-window list in LDS)
+constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
-// first lane of every run of equal keys receives the run's sum (runs are contiguous)
-__device__ __forceinline__ double segment_sum(double v, int key, int lane, bool& head)
+// Row constants of 64 rows per wave (phases 1-3 of rows_kernel with every lane on a row of its
+// own), written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
+// 256 threads per 64 rows: the first wave derives the constants (lanes = rows), then the 64 x 25
+// (row, point) cells of the secondary-eclipse scan are dealt to all four waves -- the scan is an
+// eighth of an EB row's work at 100 points, and one wave per 64 rows leaves the chip a third full.
+// Only the secondary orbits are staged in LDS (9 KB); the scan's minimum is taken with LDS atomics
+// (min ignores NaN, so NaN is flagged separately).
+__global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
 {
+    __shared__ RowC srows[64];
+    __shared__ double secmin[64];
+    __shared__ int secnan[64];
+    const int lane = threadIdx.x;
+    const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
+    const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
+    const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
+    const long n = a.n;
+    const long base = (long)blockIdx.x * 64;
+    const int nb = (int)((n - base < 64) ? (n - base) : 64);
+    double ysec = 0.0, fdil = 0.0;
+    double* dst = a.rowc + (base + lane) * kRowDoubles;
+    if (lane < nb) {
+        const double* p = a.params + base + lane;
+        RowC c;
+        double u1, u2;
+        if (a.model == TRX_MODEL_RAW) {
+            u1 = p[7 * n]; u2 = p[8 * n];
+            orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
+            c.xeb = 0.0; c.fdil = 0.0;
+        } else {
+            double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
+            if (a.model == TRX_MODEL_TP) {
+                const double R_p = p[0];
+                per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
+                u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
+                k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
+            } else {
+                const double R_EB = p[0], eb_fr = p[1 * n];
+                per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
+                u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
+                feb = eb_fr / (1.0 - eb_fr);                            // :401
+                k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
+                ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
+            }
+            const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
+            const double a_R = acm / (R_s * kRsun);                     // :343, :409
+            const double inc_r = inc * (kPi / 180.0);                   // :344, :410
+            const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
+            orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+            if (!eblike) {
+                c.xeb = 0.0;
+                c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
+            } else {
+                RowC& sc = srows[lane];
+                const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
+                orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                const Limb L = limb_weights(u1, u2);
+                sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
+                sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                if (is_host) {                                          // :427-432
+                    c.xeb = feb / fcomp;
+                    ysec = fcomp / feb;
+                    c.fdil = 1.0 / (fcomp + feb);
+                } else {                                                // :433-438
+                    c.xeb = feb / 1.0;
+                    ysec = 1.0 / feb;
+                    c.fdil = fcomp / (1.0 + feb);
+                }
+            }
+        }
+        const Limb L = limb_weights(u1, u2);
+        c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
+        c.excl = 0.0;
+        fdil = c.fdil;
+        const double* src = reinterpret_cast<const double*>(&c);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ov = __shfl_down(v, o, 64);
-        const int ok = __shfl_down(key, o, 64);
-        if (lane + o < 64 && ok == key) v += ov;
+        for (int q = 0; q < kRowDoubles; ++q) dst[q] = src[q];
     }
-    const int prev = __shfl_up(key, 1, 64);
-    head = (lane == 0) || (prev != key);
-    return v;
+    if (!eblike) return;
+    if (lane < 64) { secmin[lane] = INFINITY; secnan[lane] = 0; }
+    __syncthreads();
+    for (int it = lane; it < nb * kSecPoints; it += 256) {
+        const int r = it / kSecPoints, j = it - r * kSecPoints;
+        const RowC sc = srows[r];
+        const Limb L{sc.cle, sc.cld, sc.ced};
+        // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
+        double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
+        if (j == kSecPoints - 1) ts = 0.05;
+        const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
+        if (f != f) atomicOr(&secnan[r], 1);
+        else __hip_atomic_fetch_min(&secmin[r], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (lane < nb) {
+        double m = secnan[lane] ? NAN : secmin[lane];                   // np.min propagates NaN
+        m = (m + ysec) / (1.0 + ysec);
+        const double secdepth = 1.0 - (m + fdil) / (1.0 + fdil);
+        dst[kRowDoubles - 1] = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;  // RowC::excl, :535
+        if (a.out_sec) a.out_sec[base + lane] = secdepth;
+    }
+}
+static_assert(offsetof(RowC, excl) == (kRowDoubles - 1) * sizeof(double), "excl is the last field of RowC");
+
+// per-cell state of the chunk in flight (lane = cell), read by the lanes its pairs are dealt to
+struct CellState {
+    double sE[64], cE[64];                  // eccentric anomaly at the exposure centre
+    double facc[64];                        // the cell's sum over its nodes
+    unsigned short j[64];                   // time index
+    signed char tier[64];                   // node set (-1 = all S sub-exposures)
+    unsigned char row[64], anchored[64];
+};
+
+// exclusive prefix sum over the lanes of a non-negative count < 2^BITS, and the wave total
+template <int BITS>
+__device__ __forceinline__ int lane_prefix(int cnt, int& total)
+{
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1);
+        off += lanes_below(m) << b;
+        total += __popcll(m) << b;
+    }
+    return off;
 }
 
 template <int MODE, bool STEP, bool FP32>
@@ -519,23 +640,16 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     extern __shared__ double lds[];
     const int B = a.B;
     RowC* rows = reinterpret_cast<RowC*>(lds);
-    double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 per row
+    double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 corrections per row
     double* hmout = hacc + B;                                         // [B] diluted model of an unocculted cell: 1, or NaN
     double* tier_xw = hmout + B;
-    const int SB = a.SB;
-    const int cap = 64 * SB;
-    double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
-    unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
-    unsigned short* rowof = items + cap;                              // [64] row of each lane's cell
-    unsigned short* winlist = rowof + 64;                             // [kCellsWindow] in-window cells
-    // the light curve itself (<= 160 points by default: 2.5 KB): every chunk reads time stamps and
-    // fluxes of arbitrary cells, and a global load right before its use costs more than the chunk's
-    // other "rest" work at 3 waves per SIMD
-    double* tl = lds + a.tl_off;                                      // [n_time], behind slab and overlay
+    unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
+    unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
+    CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
+    // the light curve itself: every chunk reads time stamps and fluxes of arbitrary cells, and a
+    // global load right before its use costs more than the chunk's other "rest" work
+    double* tl = lds + a.tl_off;                                      // [n_time]
     double* fl = tl + a.n_time;                                       // [n_time] (MODE_LNL)
-    HeavyState& hs = *reinterpret_cast<HeavyState*>(fl + a.n_time);   // contact cells of a sweep-2 chunk
-    RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // phases 1-3 only (overlay)
-    double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
     if (a.use_tiers && threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
@@ -545,8 +659,6 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     }
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
-    const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
-    const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
     const long n = a.n;
     const double s2 = a.s2;
     const int n_time = a.n_time;
@@ -577,62 +689,16 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         if ((v >> 3) >= per_xcd || batch >= a.nbatch) continue;
         const long base = batch * B;
         const int nb = (int)((n - base < B) ? (n - base) : B);
-        double ysec = 0.0;
         TRX_TICK(t_pro);
-
-        // ---- phase 1: per-row constants, lanes = rows ----------------------------------
+        // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
+        {
+            const double* src = a.rowc + base * kRowDoubles;
+            double* dst = reinterpret_cast<double*>(rows);
+            for (int i = lane; i < nb * kRowDoubles; i += 64) dst[i] = src[i];
+        }
+        __syncthreads();
         if (lane < nb) {
-            const double* p = a.params + base + lane;
-            RowC& c = rows[lane];
-            double u1, u2;
-            if (a.model == TRX_MODEL_RAW) {
-                u1 = p[7 * n]; u2 = p[8 * n];
-                orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
-                c.xeb = 0.0; c.fdil = 0.0;
-            } else {
-                double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
-                if (a.model == TRX_MODEL_TP) {
-                    const double R_p = p[0];
-                    per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
-                    u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
-                    k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
-                } else {
-                    const double R_EB = p[0], eb_fr = p[1 * n];
-                    per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
-                    u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
-                    feb = eb_fr / (1.0 - eb_fr);                            // :401
-                    k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
-                    ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
-                }
-                const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
-                const double a_R = acm / (R_s * kRsun);                     // :343, :409
-                const double inc_r = inc * (kPi / 180.0);                   // :344, :410
-                const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
-                orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
-                if (!eblike) {
-                    c.xeb = 0.0;
-                    c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
-                } else {
-                    RowC& sc = srows[lane];
-                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
-                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
-                    const Limb L = limb_weights(u1, u2);
-                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
-                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
-                    if (is_host) {                                          // :427-432
-                        c.xeb = feb / fcomp;
-                        ysec = fcomp / feb;
-                        c.fdil = 1.0 / (fcomp + feb);
-                    } else {                                                // :433-438
-                        c.xeb = feb / 1.0;
-                        ysec = 1.0 / feb;
-                        c.fdil = fcomp / (1.0 + feb);
-                    }
-                }
-            }
-            const Limb L = limb_weights(u1, u2);
-            c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
-            c.excl = 0.0;
+            const RowC& c = rows[lane];
             hacc[lane] = 0.0;
             // an unocculted cell: 1 diluted is 1 (or NaN for a degenerate flux ratio)
             double m1 = 1.0;
@@ -641,38 +707,8 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             hmout[lane] = m1;
         }
         __syncthreads();
-
-        // ---- phases 2+3: secondary eclipse depth (EB families) --------------------------
-        if (eblike) {
-            for (int it = lane; it < nb * kSecPoints; it += 64) {
-                const int r = it / kSecPoints, j = it - r * kSecPoints;
-                const RowC sc = srows[r];
-                const Limb L{sc.cle, sc.cld, sc.ced};
-                double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
-                if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
-            }
-            __syncthreads();
-            if (lane < nb) {
-                double m = INFINITY;
-                bool has_nan = false;
-                for (int j = 0; j < kSecPoints; ++j) {
-                    const double f = sec[lane * kSecPoints + j];
-                    has_nan = has_nan || (f != f);
-                    m = (f < m) ? f : m;
-                }
-                if (has_nan) m = NAN;                                       // np.min propagates NaN
-                const double fd = rows[lane].fdil;
-                m = (m + ysec) / (1.0 + ysec);
-                const double secdepth = 1.0 - (m + fd) / (1.0 + fd);
-                rows[lane].excl = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;   // :535
-                if (MODE == MODE_GRID && a.out_sec) a.out_sec[base + lane] = secdepth;
-            }
-            __syncthreads();
-        }
-
-        // ---- phase 4: the cells of the batch ---------------------------------------------
         TRX_TOCK(0, t_pro);
+
         const int ncell = nb * n_time;
         for (int win0 = 0; win0 < ncell; win0 += kCellsWindow) {
             const int win1 = (win0 + kCellsWindow < ncell) ? (win0 + kCellsWindow) : ncell;
@@ -703,115 +739,96 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             __syncthreads();
             TRX_TOCK(1, t_p1);
             // pass 2: the in-window cells, 64 at a time.  A cell next to a limb contact evaluates
-            // all S sub-exposures, the others 3-9 nodes; the node loop of stage A runs to the
-            // largest count in the wave, and on a coarse time grid nearly every 64-cell chunk would
-            // hold a contact cell.  So the first sweep only files those cells (back into the list,
-            // behind the read cursor) and a second sweep takes them 64 at a time.
+            // all S sub-exposures, the others 3-9 nodes: the first sweep only files those cells
+            // (back into the list, behind the read cursor) and a second sweep takes them, so that
+            // pairs that may turn out to be off the disc stay out of the first sweep's trips.
             int nheavy = 0;
             for (int sweep = 0; sweep < 2; ++sweep) {
             const int count = sweep ? nheavy : nw;
             for (int w0 = 0; w0 < count; w0 += 64) {
                 TRX_TICK(t_plan);
-                const bool listed = (w0 + lane) < count;
-                bool valid = listed;
-                const int rel = (int)winlist[listed ? (w0 + lane) : (count - 1)];
+                bool valid = (w0 + lane) < count;
+                const int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
                 const int cell = win0 + rel;
                 int rr = (int)(((float)cell + 0.5f) * inv_nt);
                 rr = rr < nb ? rr : nb - 1;
                 const int j = cell - rr * n_time;
-#ifdef TRX_CELLS_ROW_BY_REF
-                const RowC& c = rows[rr];
-#else
-                const RowC c = rows[rr];
-#endif
-                const double t = tl[j];
                 CellPlan pl;
-                if (valid) pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                if (valid) pl = plan_cell<false>(rows[rr], tl[j], a.exptime, a.S, a.tiers, a.use_tiers != 0);
                 if (sweep == 0 && a.use_tiers) {
                     const bool heavy = valid && pl.tier < 0 && pl.n > 0;
                     const unsigned long long mh = __ballot(heavy);
                     if (heavy) { winlist[nheavy + lanes_below(mh)] = (unsigned short)rel; pl.n = 0; valid = false; }
                     nheavy += __popcll(mh);
                 }
-                rowof[lane] = (unsigned short)rr;
+                const int tier = pl.tier, nodes = valid ? pl.n : 0;
+                cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
+                cs.facc[lane] = 0.0;
+                cs.j[lane] = (unsigned short)j;
+                cs.tier[lane] = (signed char)tier;
+                cs.row[lane] = (unsigned char)rr;
+                cs.anchored[lane] = pl.anchored ? 1 : 0;
                 TRX_TOCK(2, t_plan);
-                TRX_TICK(t_rest);
-                const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
-                const double* ws = xs + kTiers * kTierMaxNodes;
-                const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
-                double fsum = 0.0;
-                // second sweep: every cell of the chunk evaluates all S sub-exposures, but a batch
-                // holds only a dozen such cells -- their (cell, sub-exposure) pairs are dealt to all
-                // 64 lanes (heavy_stage_a) instead of 12 lanes walking S trips each
-                const bool flat = (sweep == 1) && a.use_tiers;
-                const unsigned long long mflat = __ballot(flat && valid && pl.n > 0 && pl.anchored);
-                const int nh = __popcll(mflat);
-                if (flat && valid && pl.n > 0 && pl.anchored) {
-                    const int o = lanes_below(mflat);
-                    hs.sE[o] = pl.sE; hs.cE[o] = pl.cE; hs.t[o] = t;
-                    hs.lane[o] = (unsigned char)lane; hs.row[o] = (unsigned char)rr;
-                }
-                const int n_loop = (flat && pl.anchored) ? 0 : pl.n;
-                for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
-                    int n_in = 0, n_lb = 0, ns = 0;
-                    TRX_TICK(t_a);
-                    // stage A
-                    for (int si = 0; si < SB && __any(s0 + si < n_loop); ++si) {
-                        const int s = s0 + si + 1;
-                        int cls = 0;
-                        double vz = 1.0;
-                        if (s <= n_loop) {
-                            const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
-                            double Y;
-                            const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
-                            if (Y >= 0.0 && z2 < opp2) {
-                                vz = sqrt_fast(z2);
-                                cls = (c.k < 1.0 && vz <= omk) ? 1 : 2;
+                TRX_TICK(t_a);
+                // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
+                // takes as many nodes of every cell as fit the pair table (a first-sweep chunk in
+                // one pass; 64 contact cells x S = 20 sub-exposures in two).
+                const int ncells = __popcll(__ballot(nodes > 0));
+                int per = ncells > 0 ? kCellsPairs / ncells : kCellsPairs;
+                per = per > 1023 ? 1023 : per;
+                for (int s0 = 0; __any(s0 < nodes); s0 += per) {
+                    int cnt = nodes - s0;
+                    cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
+                    int total;
+                    const int off = lane_prefix<10>(cnt, total);
+                    for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
+                    __syncthreads();
+                    // one pair per lane: the orbit stepped from the cell's centre solution (|dM| <=
+                    // half an exposure), the Mandel-Agol flux, and the node's term added to the
+                    // cell's sum in LDS (ds_add_f64; a cell's pairs sit in consecutive lanes and the
+                    // LDS unit takes them in lane order: node order, bit-repeatable)
+                    for (int p0 = 0; p0 < total; p0 += 64) {
+                        const int p = p0 + lane;
+                        if (p < total) {
+                            const int d = (int)pdesc[p];
+                            const int h = d & 63, s = s0 + (d >> 6);
+                            const RowC& c = rows[cs.row[h]];
+                            const int ht = (int)cs.tier[h];
+                            const double t = tl[cs.j[h]];
+                            const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
+                                                         : tier_xw[ht * kTierMaxNodes + s];
+                            const double Mc = c.nmot * (t - c.t0) + c.Mtr;
+                            const double M = c.nmot * ((t + a.exptime * frac) - c.t0) + c.Mtr;
+                            double sE = cs.sE[h], cE = cs.cE[h];
+                            bool have = false;
+                            if (STEP && cs.anchored[h]) have = kepler_step(M - Mc, c.e, sE, cE);
+                            if (!have) kepler_full(M, c.e, sE, cE);
+                            const double ce = cE - c.e;
+                            const double X = fma(c.ax, ce, c.bx * sE);
+                            const double Y = fma(c.ay, ce, c.by * sE);
+                            const double yc = Y * c.cosi;
+                            const double z2 = fma(X, X, yc * yc);
+                            const double opp = 1.0 + c.k;
+                            double f = 1.0;
+                            if (Y >= 0.0 && z2 < opp * opp) {
+                                const Limb L{c.cle, c.cld, c.ced};
+                                f = disc_flux<FP32>(sqrt_fast(z2), c.k, L);
                             } else if (z2 != z2) {
-                                vz = z2;
+                                f = z2;
                             }
-                        }
-                        const int idx = si * 64 + lane;
-                        zbuf[idx] = vz;
-                        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-                        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
-                        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
-                        n_in += __popcll(m1);
-                        n_lb += __popcll(m2);
-                        ns = si + 1;
-                    }
-                    if (nh > 0 && s0 < a.S) {
-                        const int ns_pass = (a.S - s0 < SB) ? (a.S - s0) : SB;
-                        __syncthreads();
-                        heavy_stage_a<STEP>(hs, nh, s0, ns_pass, a, [&](int q) -> const RowC& { return rows[q]; },
-                                            zbuf, items, cap, lane, n_in, n_lb);
-                        ns = ns > ns_pass ? ns : ns_pass;
-                    }
-                    __syncthreads();
-                    TRX_TOCK(3, t_a);
-                    TRX_TICK(t_b);
-                    // stage B: an item's row comes with its lane of origin
-                    for (int i = lane; i < n_in + n_lb; i += 64) {
-                        const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
-                        const RowC& ic = rows[rowof[idx & 63]];
-                        const Limb L{ic.cle, ic.cld, ic.ced};
-                        zbuf[idx] = disc_flux<FP32>(zbuf[idx], ic.k, L);
-                    }
-                    __syncthreads();
-                    TRX_TOCK(4, t_b);
-                    // stage C
-                    for (int si = 0; si < ns; ++si) {
-                        const int s = s0 + si + 1;
-                        if (s <= pl.n) {
-                            const double f = zbuf[si * 64 + lane];
-                            fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
+                            const double term = (ht < 0) ? f : tier_xw[(kTiers + ht) * kTierMaxNodes + s] * (1.0 - f);
+                            if (ht < 0 || term != 0.0)
+                                __hip_atomic_fetch_add(&cs.facc[h], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                     __syncthreads();
                 }
-                double contrib = 0.0;
+                TRX_TOCK(3, t_a);
+                TRX_TICK(t_rest);
                 if (valid) {
-                    double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
+                    const RowC& c = rows[rr];
+                    const double fsum = cs.facc[lane];
+                    double m = (pl.n == 0) ? 1.0 : ((tier < 0) ? fsum / a.dS : 1.0 - fsum);
                     if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                     if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
                     if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
@@ -819,23 +836,15 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
                         // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1          :486, :537, :586
-                        contrib = ((1.0 - m) * ((fl[j] - m) + (fl[j] - 1.0))) / s2;
+                        const double f = fl[j];
+                        const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) / s2;
+                        // one LDS atomic per cell with a non-unit model: the wave's lanes meet on 2-3
+                        // accumulators and the LDS unit serialises them in a fixed order, so results
+                        // repeat bit for bit from run to run; a six-step shuffle reduction per chunk
+                        // costs ten times the latency (profiles/r02_d_cells_variants.txt)
+                        if (contrib != 0.0)
+                            __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                }
-                if (MODE == MODE_LNL) {
-#ifdef TRX_CELLS_SEGMENT_SUM
-                    // a deferred cell stays in its row's run (with a zero) so that runs stay contiguous
-                    bool head;
-                    const double ssum = segment_sum(contrib, listed ? rr : -1, lane, head);
-                    if (listed && head) hacc[rr] += ssum;
-#else
-                    // one LDS atomic per cell with a non-unit model (ds_add_f64): the wave's lanes
-                    // meet on 2-3 accumulators and the LDS unit serialises them in a fixed order,
-                    // so results repeat bit for bit from run to run; a six-step shuffle reduction
-                    // per chunk costs ten times the latency (profiles/r02_d_cells_variants.txt)
-                    if (valid && contrib != 0.0)
-                        __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                 }
                 TRX_TOCK(5, t_rest);
             }
@@ -851,10 +860,8 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     }
 #ifdef TRX_PHASE_TIMERS
     TRX_TOCK(7, t_all);
-    if (lane == 0) {
-        tm[5] -= tm[3] + tm[4];              // "rest" brackets the staged loop
+    if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
-    }
 #endif
 }
 
@@ -1309,11 +1316,11 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
     // 100, 4 at 200, whatever the row count -- larger batches fill the prologue lanes and the chunks
     // better, but the batches of a launch differ in work (rows with long transits), and with fewer,
     // longer waves the last round over the chip's ~3000 wave slots leaves more of them idle.
-    int B = (700 + a.n_time / 2) / a.n_time;
+    int B = (640 + a.n_time / 2) / a.n_time;
     B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
     const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
     if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
-    else while (B > 1 && a.n / B < 4096) B = (B + 1) / 2;     // few rows: fill the chip first
+    else while (B > 1 && a.n / B < 10000) B = (B + 1) / 2;    // few rows: fill the chip's 4096 wave slots first
     a.B = B;
     a.s2 = a.sigma * a.sigma;
     a.dS = (double)a.S;
@@ -1323,22 +1330,25 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
     const long want_grid = 8 * ((a.nbatch + 7) / 8);
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.SB = a.S < kCellsNodesPerPass ? a.S : kCellsNodesPerPass;
-    // zbuf + items + rowof + winlist; the phase 1-3 arrays overlay zbuf (+ what follows it)
-    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short))
-                + (64 + kCellsWindow) * sizeof(unsigned short);
-    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
-    // the staged light curve sits behind the slab: the overlay must not reach it (it is filled first)
-    if (slab < overlay) slab = (overlay + 7) & ~(size_t)7;
-    const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
+    // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
+    const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
+                      + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
+    static_assert((kCellsPairs + kCellsWindow) % 4 == 0 && sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
     a.tl_off = (int)(head / sizeof(double));
-    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double) + sizeof(HeavyState);
-    if (lds > 64 * 1024) return launch_rows_kernel<MODE>(a0, st);      // very long curves forced here by a test knob
+    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double);
+    if (lds > 64 * 1024 || a.n_time > 65535) return launch_rows_kernel<MODE>(a0, st);   // very long curves forced here by a test knob
+    // the row constants: 144 B per row of stream-ordered scratch, filled 64 rows per wave
+    void* scratch = nullptr;
+    TRX_HIP(hipMallocAsync(&scratch, (size_t)a.n * kRowDoubles * sizeof(double), st));
+    a.rowc = static_cast<double*>(scratch);
+    hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(256), 0, st, a);
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
     else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
     else            hipLaunchKernelGGL((cells_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
-    TRX_HIP(hipGetLastError());
+    const hipError_t launched = hipGetLastError();
+    TRX_HIP(hipFreeAsync(scratch, st));
+    TRX_HIP(launched);
     return TRX_OK;
 }
 
@@ -1391,7 +1401,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1403,7 +1413,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
