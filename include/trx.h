@@ -159,6 +159,9 @@ int trx_set_debug_node_counts(int on);
  *    a time across row boundaries) instead of the one-row-at-a-time kernel; 0 = never.  Model
  *    values are bit-identical between the two; chi^2 differs by summation order (~1e-16 relative). */
 int trx_set_cell_packing_below(int n_time);
+/*  - trx_set_long_pairs(0): longer light curves go through the staged one-row-at-a-time kernel of
+ *    round 1 instead of the pair-dealing kernel with one row per wave (A/B runs). */
+int trx_set_long_pairs(int on);
 
 /* ------------------------------------------------------------------------------------------
  * The per-draw half of one scenario evidence as ONE kernel (no reference counterpart as a single

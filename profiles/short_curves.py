@@ -1,5 +1,6 @@
 """Throughput of the likelihood kernel on SHORT light curves (the reference's operating point:
-100-200 binned points), 18 scenario families, one-row-at-a-time kernel vs packed-cell kernel.
+100-200 binned points), 18 scenario families: the staged one-row-at-a-time kernel of round 1
+(rows_kernel) and the pair-dealing kernel with one row / a batch of rows per wave (cells_kernel).
 usage: python profiles/short_curves.py [rows_per_family]   (TRX_LIB selects an A/B build)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +21,9 @@ for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
     blocks = [(_lib.dev(synth.family_rows(rng, fam, nr)), fam) for fam in synth.FAMILIES]
     out = torch.empty(nr, dtype=torch.float64, device="cuda")
     line = "n_time %5d:" % n_time
-    for name, below in (("row kernel", 0), ("packed cells", 1 << 30)):
+    for name, below, pairs in (("staged rows", 0, 0), ("one row per wave", 0, 1), ("row batches", 1 << 30, 1)):
         L.trx_set_cell_packing_below(below)
+        L.trx_set_long_pairs(pairs)
         def step():
             for r_d, fam in blocks:
                 _lib.lnl_batch(fam[1], _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0, t_d, f_d, synth.SIGMA, r_d,
@@ -32,6 +34,7 @@ for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
         for _ in range(3): step()
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 3
-        line += "  %s %.3f ms = %.3g evals/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
+        line += "  %s %.2f ms = %.3g/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
     L.trx_set_cell_packing_below(224)
+    L.trx_set_long_pairs(1)
     print(line)

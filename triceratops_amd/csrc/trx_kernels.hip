@@ -528,6 +528,17 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
     const int nb = (int)((n - base < 64) ? (n - base) : 64);
     double ysec = 0.0, fdil = 0.0;
     double* dst = a.rowc + (base + lane) * kRowDoubles;
+    if (blockIdx.x == 0 && a.flux && (lane >> 6) == 3) {
+        // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
+        // blocks: rows whose model is flat over the data get exactly this value and tie
+        double acc = 0.0;
+        for (int j = lane & 63; j < a.n_time; j += 64) {
+            const double d = a.flux[j] - 1.0;
+            acc += (d * d) / a.s2;
+        }
+        acc = wave_sum(acc);
+        if ((lane & 63) == 0) a.rowc[n * kRowDoubles] = acc;
+    }
     if (lane < nb) {
         const double* p = a.params + base + lane;
         RowC c;
@@ -613,10 +624,11 @@ static_assert(offsetof(RowC, excl) == (kRowDoubles - 1) * sizeof(double), "excl 
 // per-cell state of the chunk in flight (lane = cell), read by the lanes its pairs are dealt to
 struct CellState {
     double sE[64], cE[64];                  // eccentric anomaly at the exposure centre
+    double t[64];                           // exposure centre
     double facc[64];                        // the cell's sum over its nodes
-    unsigned short j[64];                   // time index
     signed char tier[64];                   // node set (-1 = all S sub-exposures)
     unsigned char row[64], anchored[64];
+    unsigned char pad[64];
 };
 
 // exclusive prefix sum over the lanes of a non-negative count < 2^BITS, and the wave total
@@ -634,11 +646,16 @@ __device__ __forceinline__ int lane_prefix(int cnt, int& total)
     return off;
 }
 
-template <int MODE, bool STEP, bool FP32>
+// LONG = false: a batch of B rows per wave, light curve staged in LDS, row constants read from the
+//               row blocks in LDS, chi^2 corrections in one LDS accumulator per row;
+// LONG = true:  one row per wave (light curves of kCellsLongFrom points and more): row constants in
+//               scalar registers, time stamps and fluxes read from global memory (a chunk's cells
+//               are mostly neighbours), chi^2 summed directly per lane and reduced once per row.
+template <int MODE, bool STEP, bool FP32, bool LONG>
 __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
 {
     extern __shared__ double lds[];
-    const int B = a.B;
+    const int B = LONG ? 1 : a.B;
     RowC* rows = reinterpret_cast<RowC*>(lds);
     double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 corrections per row
     double* hmout = hacc + B;                                         // [B] diluted model of an unocculted cell: 1, or NaN
@@ -646,10 +663,11 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
-    // the light curve itself: every chunk reads time stamps and fluxes of arbitrary cells, and a
-    // global load right before its use costs more than the chunk's other "rest" work
-    double* tl = lds + a.tl_off;                                      // [n_time]
-    double* fl = tl + a.n_time;                                       // [n_time] (MODE_LNL)
+    // short curves: the light curve itself in LDS -- every chunk reads time stamps and fluxes of
+    // arbitrary cells, and a global load right before its use costs more than the chunk's other
+    // "rest" work
+    const double* tl = LONG ? a.time : (lds + a.tl_off);              // [n_time]
+    const double* fl = LONG ? a.flux : (tl + a.n_time);               // [n_time] (MODE_LNL)
     if (a.use_tiers && threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
@@ -667,21 +685,15 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     TRX_TICK(t_all);
 #endif
-    // chi^2 of the flat model (every cell exactly 1), in ONE fixed order -- that of rows_kernel
-    double flat_sum = 0.0;
-    {
-        double acc = 0.0;
+    if (!LONG) {
+        double* tw = lds + a.tl_off;
         for (int j = lane; j < n_time; j += 64) {
-            tl[j] = a.time[j];
-            if (MODE == MODE_LNL) {
-                const double f = a.flux[j];
-                fl[j] = f;
-                const double d = f - 1.0;
-                acc += (d * d) / s2;
-            }
+            tw[j] = a.time[j];
+            if (MODE == MODE_LNL) tw[n_time + j] = a.flux[j];
         }
-        if (MODE == MODE_LNL) flat_sum = wave_sum(acc);
     }
+    // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
+    const double flat_sum = (MODE == MODE_LNL) ? a.rowc[n * kRowDoubles] : 0.0;
 
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -707,6 +719,17 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             hmout[lane] = m1;
         }
         __syncthreads();
+        // LONG: the row constants are wave-uniform -- held in scalar registers they cost no VGPRs
+        // and no LDS reads in the pair loop
+        RowC cu;
+        if (LONG) {
+            const double* src = reinterpret_cast<const double*>(&rows[0]);
+            double* dst = reinterpret_cast<double*>(&cu);
+#pragma unroll
+            for (int q = 0; q < kRowDoubles; ++q) dst[q] = uniform(src[q]);
+        }
+        double lacc = 0.0;                 // LONG: this lane's share of the row's chi^2
+        bool nonflat = false;              // LONG: a cell of this lane has a model value other than 1
         TRX_TOCK(0, t_pro);
 
         const int ncell = nb * n_time;
@@ -718,12 +741,15 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             for (int c0 = win0; c0 < win1; c0 += 64) {
                 const int cell = c0 + lane;
                 const bool valid = cell < win1;
-                int rr = valid ? (int)(((float)cell + 0.5f) * inv_nt) : (nb - 1);
-                rr = rr < nb ? rr : nb - 1;
-                const int j = valid ? (cell - rr * n_time) : 0;
+                int rr = 0, j = valid ? cell : 0;
+                if (!LONG) {
+                    rr = valid ? (int)(((float)cell + 0.5f) * inv_nt) : (nb - 1);
+                    rr = rr < nb ? rr : nb - 1;
+                    j = valid ? (cell - rr * n_time) : 0;
+                }
                 bool inw = false;
                 if (valid) {
-                    const RowC& c = rows[rr];
+                    const RowC& c = LONG ? cu : rows[rr];
                     const double phase = c.nmot * (tl[j] - c.t0);
                     const double dMc = reduce_2pi(phase);
                     const double slack = 1e-15 * fabs(phase);
@@ -731,6 +757,10 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                     // no occultation anywhere in the exposure: the model is 1, diluted
                     if (MODE == MODE_GRID && !inw)
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
+                    if (LONG && MODE == MODE_LNL && !inw) {
+                        const double d = fl[j] - 1.0;
+                        lacc += (d * d) / s2;                                   // :486, :537, :586
+                    }
                 }
                 const unsigned long long mw = __ballot(inw);
                 if (inw) winlist[nw + lanes_below(mw)] = (unsigned short)(cell - win0);
@@ -750,11 +780,17 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 bool valid = (w0 + lane) < count;
                 const int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
                 const int cell = win0 + rel;
-                int rr = (int)(((float)cell + 0.5f) * inv_nt);
-                rr = rr < nb ? rr : nb - 1;
-                const int j = cell - rr * n_time;
+                int rr = 0, j = cell;
+                if (!LONG) {
+                    rr = (int)(((float)cell + 0.5f) * inv_nt);
+                    rr = rr < nb ? rr : nb - 1;
+                    j = cell - rr * n_time;
+                }
+                const double t = tl[j];
+                double fobs = 0.0;
+                if (LONG && MODE == MODE_LNL) fobs = fl[j];          // in flight during the chunk
                 CellPlan pl;
-                if (valid) pl = plan_cell<false>(rows[rr], tl[j], a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                if (valid) pl = plan_cell<false>(LONG ? cu : rows[rr], t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
                 if (sweep == 0 && a.use_tiers) {
                     const bool heavy = valid && pl.tier < 0 && pl.n > 0;
                     const unsigned long long mh = __ballot(heavy);
@@ -763,8 +799,8 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 }
                 const int tier = pl.tier, nodes = valid ? pl.n : 0;
                 cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
+                cs.t[lane] = t;
                 cs.facc[lane] = 0.0;
-                cs.j[lane] = (unsigned short)j;
                 cs.tier[lane] = (signed char)tier;
                 cs.row[lane] = (unsigned char)rr;
                 cs.anchored[lane] = pl.anchored ? 1 : 0;
@@ -792,13 +828,13 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         if (p < total) {
                             const int d = (int)pdesc[p];
                             const int h = d & 63, s = s0 + (d >> 6);
-                            const RowC& c = rows[cs.row[h]];
+                            const RowC& c = LONG ? cu : rows[cs.row[h]];
                             const int ht = (int)cs.tier[h];
-                            const double t = tl[cs.j[h]];
+                            const double tc = cs.t[h];
                             const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
                                                          : tier_xw[ht * kTierMaxNodes + s];
-                            const double Mc = c.nmot * (t - c.t0) + c.Mtr;
-                            const double M = c.nmot * ((t + a.exptime * frac) - c.t0) + c.Mtr;
+                            const double Mc = c.nmot * (tc - c.t0) + c.Mtr;
+                            const double M = c.nmot * ((tc + a.exptime * frac) - c.t0) + c.Mtr;
                             double sE = cs.sE[h], cE = cs.cE[h];
                             bool have = false;
                             if (STEP && cs.anchored[h]) have = kepler_step(M - Mc, c.e, sE, cE);
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 TRX_TOCK(3, t_a);
                 TRX_TICK(t_rest);
                 if (valid) {
-                    const RowC& c = rows[rr];
+                    const RowC& c = LONG ? cu : rows[rr];
                     const double fsum = cs.facc[lane];
                     double m = (pl.n == 0) ? 1.0 : ((tier < 0) ? fsum / a.dS : 1.0 - fsum);
                     if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
@@ -835,15 +871,21 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                     if (MODE == MODE_GRID) {
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
-                        // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1          :486, :537, :586
-                        const double f = fl[j];
-                        const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) / s2;
-                        // one LDS atomic per cell with a non-unit model: the wave's lanes meet on 2-3
-                        // accumulators and the LDS unit serialises them in a fixed order, so results
-                        // repeat bit for bit from run to run; a six-step shuffle reduction per chunk
-                        // costs ten times the latency (profiles/r02_d_cells_variants.txt)
-                        if (contrib != 0.0)
-                            __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (LONG) {
+                            // the row's own lanes sum (f - m)^2 / sigma^2 directly    :486, :537, :586
+                            const double d = fobs - m;
+                            lacc += (d * d) / s2;
+                            nonflat = nonflat || (m != 1.0);
+                        } else {
+                            // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1: one LDS atomic per cell with a
+                            // non-unit model -- the wave's lanes meet on 2-3 accumulators and the LDS unit
+                            // serialises them in a fixed order, so results repeat bit for bit from run
+                            // to run; a six-step shuffle reduction per chunk costs ten times the latency
+                            const double f = fl[j];
+                            const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) / s2;
+                            if (contrib != 0.0)
+                                __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
                 TRX_TOCK(5, t_rest);
@@ -851,10 +893,20 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             }
             __syncthreads();
         }
-        if (MODE == MODE_LNL && lane < nb) {
-            double h = (hmout[lane] == 1.0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
-            if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
-            a.out[base + lane] = h;
+        if (MODE == MODE_LNL) {
+            if (LONG) {
+                // a row whose model is flat over the data takes the launch's flat-model value, so
+                // that such rows tie exactly whatever their windows (their lanes would sum the same
+                // terms in different orders)
+                const double direct = wave_sum(lacc);
+                double h = (hmout[0] == 1.0) ? 0.5 * (__any(nonflat) ? direct : flat_sum) : NAN;
+                if (a.model == TRX_MODEL_EB && cu.excl != 0.0) h = INFINITY;      // :535-538
+                if (lane == 0) a.out[base] = h;
+            } else if (lane < nb) {
+                double h = (hmout[lane] == 1.0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
+                if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
+                a.out[base + lane] = h;
+            }
         }
         __syncthreads();
     }
@@ -1305,22 +1357,28 @@ int launch_rows_kernel(const RowsArgs& a0, hipStream_t st)
 }
 
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{224};
+std::atomic<int> g_cells_below{272};
+
+// one row per wave through cells_kernel<LONG> (1) or the staged rows_kernel (0): A/B switch
+std::atomic<int> g_long_pairs{1};
 
 template <int MODE>
-int launch_cells(const RowsArgs& a0, hipStream_t st)
+int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
 {
     RowsArgs a = a0;
-    // about 700 cells per wave, at most kCellsMaxRows rows (LDS overlay of the prologue arrays).
-    // Measured (profiles/r02_d_cells_batch_sweep.txt): the best batch is 11 rows at 50 points, 6-8 at
-    // 100, 4 at 200, whatever the row count -- larger batches fill the prologue lanes and the chunks
-    // better, but the batches of a launch differ in work (rows with long transits), and with fewer,
-    // longer waves the last round over the chip's ~3000 wave slots leaves more of them idle.
-    int B = (640 + a.n_time / 2) / a.n_time;
-    B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
-    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
-    if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
-    else while (B > 1 && a.n / B < 10000) B = (B + 1) / 2;    // few rows: fill the chip's 4096 wave slots first
+    // short curves: about 640 cells per wave, at most kCellsMaxRows rows.  Measured
+    // (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 --
+    // larger batches fill the chunks better, but the batches of a launch differ in work (rows with
+    // long transits), and with fewer, longer waves the last round over the chip's wave slots leaves
+    // more of them idle.
+    int B = 1;
+    if (!long_rows) {
+        B = (640 + a.n_time / 2) / a.n_time;
+        B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
+        const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
+        if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
+        else while (B > 1 && a.n / B < 10000) B = (B + 1) / 2;    // few rows: fill the chip's 4096 wave slots first
+    }
     a.B = B;
     a.s2 = a.sigma * a.sigma;
     a.dS = (double)a.S;
@@ -1335,17 +1393,30 @@ int launch_cells(const RowsArgs& a0, hipStream_t st)
                       + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
     static_assert((kCellsPairs + kCellsWindow) % 4 == 0 && sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
     a.tl_off = (int)(head / sizeof(double));
-    const size_t lds = head + (size_t)2 * a.n_time * sizeof(double);
-    if (lds > 64 * 1024 || a.n_time > 65535) return launch_rows_kernel<MODE>(a0, st);   // very long curves forced here by a test knob
-    // the row constants: 144 B per row of stream-ordered scratch, filled 64 rows per wave
+    size_t lds = head + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
+    if (lds > 64 * 1024) {             // a long curve forced through the batched variant by a test knob
+        long_rows = true;
+        lds = head;
+        a.B = 1;
+        a.nbatch = a.n;
+    }
+    // the row constants: 144 B per row of stream-ordered scratch (+ the flat-model chi^2), filled 64 rows per wave
     void* scratch = nullptr;
-    TRX_HIP(hipMallocAsync(&scratch, (size_t)a.n * kRowDoubles * sizeof(double), st));
+    TRX_HIP(hipMallocAsync(&scratch, ((size_t)a.n * kRowDoubles + 1) * sizeof(double), st));
     a.rowc = static_cast<double*>(scratch);
     hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(256), 0, st, a);
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    if (!g_step.load(std::memory_order_relaxed)) hipLaunchKernelGGL((cells_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
-    else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
-    else            hipLaunchKernelGGL((cells_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
+    const bool step = g_step.load(std::memory_order_relaxed) != 0;
+    const unsigned g2 = long_rows ? (unsigned)(8 * ((a.n + 7) / 8) < max_grid ? 8 * ((a.n + 7) / 8) : max_grid) : grid;
+    if (long_rows) {
+        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true>), dim3(g2), dim3(64), lds, st, a);
+        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true>), dim3(g2), dim3(64), lds, st, a);
+        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true>), dim3(g2), dim3(64), lds, st, a);
+    } else {
+        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, false>), dim3(g2), dim3(64), lds, st, a);
+        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, false>), dim3(g2), dim3(64), lds, st, a);
+        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false>), dim3(g2), dim3(64), lds, st, a);
+    }
     const hipError_t launched = hipGetLastError();
     TRX_HIP(hipFreeAsync(scratch, st));
     TRX_HIP(launched);
@@ -1356,7 +1427,9 @@ template <int MODE>
 int launch_rows(const RowsArgs& a0, hipStream_t st)
 {
     if (a0.n_time < g_cells_below.load(std::memory_order_relaxed) && a0.n_time > 0)
-        return launch_cells<MODE>(a0, st);
+        return launch_cells<MODE>(a0, st, false);
+    if (g_long_pairs.load(std::memory_order_relaxed) && a0.n_time > 0)
+        return launch_cells<MODE>(a0, st, true);
     return launch_rows_kernel<MODE>(a0, st);
 }
 
@@ -1548,7 +1621,14 @@ int trx_set_rows_per_wave(int rows)
     return TRX_OK;
 }
 
-/* diagnostics (include/trx.h): light curves with fewer points than this use the packed-cell kernel */
+/* diagnostics (include/trx.h): 0 = longer light curves through the staged rows_kernel */
+int trx_set_long_pairs(int on)
+{
+    g_long_pairs.store(on ? 1 : 0, std::memory_order_relaxed);
+    return TRX_OK;
+}
+
+/* diagnostics (include/trx.h): light curves with fewer points than this are processed in batches of rows per wave */
 int trx_set_cell_packing_below(int n_time)
 {
     if (n_time < 0) return fail(TRX_ERR_ARG, "n_time threshold must be >= 0%s (got %ld)", "", (long)n_time);
