@@ -141,15 +141,21 @@ def collect_pmc(args):
                 return None
             if p.returncode != 0:
                 return None
-            per = {}
+            # one likelihood launch = rowc_kernel (row constants to scratch) + cells_kernel<lnl>: both counted
+            per, prologue = {}, 0.0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if "rows_kernel<0" in row["Kernel_Name"].replace(" ", "") and row["Counter_Name"] == counter:
+                        if row["Counter_Name"] != counter:
+                            continue
+                        name = row["Kernel_Name"].replace(" ", "")
+                        if "cells_kernel<0" in name:
                             per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                        elif "rowc_kernel" in name:
+                            prologue += float(row["Counter_Value"])
             if not per:
                 return None
-            got[counter] = (float(np.mean(list(per.values()))), len(per))
+            got[counter] = ((float(np.sum(list(per.values()))) + prologue) / len(per), len(per))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 on the read side; KB units
@@ -409,7 +415,7 @@ def run_grid(ctx):
         # no census in this run: price every cell at ONE model evaluation (a lower bound of the executed work)
         achieved = (F_ORBIT + F_MA) * cells_per_launch / mean_launch_s / 1e12
         roof.update({"achieved": achieved, "frac": achieved / FP64_VALU_PEAK_TF, "traffic": None})
-    roof["note"] = ("dominant kernel rows_kernel<lnl> is fp64-VALU bound (no MFMA shape, ~0.05 B/eval of HBM "
+    roof["note"] = ("dominant kernel cells_kernel<lnl, one row per wave> (+ its prologue rowc_kernel, 2 %% of the launch) is fp64-VALU bound (no MFMA shape, ~0.05 B/eval of HBM "
                     "traffic). achieved = executed model evaluations (census of this run) x %d plain operations / "
                     "launch time. plain_algorithm_* prices the launch as if all %d sub-exposures of every cell "
                     "had been evaluated; the kernel reaches those averages (to 1e-13) from 3-9 Gauss nodes, so "

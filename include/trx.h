@@ -140,7 +140,8 @@ int trx_flux_grid_host(int model, int flags,
 int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out);
 
 /* Tuning knob for benchmarks/tests (process-wide, like the diagnostics below): rows staged per
- * wavefront (1..22, clamped to 16 by the one-row-at-a-time kernel; 0 = automatic). */
+ * wavefront of the batched variant (light curves below trx_set_cell_packing_below's threshold), 1..22;
+ * 0 = automatic. */
 int trx_set_rows_per_wave(int rows);
 
 /* Diagnostics (process-wide switches, default 1 / 1 / 0; no reference counterpart):
@@ -148,20 +149,17 @@ int trx_set_rows_per_wave(int rows);
  *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
  *    model is analytic (the two agree to ~1e-13 in flux);
  *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
- *    previous one;
+ *    exposure centre's solution;
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
  *    for each cell instead of the flux. */
 int trx_set_supersample_tiers(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
-/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 224) go through
- *    the packed-cell kernel (a wave walks the (row, time) cells of ~2048 cells' worth of rows, 64 at
- *    a time across row boundaries) instead of the one-row-at-a-time kernel; 0 = never.  Model
- *    values are bit-identical between the two; chi^2 differs by summation order (~1e-16 relative). */
+/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 272) are
+ *    processed in batches of rows per wave (the (row, time) cells of ~640 cells' worth of rows walked
+ *    64 at a time across row boundaries, light curve staged in LDS), longer ones one row per wave;
+ *    0 = never.  Model values agree to rounding between the two; chi^2 differs by summation order. */
 int trx_set_cell_packing_below(int n_time);
-/*  - trx_set_long_pairs(0): longer light curves go through the staged one-row-at-a-time kernel of
- *    round 1 instead of the pair-dealing kernel with one row per wave (A/B runs). */
-int trx_set_long_pairs(int on);
 
 /* ------------------------------------------------------------------------------------------
  * The per-draw half of one scenario evidence as ONE kernel (no reference counterpart as a single

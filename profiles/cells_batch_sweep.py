@@ -29,4 +29,4 @@ for n_time in times:
         line += "  B=%s %.2f" % (B if B else "auto", a.elapsed_time(b) / 3)
     print(line + "  (ms per 18 launches)")
 L.trx_set_rows_per_wave(0)
-L.trx_set_cell_packing_below(224)
+L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)

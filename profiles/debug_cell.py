@@ -28,4 +28,4 @@ for name, below, tiers in (("rows", 0, 1), ("cells", 1 << 30, 1), ("rows-notiers
     dr = np.abs(g[r] - wg[r]); print("   row", r, "params", rows[:, r], "worst cells", np.argsort(dr)[-3:], dr[np.argsort(dr)[-3:]], "h", h[r], wh[r])
     # chi2 from the grid itself
     hg = 0.5 * np.sum((flux - g[r]) ** 2 / synth.SIGMA ** 2); print("   chi2/2 from this kernel's grid:", hg)
-L.trx_set_cell_packing_below(224); L.trx_set_supersample_tiers(1)
+L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW); L.trx_set_supersample_tiers(1)

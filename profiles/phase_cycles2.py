@@ -27,4 +27,4 @@ for fam in (synth.FAMILIES[0], synth.FAMILIES[1]):
         v = np.array(list(out), dtype=float)
         print("%s n_time=%d %s: %.3f ms; wave-cycles per row %.0f;" % (fam[0], n_time, "cells" if below else "rows ", a.elapsed_time(b), v[7] / n),
               " ".join("%s %.1f%%" % (nm, 100 * x / v[7]) for nm, x in zip(names[below], v) if nm not in ("-", "total")))
-L.trx_set_cell_packing_below(224)
+L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)

@@ -1,6 +1,6 @@
 """Throughput of the likelihood kernel on SHORT light curves (the reference's operating point:
-100-200 binned points), 18 scenario families: the staged one-row-at-a-time kernel of round 1
-(rows_kernel) and the pair-dealing kernel with one row / a batch of rows per wave (cells_kernel).
+100-200 binned points), 18 scenario families: cells_kernel with one row per wave (LONG) and with a
+batch of rows per wave.
 usage: python profiles/short_curves.py [rows_per_family]   (TRX_LIB selects an A/B build)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,9 +21,8 @@ for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
     blocks = [(_lib.dev(synth.family_rows(rng, fam, nr)), fam) for fam in synth.FAMILIES]
     out = torch.empty(nr, dtype=torch.float64, device="cuda")
     line = "n_time %5d:" % n_time
-    for name, below, pairs in (("staged rows", 0, 0), ("one row per wave", 0, 1), ("row batches", 1 << 30, 1)):
+    for name, below in (("one row per wave", 0), ("row batches", 1 << 30)):
         L.trx_set_cell_packing_below(below)
-        L.trx_set_long_pairs(pairs)
         def step():
             for r_d, fam in blocks:
                 _lib.lnl_batch(fam[1], _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0, t_d, f_d, synth.SIGMA, r_d,
@@ -35,6 +34,5 @@ for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 3
         line += "  %s %.2f ms = %.3g/s" % (name, ms, n_time * nr * 18 / ms * 1e3)
-    L.trx_set_cell_packing_below(224)
-    L.trx_set_long_pairs(1)
+    L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
     print(line)

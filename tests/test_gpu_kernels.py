@@ -201,7 +201,7 @@ def test_packed_cell_kernel_equals_row_kernel(model, n_time):
             h = _lib.lnl_batch(model, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, synth.NSAMPLES)
             res[name] = (g.cpu().numpy(), s.cpu().numpy(), h.cpu().numpy())
     finally:
-        L.trx_set_cell_packing_below(224)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
         L.trx_set_rows_per_wave(0)
     g0, s0, h0 = res["rows"]
     for name in ("cells", "cells7", "cells1"):
@@ -220,7 +220,7 @@ def test_packed_cell_kernel_equals_row_kernel(model, n_time):
 
 def test_packed_cell_kernel_raw_model_and_census():
     """pytransit-shaped rows through the packed-cell kernel: equals the oracle, and the census knob
-    reports the same plans as the one-row-at-a-time kernel"""
+    reports the same plans as the one-row-per-wave variant"""
     rng = np.random.default_rng(77)
     rows = _raw_stress_rows(rng, 700)
     rows = np.ascontiguousarray(rows[:, rows[0] <= 1.0][:, :333])
@@ -238,7 +238,7 @@ def test_packed_cell_kernel_raw_model_and_census():
                                            want_secdepth=False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
-        L.trx_set_cell_packing_below(224)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
     assert np.array_equal(counts[0], counts[1 << 30])
 
 
@@ -260,7 +260,7 @@ def test_second_near_side_passage_on_a_very_eccentric_orbit():
             got, _ = _lib.flux_grid(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(row), synth.EXPTIME, synth.NSAMPLES)
             assert np.abs(got.cpu().numpy() - want).max() < ATOL_FLUX, below
     finally:
-        L.trx_set_cell_packing_below(224)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
 
 
 def test_rows_with_a_flat_model_tie_exactly():
@@ -284,7 +284,7 @@ def test_rows_with_a_flat_model_tie_exactly():
             assert np.unique(h[flat]).size == 1 and np.unique(h[~flat]).size > 3000
             vals[below] = h[flat][0]
     finally:
-        L.trx_set_cell_packing_below(224)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
     assert vals[0] == vals[1 << 30]
     assert abs(vals[0] / (0.5 * np.sum((flux - 1.0) ** 2 / synth.SIGMA ** 2)) - 1) < 1e-13
 
@@ -457,12 +457,12 @@ def test_mixed_precision_model_tolerance(n_time):
 
 
 def test_large_batches_spot_checked():
-    """3e6 rows x 48 points (packed-cell kernel, 22 rows per wave; and the one-row-at-a-time kernel
-    with 1 row per wave, which walks the grid-stride loop over > 2^20 batches with the XCD-aware
-    batch mapping) and 200 rows x 20000 points: random rows against the oracle, and no cross-row
-    state: the same rows launched alone give the same chi^2 -- bitwise in the one-row-at-a-time
-    kernel, to summation order (1e-11) in the packed-cell kernel, whose per-row sum is split at
-    the 64-cell chunk boundaries the row happens to straddle."""
+    """3e6 rows x 48 points (batches of rows per wave; and one row per wave, which walks the
+    grid-stride loop over > 2^20 batches with the XCD-aware batch mapping) and 200 rows x 20000
+    points: random rows against the oracle, and no cross-row state: the same rows launched alone
+    give the same chi^2 -- bitwise with one row per wave, to summation order (1e-11) in batches,
+    where a row's cells share 64-cell chunks with its neighbours' (the Kepler stepping of a chunk
+    runs until its slowest lane has converged)."""
     rng, t, flux = _lc(48, seed=9)
     rows = synth.tp_rows(rng, 3_000_000, True)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)
@@ -480,7 +480,7 @@ def test_large_batches_spot_checked():
         alone1 = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows[:, pick]), synth.EXPTIME, 20).cpu().numpy()
     finally:
         L.trx_set_rows_per_wave(0)
-        L.trx_set_cell_packing_below(224)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
     assert np.array_equal(alone1, h1[pick])
     assert np.abs(h1 / h - 1).max() < 1e-11, np.abs(h1 / h - 1).max()
     rng, t, flux = _lc(20000, seed=10)

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "trx_lnl_batch", "trx_flux_grid", "trx_chi2_grid", "trx_workspace_bytes",
     "trx_log_mean_exp", "trx_lnz_scenario", "trx_lnz_from_halfchi2", "trx_lnl_batch_host", "trx_flux_grid_host",
     "trx_log_mean_exp_host", "trx_set_rows_per_wave", "trx_set_supersample_tiers",
-    "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_set_long_pairs", "trx_draw_scenario", "trx_draw_args_size", "trx_version", "trx_last_error",
+    "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_version", "trx_last_error",
     "trx_device_count",
 )
 
@@ -35,6 +35,8 @@ class TrxError(RuntimeError):
 # flags OR-ed into every likelihood launch of the lnZ_* / calc_probs layer: set_precision("fp32")
 # puts TRX_FLAG_FP32_MODEL here (BASELINE config 5); the plain wrappers below take explicit flags
 EXTRA_FLAGS = 0
+# library default of trx_set_cell_packing_below (tests and A/B scripts restore it)
+CELL_PACKING_BELOW = 272
 # work counters of the scenario layer (bench.py reads them): rows and (row, time) cells that
 # went through trx_lnz_scenario since the last reset
 STATS = {"rows": 0, "cells": 0, "launches": 0}
@@ -104,8 +106,6 @@ def lib():
     L.trx_set_supersample_tiers.argtypes = [c_int]
     L.trx_set_debug_node_counts.restype = c_int
     L.trx_set_debug_node_counts.argtypes = [c_int]
-    L.trx_set_long_pairs.restype = c_int
-    L.trx_set_long_pairs.argtypes = [c_int]
     L.trx_set_cell_packing_below.restype = c_int
     L.trx_set_cell_packing_below.argtypes = [c_int]
     L.trx_version.restype = ctypes.c_char_p

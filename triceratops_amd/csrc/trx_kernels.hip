@@ -1,19 +1,20 @@
 // libtrx.so: HIP kernels + C ABI (include/trx.h) for gfx950.
 //
 // Kernels
-//   rows_kernel<MODE, STEP, FP32>
-//                             one wavefront (64-thread workgroup) per batch of B Monte-Carlo
-//                             rows, 4 waves per SIMD.  Phase 1: lanes < B derive the per-row
-//                             constant block (unit conversion, radius-ratio rule, orbit
-//                             constants, transit window, dilution, limb weights) in place in
-//                             LDS.  Phases 2-3 (EB): the B x 25 secondary-eclipse cells are
-//                             spread over the lanes, lanes < B reduce them to the secondary
-//                             depth / exclusion flag.  Phase 4: for each row the lanes take 64
-//                             consecutive time stamps; every lane plans its cell (none, 3-9
-//                             Gauss nodes or all S sub-exposures), the (cell, node)
-//                             evaluations of the chunk are packed by case through LDS, and the
-//                             result is either wave-reduced to chi^2 (MODE_LNL, shuffle
-//                             butterfly) or stored as the model row (MODE_GRID).
+//   rowc_kernel               per-row constants (unit conversion, radius-ratio rule, orbit
+//                             constants, transit window, dilution, limb weights) of 64 rows per
+//                             workgroup, lanes = rows; for EB rows the 25-point secondary-eclipse
+//                             scan with lanes = (row, point) -> depth / exclusion flag.  Output:
+//                             one 18-double block per row in stream-ordered scratch.
+//   cells_kernel<MODE, STEP, FP32, LONG>
+//                             the light-curve model and its chi^2.  One wavefront (64-thread
+//                             workgroup) per row (LONG) or per batch of rows (short curves); the
+//                             transit-window test files the in-window (row, time) cells in LDS,
+//                             each lane plans one cell (none, 3-9 Gauss nodes or all S
+//                             sub-exposures), and the (cell, node) pairs of 64 cells are dealt to
+//                             all lanes: orbit step from the cell's centre solution, Mandel-Agol
+//                             flux, term added to the cell's sum in LDS.  Result: chi^2/2 per row
+//                             (MODE_LNL) or the model row (MODE_GRID).
 //   chi2_grid_kernel          row reduction over a materialised (n, n_time) grid, HBM bound.
 //   lme_partial_kernel / lme_final_kernel
 //                             log-mean-exp: single pass online (max, sum exp) per thread,
@@ -65,7 +66,7 @@ struct RowsArgs {
     double* out_sec;   // MODE_GRID: [n] or null
     int B;
     long nbatch;
-    int use_tiers, SB, debug_nodes;
+    int use_tiers, debug_nodes;
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     TierTable tiers;
@@ -73,15 +74,6 @@ struct RowsArgs {
     // computing them in the kernel parks them in long-lived vector registers
     double s2, dS, rS;
 };
-
-// nodes of a 64-cell chunk staged in LDS per pass: 10 x 64 x (8 + 2) B = 6.3 KB per wave (+ 1.6 KB
-// of contact-cell state), so that LDS never limits the 16 waves per CU the register budget allows;
-// 10 covers every reduced node set (3-9 nodes) in one pass, the all-sub-exposure cells take two
-// (profiles/r01_k_ab_pack.txt: 20 -> 11.70 ms, 12 -> 11.24, 10 -> 11.26, 8 -> 11.41 at 3 waves/SIMD)
-#ifndef TRX_NODES_PER_PASS
-#define TRX_NODES_PER_PASS 10
-#endif
-constexpr int kMaxNodesPerPass = TRX_NODES_PER_PASS;
 
 // a wave-uniform double moved to a scalar register pair
 __device__ __forceinline__ double uniform(double v)
@@ -118,382 +110,39 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
     return k;
 }
 
-// register budget: with the staged evaluation the kernel waits on LDS round trips between its
-// stages and gains from a 4th wave per SIMD (128 VGPRs): 11.24 -> 10.53 ms per launch.  That
-// budget holds without scratch because the row constants ride in SGPRs in the time loop and are
-// built in place in LDS in the prologue (12 B/lane left, once per row); 5 waves spill into the
-// hot loops (14.4 ms).  profiles/r01_k_ab_pack.txt
-#ifndef TRX_WAVES_PER_EU
-#define TRX_WAVES_PER_EU 4
-#endif
-
-// Centre state of the contact cells of a chunk, staged in LDS for the flattened stage A below.
-struct HeavyState {
-    double sE[64], cE[64], t[64];
-    unsigned char lane[64], row[64];
-};
-
-// Stage A for the cells next to a limb contact ("heavy": all S sub-exposures are evaluated).
-// A lane that walks its own S sub-exposures keeps the wave in the node loop for S trips while the
-// cells with 3-9 Gauss nodes idle; a chunk at ingress or egress holds ~10 such cells, so more than
-// half of stage A was spent in chunks running at a third of their lanes.  Here the (cell, sub-
-// exposure) pairs of the chunk's heavy cells are dealt to ALL lanes: every pair steps the orbit
-// from its cell's exposure-centre solution (|dM| <= half an exposure) and files its z like the
-// per-lane loop does, into zbuf[si * 64 + lane of the cell].
-//   rowc(r): orbit constants of row r (wave-uniform in rows_kernel, per-lane in cells_kernel)
-template <bool STEP, class RowFn>
-__device__ __forceinline__ void heavy_stage_a(const HeavyState& hs, int nh, int s0, int ns_pass,
-                                              const RowsArgs& a, RowFn rowc, double* zbuf,
-                                              unsigned short* items, int cap, int lane, int& n_in,
-                                              int& n_lb)
-{
-    const int total = nh * ns_pass;
-    const float inv = 1.0f / (float)ns_pass;
-    for (int w0 = 0; w0 < total; w0 += 64) {
-        const int w = w0 + lane;
-        const bool on = w < total;
-        int h = on ? (int)(((float)w + 0.5f) * inv) : 0;
-        h = h < nh ? h : nh - 1;
-        const int si = on ? (w - h * ns_pass) : 0;
-        const RowC& c = rowc((int)hs.row[h]);
-        int cls = 0;
-        double vz = 1.0;
-        int idx = 0;
-        if (on) {
-            const double t = hs.t[h];
-            const double frac = fma((double)(s0 + si + 1) - 0.5, a.rS, -0.5);
-            const double Mc = c.nmot * (t - c.t0) + c.Mtr;
-            const double M = c.nmot * ((t + a.exptime * frac) - c.t0) + c.Mtr;
-            double sE = hs.sE[h], cE = hs.cE[h];
-            bool have = false;
-            if (STEP) have = kepler_step(M - Mc, c.e, sE, cE);
-            if (!have) kepler_full(M, c.e, sE, cE);
-            const double ce = cE - c.e;
-            const double X = fma(c.ax, ce, c.bx * sE);
-            const double Y = fma(c.ay, ce, c.by * sE);
-            const double yc = Y * c.cosi;
-            const double z2 = fma(X, X, yc * yc);
-            const double opp = 1.0 + c.k, omk = 1.0 - c.k;
-            if (Y >= 0.0 && z2 < opp * opp) {
-                vz = sqrt_fast(z2);
-                cls = (c.k < 1.0 && vz <= omk) ? 1 : 2;
-            } else if (z2 != z2) {
-                vz = z2;
-            }
-            idx = si * 64 + (int)hs.lane[h];
-            zbuf[idx] = vz;
-        }
-        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
-        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
-        n_in += __popcll(m1);
-        n_lb += __popcll(m2);
-    }
-}
-
-template <int MODE, bool STEP, bool FP32>
-__global__ __launch_bounds__(64, TRX_WAVES_PER_EU) void rows_kernel(RowsArgs a)
-{
-    extern __shared__ double lds[];
-    const int B = a.B;
-    RowC* rows = reinterpret_cast<RowC*>(lds);
-    double* tier_xw = lds + (size_t)B * kRowDoubles;                  // [x | w] of the tier table
-    const int SB = a.SB;                                              // nodes per lane per pass
-    const int cap = 64 * SB;
-    double* zbuf = tier_xw + 2 * kTiers * kTierMaxNodes;              // [SB][64] z in, flux out
-    unsigned short* items = reinterpret_cast<unsigned short*>(zbuf + cap);   // [cap] case lists
-    HeavyState& hs = *reinterpret_cast<HeavyState*>(items + cap);     // contact cells of the chunk (8-byte aligned: cap is a multiple of 64)
-    // the secondary-eclipse orbit blocks and scan values live only through phases 1-3: they
-    // overlay the slab, which only the time loop uses (so rows per wave cost 144 B of LDS each)
-    RowC* srows = reinterpret_cast<RowC*>(zbuf);                      // [B] secondary-eclipse orbits
-    double* sec = zbuf + (size_t)B * kRowDoubles;                     // [B][25]
-    if (a.use_tiers && threadIdx.x == 0) {
-        // constant indices only: a dynamically indexed by-value kernel argument is copied to scratch
-#pragma unroll
-        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
-            tier_xw[i] = a.tiers.x[i];
-            tier_xw[kTiers * kTierMaxNodes + i] = a.tiers.w[i];
-        }
-    }
-    const int lane = threadIdx.x;
-    const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
-    const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
-    const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
-    const long n = a.n;
-    const double s2 = a.s2;
-
-    // Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one), each with its own L2.
-    // A row's 10-11 parameters are single 8-byte reads from 10-11 arrays, eight neighbouring rows
-    // per 64 B line: with batch = block index every XCD fetches every line.  So virtual block v
-    // takes batch (v % 8) * ceil(nbatch / 8) + v / 8: each XCD works through one contiguous
-    // eighth of the rows and its L2 sees each parameter line once (FETCH_SIZE 34 -> 7 MB).
-#ifdef TRX_PHASE_TIMERS
-    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    TRX_TICK(t_all);
-#endif
-    const long per_xcd = (a.nbatch + 7) / 8;
-    for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
-        const long batch = (v & 7) * per_xcd + (v >> 3);
-        if ((v >> 3) >= per_xcd || batch >= a.nbatch) continue;
-        const long base = batch * B;
-        const int nb = (int)((n - base < B) ? (n - base) : B);
-        double ysec = 0.0;
-        TRX_TICK(t_pro);
-
-        // ---- phase 1: per-row constants ------------------------------------------------
-        if (lane < nb) {
-            const double* p = a.params + base + lane;
-            // built in place in LDS: a local copy keeps 36 VGPRs live across the libm calls of
-            // orbit_init and pushes the prologue into scratch
-            RowC& c = rows[lane];
-            double u1, u2;
-            if (a.model == TRX_MODEL_RAW) {
-                u1 = p[7 * n]; u2 = p[8 * n];
-                orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
-                c.xeb = 0.0; c.fdil = 0.0;
-            } else {
-                double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
-                if (a.model == TRX_MODEL_TP) {
-                    const double R_p = p[0];
-                    per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
-                    u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
-                    k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
-                } else {
-                    const double R_EB = p[0], eb_fr = p[1 * n];
-                    per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
-                    u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
-                    feb = eb_fr / (1.0 - eb_fr);                            // :401
-                    k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
-                    ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
-                }
-                const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
-                const double a_R = acm / (R_s * kRsun);                     // :343, :409
-                const double inc_r = inc * (kPi / 180.0);                   // :344, :410
-                const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
-                orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
-                if (!eblike) {
-                    c.xeb = 0.0;
-                    c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
-                } else {
-                    RowC& sc = srows[lane];
-                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
-                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
-                    const Limb L = limb_weights(u1, u2);
-                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
-                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
-                    if (is_host) {                                          // :427-432
-                        c.xeb = feb / fcomp;
-                        ysec = fcomp / feb;
-                        c.fdil = 1.0 / (fcomp + feb);
-                    } else {                                                // :433-438
-                        c.xeb = feb / 1.0;
-                        ysec = 1.0 / feb;
-                        c.fdil = fcomp / (1.0 + feb);
-                    }
-                }
-            }
-            const Limb L = limb_weights(u1, u2);
-            c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
-            c.excl = 0.0;
-        }
-        __syncthreads();
-
-        // ---- phases 2+3: secondary eclipse depth (EB families) --------------------------
-        if (eblike) {
-            for (int it = lane; it < nb * kSecPoints; it += 64) {
-                const int r = it / kSecPoints, j = it - r * kSecPoints;
-                const RowC sc = srows[r];
-                const Limb L{sc.cle, sc.cld, sc.ced};
-                // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
-                double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
-                if (j == kSecPoints - 1) ts = 0.05;
-                sec[it] = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
-            }
-            __syncthreads();
-            if (lane < nb) {
-                double m = INFINITY;
-                bool has_nan = false;
-                for (int j = 0; j < kSecPoints; ++j) {
-                    const double f = sec[lane * kSecPoints + j];
-                    has_nan = has_nan || (f != f);
-                    m = (f < m) ? f : m;
-                }
-                if (has_nan) m = NAN;                                       // np.min propagates NaN
-                const double fd = rows[lane].fdil;
-                m = (m + ysec) / (1.0 + ysec);
-                const double secdepth = 1.0 - (m + fd) / (1.0 + fd);
-                rows[lane].excl = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;   // :535
-                if (MODE == MODE_GRID && a.out_sec) a.out_sec[base + lane] = secdepth;
-            }
-            __syncthreads();
-        }
-
-        // ---- phase 4: the light-curve model over the time axis --------------------------
-        // Lanes are 64 consecutive time stamps of one row.  Neighbouring cells need different
-        // numbers of model evaluations (3-9 nodes, all S sub-exposures near the contacts, none
-        // off the disc), so the evaluations are not run where they are found.  Stage A: each lane
-        // plans its cell, advances the orbit along its nodes and files every occulted node, by
-        // case (disc inside the limb / crossing it), in a list in LDS.  Stage B: the Mandel-Agol
-        // flux over the lists, 64 items of ONE case per pass.  Stage C: each lane sums its cell's
-        // nodes in their original order.
-        TRX_TOCK(0, t_pro);
-        for (int r = 0; r < nb; ++r) {
-            // the row constants are wave-uniform: held in scalar registers they cost no VGPRs
-            // (36 otherwise, which at 128 VGPRs per lane spill into the time loop)
-            RowC c;
-            {
-                const double* src = reinterpret_cast<const double*>(&rows[r]);
-                double* dst = reinterpret_cast<double*>(&c);
-#pragma unroll
-                for (int q = 0; q < kRowDoubles; ++q) dst[q] = uniform(src[q]);
-            }
-            const Limb L{c.cle, c.cld, c.ced};
-            const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
-            double acc = 0.0;
-            for (int j0 = 0; j0 < a.n_time; j0 += 64) {
-                const int j = j0 + lane;
-                const bool valid = j < a.n_time;
-                const double t = valid ? a.time[j] : 0.0;
-                CellPlan pl;
-                TRX_TICK(t_plan);
-                if (valid) pl = plan_cell(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
-                TRX_TOCK(1, t_plan);
-                TRX_TICK(t_rest);
-                const double* xs = tier_xw + (pl.tier < 0 ? 0 : pl.tier) * kTierMaxNodes;
-                const double* ws = xs + kTiers * kTierMaxNodes;
-                double fsum = 0.0;
-                // contact cells (all S sub-exposures) are taken out of the per-lane node loop and
-                // their (cell, sub-exposure) pairs dealt to all lanes (heavy_stage_a)
-                const bool heavy = valid && pl.tier < 0 && pl.n > 0 && pl.anchored;
-                const unsigned long long mheavy = __ballot(heavy);
-                const int nh = __popcll(mheavy);
-                const int n_loop = heavy ? 0 : pl.n;
-                if (heavy) {
-                    const int o = lanes_below(mheavy);
-                    hs.sE[o] = pl.sE; hs.cE[o] = pl.cE; hs.t[o] = t;
-                    hs.lane[o] = (unsigned char)lane; hs.row[o] = 0;
-                }
-                for (int s0 = 0; __any(s0 < pl.n); s0 += SB) {
-                    int n_in = 0, n_lb = 0, ns = 0;
-                    TRX_TICK(t_a);
-                    // stage A
-                    for (int si = 0; si < SB && __any(s0 + si < n_loop); ++si) {
-                        const int s = s0 + si + 1;
-                        int cls = 0;
-                        double v = 1.0;
-                        if (s <= n_loop) {
-                            const double frac = (pl.tier < 0) ? fma((double)s - 0.5, a.rS, -0.5) : xs[s - 1];
-                            double Y;
-                            const double z2 = node_z2(c, pl, t, a.exptime, frac, STEP, Y);
-                            if (Y >= 0.0 && z2 < opp2) {
-                                v = sqrt_fast(z2);
-                                cls = (c.k < 1.0 && v <= omk) ? 1 : 2;
-                            } else if (z2 != z2) {
-                                v = z2;
-                            }
-                        }
-                        const int idx = si * 64 + lane;
-                        zbuf[idx] = v;
-                        const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-                        if (cls == 1) items[n_in + lanes_below(m1)] = (unsigned short)idx;
-                        if (cls == 2) items[cap - 1 - (n_lb + lanes_below(m2))] = (unsigned short)idx;
-                        n_in += __popcll(m1);
-                        n_lb += __popcll(m2);
-                        ns = si + 1;
-                    }
-                    if (nh > 0 && s0 < a.S) {
-                        const int ns_pass = (a.S - s0 < SB) ? (a.S - s0) : SB;
-                        __syncthreads();
-                        heavy_stage_a<STEP>(hs, nh, s0, ns_pass, a, [&](int) -> const RowC& { return c; }, zbuf,
-                                            items, cap, lane, n_in, n_lb);
-                        ns = ns > ns_pass ? ns : ns_pass;
-                    }
-                    __syncthreads();
-                    TRX_TOCK(2, t_a);
-                    TRX_TICK(t_b);
-                    // stage B: inside items, then the rest, back to back: at most one pass holds both
-                    // cases (they share the cel loop, so the mixed pass costs less than a padded extra one)
-                    for (int i = lane; i < n_in + n_lb; i += 64) {
-                        const int idx = (i < n_in) ? items[i] : items[cap - 1 - (i - n_in)];
-                        zbuf[idx] = disc_flux<FP32>(zbuf[idx], c.k, L);
-                    }
-                    __syncthreads();
-                    TRX_TOCK(3, t_b);
-                    // stage C
-                    for (int si = 0; si < ns; ++si) {
-                        const int s = s0 + si + 1;
-                        if (s <= pl.n) {
-                            const double f = zbuf[si * 64 + lane];
-                            fsum += (pl.tier < 0) ? f : ws[s - 1] * (1.0 - f);
-                        }
-                    }
-                    __syncthreads();
-                }
-                if (valid) {
-                    double m = (pl.n == 0) ? 1.0 : ((pl.tier < 0) ? fsum / a.dS : 1.0 - fsum);
-                    if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
-                    if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
-                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
-                    if (MODE == MODE_GRID) {
-                        a.out[(size_t)(base + r) * a.n_time + j] = m;
-                    } else {
-                        const double d = a.flux[j] - m;
-                        acc += (d * d) / s2;                                // :486, :537, :586
-                    }
-                }
-                TRX_TOCK(4, t_rest);
-            }
-            if (MODE == MODE_LNL) {
-                double h = 0.5 * wave_sum(acc);
-                if (a.model == TRX_MODEL_EB && c.excl != 0.0) h = INFINITY; // :535-538
-                if (lane == 0) a.out[base + r] = h;
-            }
-        }
-        __syncthreads();
-    }
-#ifdef TRX_PHASE_TIMERS
-    TRX_TOCK(7, t_all);
-    if (lane == 0) {
-        tm[4] -= tm[2] + tm[3];              // "rest" brackets the staged loop
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
-    }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------
-// Short light curves (the reference's real operating point is 100-200 binned points,
-// examples/TSCIII_tutorial.ipynb cell 4): rowc_kernel + cells_kernel.  rows_kernel loses lanes there
-// four ways: the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at 100
-// points, profiles/r01_r_phase_cycles.txt), a 100-point row fills 64 + 36 lanes, a 64-cell chunk of
-// a coarse time grid spans 0.3 d, so in- and out-of-transit cells share every chunk and the lanes
-// of the out-of-window cells idle through the plan and the orbit stage (a 2000-point chunk spans
-// 0.016 d and is all in or all out), and the in-window cells of such a chunk have unrelated node
-// counts (3-9 Gauss nodes, S next to a contact), so a per-lane node loop runs to the largest.
-//   * rowc_kernel derives the row constants of 64 rows per wave -- lanes = rows, then lanes =
+// The likelihood path: rowc_kernel + cells_kernel.
+// Round 1's kernel took one row at a time, 64 consecutive time stamps per trip, every lane walking
+// its own cell's nodes.  That loses lanes four ways, the more the shorter the light curve (the
+// reference's real operating point is 100-200 binned points, examples/TSCIII_tutorial.ipynb cell
+// 4): the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at 100 points,
+// profiles/r01_r_phase_cycles.txt); a 100-point row fills 64 + 36 lanes; a 64-cell chunk of a
+// coarse time grid spans 0.3 d, so in- and out-of-transit cells share every chunk and the lanes of
+// the out-of-window cells idle through the plan and the orbit stage; and neighbouring cells have
+// different node counts (3-9 Gauss nodes, S next to a contact), so a per-lane node loop runs to
+// the largest.  Here
+//   * rowc_kernel derives the row constants of 64 rows per workgroup -- lanes = rows, then lanes =
 //     (row, point) for the secondary-eclipse scan -- and stores the 18-double blocks in device
 //     scratch (144 B per row, stream-ordered allocation inside the call);
-//   * cells_kernel takes a batch of B <= 22 rows per wave and loads their blocks into LDS.  The
-//     (row, time) cells of the batch form ONE index space, cell = r * n_time + j, walked in windows
-//     of kCellsWindow cells: pass 1 applies the transit-window test to 64 cells at a time across row
-//     boundaries, settles the out-of-window cells (model exactly 1) and files the in-window ones,
+//   * cells_kernel takes one row (LONG, 272 points and more) or a batch of B <= 22 rows per wave.
+//     The (row, time) cells form ONE index space, cell = r * n_time + j, walked in windows of
+//     kCellsWindow cells: pass 1 applies the transit-window test to 64 cells at a time (across row
+//     boundaries), settles the out-of-window cells (model exactly 1) and files the in-window ones,
 //     in order, in a list in LDS; pass 2 takes that list 64 cells at a time: each lane plans its
 //     cell (Kepler solve at the exposure centre + node count), then the (cell, node) PAIRS of the
-//     chunk are dealt to all 64 lanes: stage A steps each pair's orbit from its cell's centre
-//     solution and files its z by case, stage B runs the Mandel-Agol flux over the case lists,
-//     stage C has each cell sum its own pairs in node order.  Every stage runs full lanes whatever
-//     the mix of node counts.  Cells next to a limb contact (all S sub-exposures) are filed again
-//     and take a second sweep, 64 of them at a time, so that their S pairs per cell do not dilute
-//     the case lists of the first sweep's chunks;
-//   * a lane's row constants come from the row blocks in LDS (cells of different rows share a
-//     wave, so they cannot ride in SGPRs);
-//   * chi^2 of a row = chi^2 of the flat model (every cell exactly 1: one number per launch, summed
-//     in rows_kernel's order) + the corrections ((f-m)^2 - (f-1)^2)/sigma^2 of its in-window
-//     cells, added to one LDS accumulator per row.  The window pass therefore touches no flux, and
-//     draws whose model is flat over the data tie EXACTLY (the reference's argsort orders such
-//     ties in the best-fit table); grid mode stores cell = output offset.
-// The device functions and node tables are those of rows_kernel; the two kernels agree to
-// rounding in the model (a node is reached from the exposure centre here, from the previous node
-// there) and to summation order in chi^2.
+//     chunk are dealt to all 64 lanes: a pair steps the orbit from its cell's centre solution,
+//     evaluates the Mandel-Agol flux and adds its term to the cell's sum in LDS.  Every stage runs
+//     full lanes whatever the mix of node counts.  Cells next to a limb contact (all S
+//     sub-exposures, some of them off the disc) are filed again and take a second sweep, so that
+//     the first sweep's pairs are all on the disc;
+//   * batches: a lane's row constants come from the row blocks in LDS (cells of different rows share
+//     a wave); chi^2 of a row = chi^2 of the flat model (every cell exactly 1: one number per
+//     launch) + the corrections ((f-m)^2 - (f-1)^2)/sigma^2 of its in-window cells, added to one
+//     LDS accumulator per row: the window pass touches no flux, and draws whose model is flat over
+//     the data tie EXACTLY (the reference's argsort orders such ties in the best-fit table);
+//   * LONG: the row constants ride in scalar registers, time stamps and fluxes are read from global
+//     memory, and the lanes sum (f-m)^2/sigma^2 directly (a perfect fit gives exactly 0); a row
+//     with a flat model takes the launch's flat-model value, so those rows tie exactly as well.
 #ifndef TRX_CELLS_WAVES_PER_EU
 #define TRX_CELLS_WAVES_PER_EU 4
 #endif
@@ -507,8 +156,7 @@ constexpr int kCellsMaxRows = 22;
 constexpr int kCellsWindow = TRX_CELLS_WINDOW;     // cells per window pass (in-window list in LDS)
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
-// Row constants of 64 rows per wave (phases 1-3 of rows_kernel with every lane on a row of its
-// own), written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
+// Row constants of 64 rows per workgroup, every lane of the first wave on a row of its own, written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
 // 256 threads per 64 rows: the first wave derives the constants (lanes = rows), then the 64 x 25
 // (row, point) cells of the secondary-eclipse scan are dealt to all four waves -- the scan is an
 // eighth of an EB row's work at 100 points, and one wave per 64 rows leaves the chip a third full.
@@ -790,7 +438,15 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 double fobs = 0.0;
                 if (LONG && MODE == MODE_LNL) fobs = fl[j];          // in flight during the chunk
                 CellPlan pl;
-                if (valid) pl = plan_cell<false>(LONG ? cu : rows[rr], t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                if (valid) {
+                    const RowC& c = LONG ? cu : rows[rr];
+                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                    if (STEP && !pl.anchored && pl.n > 0) {
+                        // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
+                        kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
+                        pl.anchored = true;
+                    }
+                }
                 if (sweep == 0 && a.use_tiers) {
                     const bool heavy = valid && pl.tier < 0 && pl.n > 0;
                     const unsigned long long mh = __ballot(heavy);
@@ -899,11 +555,11 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 // that such rows tie exactly whatever their windows (their lanes would sum the same
                 // terms in different orders)
                 const double direct = wave_sum(lacc);
-                double h = (hmout[0] == 1.0) ? 0.5 * (__any(nonflat) ? direct : flat_sum) : NAN;
+                double h = (hmout[0] == 1.0 || n_time == 0) ? 0.5 * (__any(nonflat) ? direct : flat_sum) : NAN;
                 if (a.model == TRX_MODEL_EB && cu.excl != 0.0) h = INFINITY;      // :535-538
                 if (lane == 0) a.out[base] = h;
             } else if (lane < nb) {
-                double h = (hmout[lane] == 1.0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
+                double h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
                 if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
                 a.out[base + lane] = h;
             }
@@ -1318,49 +974,8 @@ bool fill_tiers(TierTable& T, int S)
     return ok;
 }
 
-int pick_rows_per_wave(int n_time, long n)
-{
-    const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
-    if (forced > 0) return forced > 16 ? 16 : forced;
-    // measured (profiles/r01_n_rows_per_wave.txt): rows are processed one after the other by the
-    // wave, so more rows per wave only amortise the prologue's idle lanes while making fewer,
-    // longer waves.  4 is best up to ~250 points, 2 up to ~1000, 1 at 2000.
-    int B = (n_time >= 1024) ? 1 : ((n_time >= 256) ? 2 : 4);
-    while (B > 1 && n / B < 8192) B >>= 1;
-    return B;
-}
-
-template <int MODE>
-int launch_rows_kernel(const RowsArgs& a0, hipStream_t st)
-{
-    RowsArgs a = a0;
-    a.B = pick_rows_per_wave(a.n_time, a.n);
-    a.s2 = a.sigma * a.sigma;
-    a.dS = (double)a.S;
-    a.rS = 1.0 / a.dS;
-    a.nbatch = (a.n + a.B - 1) / a.B;
-    const long max_grid = 1L << 20;
-    const long want_grid = 8 * ((a.nbatch + 7) / 8);          // a multiple of 8: v % 8 == blockIdx % 8
-    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
-    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.SB = a.S < kMaxNodesPerPass ? a.S : kMaxNodesPerPass;
-    size_t slab = (size_t)64 * a.SB * (sizeof(double) + sizeof(unsigned short)) + sizeof(HeavyState);
-    const size_t overlay = (size_t)a.B * (kRowDoubles + kSecPoints) * sizeof(double);   // phases 1-3 only
-    if (slab < overlay) slab = overlay;
-    const size_t lds = ((size_t)a.B * kRowDoubles + 2 * kTiers * kTierMaxNodes) * sizeof(double) + slab;
-    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    if (!g_step.load(std::memory_order_relaxed))    hipLaunchKernelGGL((rows_kernel<MODE, false, false>), dim3(grid), dim3(64), lds, st, a);
-    else if (fp32)  hipLaunchKernelGGL((rows_kernel<MODE, true, true>), dim3(grid), dim3(64), lds, st, a);
-    else            hipLaunchKernelGGL((rows_kernel<MODE, true, false>), dim3(grid), dim3(64), lds, st, a);
-    TRX_HIP(hipGetLastError());
-    return TRX_OK;
-}
-
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
 std::atomic<int> g_cells_below{272};
-
-// one row per wave through cells_kernel<LONG> (1) or the staged rows_kernel (0): A/B switch
-std::atomic<int> g_long_pairs{1};
 
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
@@ -1426,11 +1041,8 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
 template <int MODE>
 int launch_rows(const RowsArgs& a0, hipStream_t st)
 {
-    if (a0.n_time < g_cells_below.load(std::memory_order_relaxed) && a0.n_time > 0)
-        return launch_cells<MODE>(a0, st, false);
-    if (g_long_pairs.load(std::memory_order_relaxed) && a0.n_time > 0)
-        return launch_cells<MODE>(a0, st, true);
-    return launch_rows_kernel<MODE>(a0, st);
+    const bool batches = a0.n_time > 0 && a0.n_time < g_cells_below.load(std::memory_order_relaxed);
+    return launch_cells<MODE>(a0, st, !batches);
 }
 
 int launch_lme(const double* logw, const double* h, const double* lnprior, double c0, long n,
@@ -1474,7 +1086,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1486,7 +1098,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1618,13 +1230,6 @@ int trx_set_rows_per_wave(int rows)
     if (rows < 0 || rows > kCellsMaxRows)
         return fail(TRX_ERR_ARG, "rows per wave must be 0 (automatic) .. 22%s (got %ld)", "", (long)rows);
     g_rows_per_wave = rows;
-    return TRX_OK;
-}
-
-/* diagnostics (include/trx.h): 0 = longer light curves through the staged rows_kernel */
-int trx_set_long_pairs(int on)
-{
-    g_long_pairs.store(on ? 1 : 0, std::memory_order_relaxed);
     return TRX_OK;
 }
 
