@@ -13,9 +13,13 @@
  *   - pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()) unless the
  *     function name ends in _host;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
- *     stream) and the call returns without synchronising; no allocation and no
- *     host-device sync inside the enqueue functions: safe to capture into a hipGraph and
- *     to call concurrently on different streams / devices.  The library's only state is
+ *     stream) and the call returns without synchronising: safe to call concurrently on
+ *     different streams / devices.  The entry points that evaluate the light-curve model
+ *     (trx_lnl_batch, trx_flux_grid, trx_lnz_scenario) take 144 B per row of scratch for the
+ *     per-row constants from the device's default stream-ordered memory pool
+ *     (hipMallocAsync / hipFreeAsync on `stream`: no synchronisation, and after the first
+ *     calls no driver allocation -- the pool's release threshold is raised once per device);
+ *     the others allocate nothing.  The library's only state is
  *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
  *     read-only afterwards) and (ii) the process-wide tuning / diagnostics switches declared
  *     at the end of this header (atomics read once per enqueue; meant for benchmarks and

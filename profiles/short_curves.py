@@ -1,7 +1,7 @@
 """Throughput of the likelihood kernel on SHORT light curves (the reference's operating point:
 100-200 binned points), 18 scenario families: cells_kernel with one row per wave (LONG) and with a
 batch of rows per wave.
-usage: python profiles/short_curves.py [rows_per_family]   (TRX_LIB selects an A/B build)"""
+usage: python profiles/short_curves.py [rows_per_family [n_time ...]]   (TRX_LIB selects an A/B build)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,7 +11,7 @@ n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 L = _lib.lib()
 print("# %s, %d rows per family, 18 families; evals/s = n_time x rows x 18 / time of the 18 launches" % (
     os.path.basename(_lib.LIB_PATH), n_rows))
-for n_time in (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000):
+for n_time in ([int(x) for x in sys.argv[2:]] or (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000)):
     rng = np.random.default_rng(synth.SEED)
     t = synth.time_grid(n_time)
     t_d = _lib.dev(t)

@@ -263,11 +263,12 @@ def test_second_near_side_passage_on_a_very_eccentric_orbit():
         L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
 
 
-def test_rows_with_a_flat_model_tie_exactly():
-    """draws whose model is exactly 1 over the data window share ONE chi^2 value bit for bit, in
-    both kernels and wherever the row sits in its batch (the reference's argsort then orders the
-    ties; a 1-ulp scatter would scramble the tail of the best-fit table)"""
-    rng, t, flux = _lc(100)
+@pytest.mark.parametrize("n_time", [100, 700])
+def test_rows_with_a_flat_model_tie_exactly(n_time):
+    """draws whose model is exactly 1 over the data window share ONE chi^2 value bit for bit, with
+    one row or a batch of rows per wave and wherever the row sits in its batch (the reference's
+    argsort then orders the ties; a 1-ulp scatter would scramble the tail of the best-fit table)"""
+    rng, t, flux = _lc(n_time)
     rows = synth.tp_rows(rng, 5000, True)
     rows[2, rng.random(5000) < 0.3] = 20.0     # inc = 20 deg: (almost) never transits
     t_d, r_d = _lib.dev(t), _lib.dev(rows)
@@ -314,6 +315,11 @@ def test_empty_and_single():
     empty = torch.empty((10, 0), dtype=torch.float64, device="cuda")
     out = _lib.lnl_batch(0, 0, _lib.dev(t), _lib.dev(flux), synth.SIGMA, empty, synth.EXPTIME, 20)
     assert out.numel() == 0
+    # an empty light curve: chi^2 = 0 for every draw, +inf where the EB secondary rule excludes it
+    rows = synth.eb_rows(rng, 300, True)
+    got = _lib.lnl_batch(1, 0, _lib.dev(t[:0]), _lib.dev(flux[:0]), synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20).cpu().numpy()
+    want = O.lnl_batch(1, t[:0], flux[:0], synth.SIGMA, rows)
+    assert np.array_equal(got, want) and set(np.unique(got)) <= {0.0, np.inf}
 
 
 def test_chi2_grid_matches_fused_and_oracle():

@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <cstddef>
+#include <cstdint>
 #include <mutex>
 
 #include "../../include/trx.h"
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         }
     }
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
-    const double flat_sum = (MODE == MODE_LNL) ? a.rowc[n * kRowDoubles] : 0.0;
+    const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? a.rowc[n * kRowDoubles] : 0.0;
 
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -974,6 +975,25 @@ bool fill_tiers(TierTable& T, int S)
     return ok;
 }
 
+// The scratch of a likelihood call comes from the device's default stream-ordered pool.  By default
+// that pool hands freed memory back to the driver at the next synchronisation, and the next call
+// pays a driver allocation; once per device the release threshold is raised so that the pool keeps
+// what it has served (at most the scratch of the calls in flight: 144 B per row each).
+int keep_scratch_pool()
+{
+    constexpr int kMaxDevices = 64;
+    static std::atomic<bool> done[kMaxDevices];
+    int dev = 0;
+    TRX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices || done[dev].load(std::memory_order_acquire)) return TRX_OK;
+    hipMemPool_t pool;
+    TRX_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+    uint64_t keep = UINT64_MAX;
+    TRX_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    done[dev].store(true, std::memory_order_release);
+    return TRX_OK;
+}
+
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
 std::atomic<int> g_cells_below{272};
 
@@ -1016,6 +1036,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         a.nbatch = a.n;
     }
     // the row constants: 144 B per row of stream-ordered scratch (+ the flat-model chi^2), filled 64 rows per wave
+    if (int rc = keep_scratch_pool()) return rc;
     void* scratch = nullptr;
     TRX_HIP(hipMallocAsync(&scratch, ((size_t)a.n * kRowDoubles + 1) * sizeof(double), st));
     a.rowc = static_cast<double*>(scratch);
