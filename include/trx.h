@@ -15,11 +15,14 @@
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
  *     stream) and the call returns without synchronising: safe to call concurrently on
  *     different streams / devices.  The entry points that evaluate the light-curve model
- *     (trx_lnl_batch, trx_flux_grid, trx_lnz_scenario) take 144 B per row of scratch for the
- *     per-row constants from the device's default stream-ordered memory pool
- *     (hipMallocAsync / hipFreeAsync on `stream`: no synchronisation, and after the first
- *     calls no driver allocation -- the pool's release threshold is raised once per device);
- *     the others allocate nothing.  The library's only state is
+ *     (trx_lnl_batch, trx_flux_grid, trx_lnz_scenario, trx_scenario_evidence) keep scratch per
+ *     (device, stream) inside the library -- 144 B per row for the per-row constants, the draw
+ *     block of trx_scenario_evidence -- which serves call after call on that stream and only
+ *     grows (the stream is synchronised before a buffer is replaced by a larger one);
+ *     trx_release_scratch() frees it all.  Do not enqueue on ONE stream from two host threads
+ *     at once.  trx_lnl_batch, trx_flux_grid, trx_lnz_scenario and the reductions can be captured
+ *     into a hipGraph (while `stream` is capturing, the scratch is a pair of graph memory nodes).
+ *     The library's only other state is
  *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
  *     read-only afterwards) and (ii) the process-wide tuning / diagnostics switches declared
  *     at the end of this header (atomics read once per enqueue; meant for benchmarks and
@@ -259,6 +262,38 @@ typedef struct {
 
 int trx_draw_scenario(const trx_draw_args* args, void* stream);
 size_t trx_draw_args_size(void);   /* sizeof(trx_draw_args): lets a foreign binding check its layout */
+
+/* One lnZ_* call of calc_probs end to end (the body of e.g. lnZ_TTP, marginal_likelihoods.py:39-172,
+ * as calc_probs uses it, triceratops.py:797-817: it keeps the best draw and lnZ of each scenario):
+ * draw kernel -> ordered compaction of the geometry mask(s) -> lnL_*_p of the masked draws ->
+ * _log_mean_exp(lnL [+ lnprior_companion], N_total = N) -> the draw with the smallest chi^2
+ * (first of equals, NaN first: numpy's / torch's argmin).  Planet scenarios give one branch, binary
+ * scenarios two (q < 0.95 at P_orb, q >= 0.95 at 2 P_orb).
+ *   draw      as for trx_draw_scenario; its output pointers (cols, mask, mask_twin, lnprior, flag,
+ *             dump) are ignored: the buffers are stream-ordered scratch of the call
+ *   out       HOST, [branches][TRX_SCENARIO_OUT]: the best draw's columns (11 or 14, the layout
+ *             of trx_draw_args.cols; draw 0 when no draw passes the mask), then lnZ, then the
+ *             number of draws that passed the mask
+ *   out_flag  HOST, [1]: trx_draw_args.flag
+ * The call synchronises `stream` twice (the masked counts size the likelihood launches; the
+ * result) and returns with `out` filled. */
+#define TRX_SCENARIO_OUT 16
+typedef struct {
+    const trx_draw_args* draw;
+    const double* time;          /* [n_time] device */
+    const double* flux;          /* [n_time] device */
+    int n_time, nsupersample;
+    double sigma, lnsigma, exptime;
+    int flags;                   /* TRX_FLAG_* of trx_lnl_batch */
+    int want_prior;              /* lnprior_companion enters the evidence (P, S, D, B scenarios) */
+    double* out;
+    int* out_flag;
+} trx_scenario_args;
+int trx_scenario_evidence(const trx_scenario_args* args, void* stream);
+size_t trx_scenario_args_size(void);
+
+/* Frees the per-stream scratch described above (every device); all streams must be idle. */
+int trx_release_scratch(void);
 
 const char* trx_version(void);
 const char* trx_last_error(void);

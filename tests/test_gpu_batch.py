@@ -143,3 +143,40 @@ def test_threaded_units_give_the_same_results_as_one_thread():
     print("6 TOIs x 18 x N=3e5: 1 thread %.3f s, 3 threads %.3f s" % (one[2], thr_b[2]))
     assert np.array_equal(one[0], thr_a[0], equal_nan=True) and np.array_equal(one[1], thr_a[1])
     assert np.array_equal(thr_a[0], thr_b[0], equal_nan=True)
+
+
+def test_native_scenario_call_equals_the_torch_operator_path():
+    """trx_scenario_evidence (draws -> compaction -> likelihood -> evidence -> best draw in one library
+    call) against the chain of torch operators around trx_draw_scenario / trx_lnz_scenario on the same
+    Philox keys: every lnZ, every best-fit column and FPP / NFPP bit for bit, on all 18 scenarios of
+    several TOIs, with a contrast curve, in fp64 and in the mixed-precision mode"""
+    import triceratops_amd
+    from triceratops_amd import fused, sharding
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    cols = ("M_s", "R_s", "P_orb", "inc", "b", "R_p", "ecc", "w", "M_EB", "R_EB", "prob")
+    attrs = ("lnZ", "u1", "u2", "fluxratio_EB", "fluxratio_comp", "star_num")
+    try:
+        for precision in ("fp64", "fp32"):
+            triceratops_amd.set_precision(precision)
+            got = {}
+            for native in (True, False):
+                fused.NATIVE = native
+                np.random.seed(5)
+                torch.manual_seed(5)
+                _lib.reset_stats()
+                out = triceratops_amd.calc_probs_many(_jobs(4, 200_000))
+                got[native] = (out, dict(_lib.STATS))
+            for x, y in zip(got[True][0], got[False][0]):
+                assert x.FPP == y.FPP and x.NFPP == y.NFPP
+                for c in cols:
+                    assert np.array_equal(x.probs[c].values, y.probs[c].values, equal_nan=True), (precision, c)
+                for c in attrs:
+                    assert np.array_equal(np.asarray(getattr(x, c)), np.asarray(getattr(y, c)), equal_nan=True), (precision, c)
+            assert got[True][1]["rows"] == got[False][1]["rows"] > 0
+            assert got[True][1]["cells"] == got[False][1]["cells"]
+    finally:
+        fused.NATIVE = True
+        sharding.per_unit_seed = False
+        triceratops_amd.set_precision("fp64")
+        triceratops_amd.set_sampling("numpy")

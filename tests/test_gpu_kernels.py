@@ -406,7 +406,7 @@ def test_full_size_properties():
 
 
 def test_entry_points_capture_into_a_hip_graph_and_replay():
-    """include/trx.h promises: no allocation, no sync, stream-ordered -> capturable"""
+    """include/trx.h promises: no sync, stream-ordered, scratch from graph memory nodes while capturing"""
     rng, t, flux = _lc(300)
     t_d, f_d = _lib.dev(t), _lib.dev(flux)
     rows_d = _lib.dev(synth.tp_rows(rng, 2000, True))

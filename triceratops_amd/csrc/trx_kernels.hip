@@ -27,10 +27,13 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "../../include/trx.h"
 #include "trx_device.hpp"
+#include "trx_internal.hpp"
 
 namespace {
 
@@ -68,6 +71,7 @@ struct RowsArgs {
     int B;
     long nbatch;
     int use_tiers, debug_nodes;
+    int need_sec;      // rowc_kernel: run the secondary-eclipse scan (EB rows whose depth is used)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     TierTable tiers;
@@ -220,12 +224,14 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
                 c.xeb = 0.0;
                 c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
             } else {
-                RowC& sc = srows[lane];
-                const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
-                orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
-                const Limb L = limb_weights(u1, u2);
-                sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
-                sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                if (a.need_sec) {
+                    RowC& sc = srows[lane];
+                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
+                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                    const Limb L = limb_weights(u1, u2);
+                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
+                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                }
                 if (is_host) {                                          // :427-432
                     c.xeb = feb / fcomp;
                     ysec = fcomp / feb;
@@ -245,7 +251,9 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
 #pragma unroll
         for (int q = 0; q < kRowDoubles; ++q) dst[q] = src[q];
     }
-    if (!eblike) return;
+    // the scan decides the exclusion rule of lnL_EB_p (likelihoods.py:535-538) and the secdepth
+    // output of simulate_EB_transit_p; lnL_EB_twin_p (:542-587) uses neither
+    if (!a.need_sec) return;
     if (lane < 64) { secmin[lane] = INFINITY; secnan[lane] = 0; }
     __syncthreads();
     for (int it = lane; it < nb * kSecPoints; it += 256) {
@@ -975,25 +983,6 @@ bool fill_tiers(TierTable& T, int S)
     return ok;
 }
 
-// The scratch of a likelihood call comes from the device's default stream-ordered pool.  By default
-// that pool hands freed memory back to the driver at the next synchronisation, and the next call
-// pays a driver allocation; once per device the release threshold is raised so that the pool keeps
-// what it has served (at most the scratch of the calls in flight: 144 B per row each).
-int keep_scratch_pool()
-{
-    constexpr int kMaxDevices = 64;
-    static std::atomic<bool> done[kMaxDevices];
-    int dev = 0;
-    TRX_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices || done[dev].load(std::memory_order_acquire)) return TRX_OK;
-    hipMemPool_t pool;
-    TRX_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
-    uint64_t keep = UINT64_MAX;
-    TRX_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    done[dev].store(true, std::memory_order_release);
-    return TRX_OK;
-}
-
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
 std::atomic<int> g_cells_below{272};
 
@@ -1023,6 +1012,8 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const long want_grid = 8 * ((a.nbatch + 7) / 8);
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
+    a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
+                 ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
     const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
                       + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
@@ -1035,10 +1026,16 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         a.B = 1;
         a.nbatch = a.n;
     }
-    // the row constants: 144 B per row of stream-ordered scratch (+ the flat-model chi^2), filled 64 rows per wave
-    if (int rc = keep_scratch_pool()) return rc;
+    // the row constants: 144 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
+    // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
+    // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    TRX_HIP(hipMallocAsync(&scratch, ((size_t)a.n * kRowDoubles + 1) * sizeof(double), st));
+    const size_t scratch_bytes = ((size_t)a.n * kRowDoubles + 1) * sizeof(double);
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool capturing = capture == hipStreamCaptureStatusActive;
+    if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
+    else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     a.rowc = static_cast<double*>(scratch);
     hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(256), 0, st, a);
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
@@ -1054,7 +1051,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false>), dim3(g2), dim3(64), lds, st, a);
     }
     const hipError_t launched = hipGetLastError();
-    TRX_HIP(hipFreeAsync(scratch, st));
+    if (capturing) TRX_HIP(hipFreeAsync(scratch, st));
     TRX_HIP(launched);
     return TRX_OK;
 }
@@ -1095,6 +1092,42 @@ int check_rows(int model, const double* time, int n_time, const double* params, 
 
 }  // namespace
 
+// ---- per-stream scratch (trx_internal.hpp) ------------------------------------------------
+namespace trx {
+namespace {
+struct ScratchEntry {
+    void* p[kScratchSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[kScratchSlots] = {0, 0, 0, 0};
+};
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchEntry> g_scratch;
+}  // namespace
+
+hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    ScratchEntry& en = g_scratch[std::make_pair(dev, st)];
+    if (en.cap[slot] < bytes) {
+        // earlier launches on this stream may still read the old buffer
+        if (en.p[slot]) {
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            (void)(slot == 3 ? hipHostFree(en.p[slot]) : hipFree(en.p[slot]));
+            en.p[slot] = nullptr;
+            en.cap[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 256;
+        e = (slot == 3) ? hipHostMalloc(&en.p[slot], want, hipHostMallocDefault) : hipMalloc(&en.p[slot], want);
+        if (e != hipSuccess) return e;
+        en.cap[slot] = want;
+    }
+    *out = en.p[slot];
+    return hipSuccess;
+}
+}  // namespace trx
+
 // =========================================================================================
 extern "C" {
 
@@ -1107,7 +1140,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1119,7 +1152,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1295,6 +1328,22 @@ int trx_debug_phase_cycles(unsigned long long* out8)
     return TRX_OK;
 }
 #endif
+
+/* frees every per-stream scratch buffer of the library (all devices); the streams must be idle */
+int trx_release_scratch(void)
+{
+    std::lock_guard<std::mutex> lock(trx::g_scratch_mu);
+    int cur = 0;
+    TRX_HIP(hipGetDevice(&cur));
+    for (auto& kv : trx::g_scratch) {
+        TRX_HIP(hipSetDevice(kv.first.first));
+        for (int sl = 0; sl < trx::kScratchSlots; ++sl)
+            if (kv.second.p[sl]) (void)(sl == 3 ? hipHostFree(kv.second.p[sl]) : hipFree(kv.second.p[sl]));
+    }
+    trx::g_scratch.clear();
+    TRX_HIP(hipSetDevice(cur));
+    return TRX_OK;
+}
 
 const char* trx_version(void) { return "triceratops_amd libtrx 0.2.0 (gfx950)"; }
 const char* trx_last_error(void) { return g_err; }

@@ -91,7 +91,37 @@ class DrawArgs(ctypes.Structure):
                    ("seed", ctypes.c_ulonglong), ("dump", _vp)])
 
 
+class ScenarioArgs(ctypes.Structure):
+    """trx_scenario_args (include/trx.h)"""
+    _fields_ = [("draw", ctypes.POINTER(DrawArgs)), ("time", _vp), ("flux", _vp),
+                ("n_time", ctypes.c_int), ("nsupersample", ctypes.c_int),
+                ("sigma", ctypes.c_double), ("lnsigma", ctypes.c_double), ("exptime", ctypes.c_double),
+                ("flags", ctypes.c_int), ("want_prior", ctypes.c_int),
+                ("out", ctypes.POINTER(ctypes.c_double)), ("out_flag", ctypes.POINTER(ctypes.c_int))]
+
+
+SCENARIO_OUT = 16      # TRX_SCENARIO_OUT
+# True: a lnZ_* call that only has to return its best draw (calc_probs: TABLE_ROWS == 1, device
+# generator) is ONE library call, trx_scenario_evidence; False: the chain of torch operators around
+# trx_draw_scenario / trx_lnz_scenario below (the path of the 100-row table; kept as cross-check)
+NATIVE = True
 _bound = False
+_bound_scenario = False
+
+
+def _fn_scenario():
+    global _bound_scenario
+    L = _lib.lib()
+    if not _bound_scenario:
+        _fn()
+        L.trx_scenario_evidence.restype = ctypes.c_int
+        L.trx_scenario_evidence.argtypes = [ctypes.POINTER(ScenarioArgs), _vp]
+        L.trx_scenario_args_size.restype = ctypes.c_size_t
+        if L.trx_scenario_args_size() != ctypes.sizeof(ScenarioArgs):
+            raise _lib.TrxError("trx_scenario_args layout mismatch: library %d bytes, binding %d"
+                                % (L.trx_scenario_args_size(), ctypes.sizeof(ScenarioArgs)))
+        _bound_scenario = True
+    return L.trx_scenario_evidence
 
 
 def _fn():
@@ -428,6 +458,9 @@ class _Scenario:
         tab = _spline_table(dev, self.band)
         a.splines = tab.data_ptr()
         ncol = 11 if a.planet else 14
+        if (NATIVE and TABLE_ROWS == 1 and DUMP is None and _lib.TRACE is None
+                and not isinstance(dp.RNG, dp.NumpyStreamRng)):
+            return self._run_native(is_host, ncol)
         cols = torch.empty((ncol, N), dtype=F64, device=dev)
         mask = torch.empty(N, dtype=torch.uint8, device=dev)
         mask2 = torch.empty(N, dtype=torch.uint8, device=dev) if not a.planet else None
@@ -467,6 +500,38 @@ class _Scenario:
             if tabl[-1] != 0.0:
                 raise ValueError("can only convert an array of size 1 to a Python scalar")
             res.append(self._table(tabl[:-2].reshape(ncol, -1), float(tabl[-2]), twin))
+        return res[0] if a.planet else (res[0], res[1])
+
+    def _run_native(self, is_host, ncol):
+        """the whole call in the library: draws, masks, compaction, likelihood, evidence, best draw"""
+        a, dev = self.a, self.dev
+        out = (ctypes.c_double * (2 * SCENARIO_OUT))()
+        flag = ctypes.c_int(0)
+        sa = ScenarioArgs()
+        sa.draw = ctypes.pointer(a)
+        sa.time, sa.flux = self.time.data_ptr(), self.flux.data_ptr()
+        sa.n_time, sa.nsupersample = int(self.time.numel()), int(self.nsamples)
+        sa.sigma, sa.lnsigma, sa.exptime = float(self.sigma), float(np.log(self.sigma)), float(self.exptime)
+        sa.flags = ((FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if self.parallel else FLAG_SCALAR_K)
+                    | _lib.EXTRA_FLAGS)
+        sa.want_prior = int(self.want_prior)
+        sa.out, sa.out_flag = out, ctypes.pointer(flag)
+        fn = _fn_scenario()
+        with torch.cuda.device(dev):
+            rc = fn(ctypes.byref(sa), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.TrxError("trx_scenario_evidence failed with status %d: %s"
+                                % (rc, _lib.lib().trx_last_error().decode()))
+        if flag.value != 0:
+            raise ValueError("can only convert an array of size 1 to a Python scalar")
+        res = []
+        for b in range(1 if a.planet else 2):
+            row = np.array(out[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT])
+            n = int(row[ncol + 1])
+            _lib.STATS["rows"] += n
+            _lib.STATS["cells"] += n * sa.n_time
+            _lib.STATS["launches"] += 1
+            res.append(self._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
         return res[0] if a.planet else (res[0], res[1])
 
     def _best(self, h, idx, n):
