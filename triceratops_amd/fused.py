@@ -11,6 +11,7 @@ Host work per call: the constants of the broken power laws (priors.py:16-383), t
 Di Stefano rate constants (priors.py:601-660) and table pointers -- nothing per draw.
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -104,7 +105,7 @@ SCENARIO_OUT = 16      # TRX_SCENARIO_OUT
 # True: a lnZ_* call that only has to return its best draw (calc_probs: TABLE_ROWS == 1, device
 # generator) is ONE library call, trx_scenario_evidence; False: the chain of torch operators around
 # trx_draw_scenario / trx_lnz_scenario below (the path of the 100-row table; kept as cross-check)
-NATIVE = True
+NATIVE = os.environ.get("TRX_NATIVE", "1") != "0"      # TRX_NATIVE=0: A/B runs of whole programs
 _bound = False
 _bound_scenario = False
 
