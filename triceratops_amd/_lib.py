@@ -127,10 +127,19 @@ def version():
     return lib().trx_version().decode()
 
 
+_gpu_seen = False
+
+
 def require_gpu():
+    """raises unless a GPU and the HIP library are there (checked until it has succeeded once:
+    hipGetDeviceCount costs ~0.1 ms a call on this stack, a tenth of a small lnZ_* call)"""
+    global _gpu_seen
+    if _gpu_seen:
+        return
     if not torch.cuda.is_available() or lib().trx_device_count() < 1:
         raise TrxError("triceratops_amd needs an AMD GPU (gfx950); none is visible and there is no "
                        "CPU fallback")
+    _gpu_seen = True
 
 
 def compute_device():
