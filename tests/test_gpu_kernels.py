@@ -546,3 +546,29 @@ def test_supersampling_edge_counts_match_oracle(S, exptime):
                          want_secdepth=False)[0].cpu().numpy()
     want = O.evaluate_pv(t, rows[:7].T, rows[7:].T, exptime, S)
     assert np.abs(got - want).max() < ATOL_FLUX
+
+
+def test_scratch_is_per_stream_and_can_be_released():
+    """the per-(device, stream) scratch of the model entry points: launches on two streams do not
+    share it, a larger call after a smaller one grows it, and trx_release_scratch() gives it back"""
+    rng, t, flux = _lc(120)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    small, large = synth.eb_rows(rng, 700, True), synth.eb_rows(rng, 40_000, True)
+    want_s, want_l = O.lnl_batch(1, t, flux, synth.SIGMA, small), O.lnl_batch(1, t, flux, synth.SIGMA, large[:, :500])
+    s_d, l_d = _lib.dev(small), _lib.dev(large)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        for st, rows in zip(streams, (s_d, l_d) if rep % 2 == 0 else (l_d, s_d)):
+            with torch.cuda.stream(st):
+                outs.append((rows is s_d, _lib.lnl_batch(1, 0, t_d, f_d, synth.SIGMA, rows, synth.EXPTIME, 20)))
+        if rep == 1:
+            torch.cuda.synchronize()
+            assert _lib.lib().trx_release_scratch() == 0
+    torch.cuda.synchronize()
+    for is_small, h in outs:
+        if is_small:
+            _cmp_h(h.cpu().numpy(), want_s)
+        else:
+            _cmp_h(h.cpu().numpy()[:500], want_l)

@@ -108,6 +108,19 @@ def run_units(units, verbose=0):
         _fused.TABLE_ROWS = _fused.N_BEST
 
 
+_streams = {}
+
+
+def _worker_streams(device, n):
+    """the worker threads' HIP streams, kept from call to call: the library keeps its scratch per
+    stream (include/trx.h), so fresh streams every calc_probs would keep growing new buffers"""
+    import torch
+    have = _streams.setdefault(device, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device))
+    return have[:n]
+
+
 def _run_units(units, live, owner, base, dist, world, rank, verbose):
     rows = {k: len(units[k][1]) for k in live}
     offs, total = {}, 0
@@ -151,10 +164,11 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             todo.put(k)
         errors = []
 
-        def worker():
+        streams = _worker_streams(device, n_threads)
+
+        def worker(stream):
             try:
                 torch.cuda.set_device(device)        # the current device is thread-local
-                stream = torch.cuda.Stream(device)
                 with torch.cuda.stream(stream):
                     while True:
                         try:
@@ -167,7 +181,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                 errors.append(exc)
 
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
-        pool = [threading.Thread(target=worker) for _ in range(n_threads)]
+        pool = [threading.Thread(target=worker, args=(streams[i],)) for i in range(n_threads)]
         for t in pool:
             t.start()
         for t in pool:
