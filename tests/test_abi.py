@@ -36,6 +36,19 @@ def test_python_binding_lists_the_same_symbols():
     assert sorted(_lib.ABI_SYMBOLS) == _declared()
 
 
+def test_struct_bindings_match_the_library_layout():
+    """the ctypes mirrors of trx_draw_args / trx_scenario_args (fused.py) have the library's sizes"""
+    from triceratops_amd import _lib, fused
+    L = _lib.lib()
+    L.trx_draw_args_size.restype = ctypes.c_size_t
+    L.trx_scenario_args_size.restype = ctypes.c_size_t
+    assert L.trx_draw_args_size() == ctypes.sizeof(fused.DrawArgs)
+    assert L.trx_scenario_args_size() == ctypes.sizeof(fused.ScenarioArgs)
+    assert fused.SCENARIO_OUT == 16
+    # bad arguments are rejected before anything touches a device
+    assert L.trx_scenario_evidence(None, None) != 0
+
+
 def test_argument_checks_need_no_gpu():
     from triceratops_amd import _lib
     L = _lib.lib()
