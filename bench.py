@@ -375,6 +375,9 @@ def run_grid(ctx):
     roof = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "mean_launch_ms": mean_launch_s * 1e3, "cells_per_launch": cells_per_launch,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            # the row constants' round trip between rowc_kernel and cells_kernel (144 B per row written and
+            # read once): design traffic on top of the algorithmic bytes, counted in `traffic`
+            "scratch_round_trip_bytes_per_launch": 2.0 * 144.0 * n_rows,
             "hbm_GBps_algorithmic": alg_bytes_per_launch / mean_launch_s / 1e9}
     kernels = {}
     if ctx["extras"]:

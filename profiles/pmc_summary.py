@@ -18,9 +18,9 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             acc[k][c].append(v)
 for k in sorted(acc, key=lambda k: -len(acc[k])):
     short = k.split("(")[0][-60:]
-    if not any(s in k for s in ("rows_kernel", "cells_kernel", "draw_kernel", "lme", "chi2")):
+    if not any(s in k for s in ("rowc_kernel", "cells_kernel", "draw_kernel", "lme", "chi2")):
         continue
-    print("==", ("cells_kernel" if "cells_kernel" in k else "rows_kernel" if "rows_kernel" in k else short), "<0" if "<0" in k else "<1" if "<1" in k else "")
+    print("==", ("cells_kernel" if "cells_kernel" in k else "rowc_kernel" if "rowc_kernel" in k else short), "<0" if "<0" in k else "<1" if "<1" in k else "")
     for c in sorted(acc[k]):
         v = acc[k][c]
         print("   %-28s n=%3d mean=%.6g" % (c, len(v), sum(v) / len(v)))

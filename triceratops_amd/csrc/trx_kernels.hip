@@ -95,9 +95,10 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// Optional phase timers (build with -DTRX_PHASE_TIMERS; profiles/phase_cycles.py): wave cycles
-// spent in the prologue (0), cell plans (1), stage A (2), stage B (3), stage C and the rest of
-// the time loop (4), summed over all waves.  Not compiled into the product library.
+// Optional phase timers (build with -DTRX_PHASE_TIMERS; profiles/phase_cycles2.py): wave cycles spent
+// loading the row blocks (0), in the window pass (1), the cell plans (2), the pair trips (3) and the
+// rest of a chunk (5), summed over all waves.  Not compiled into the product library; the cycle
+// counter reads perturb the one-row variant's code heavily (shares only, not times).
 #ifdef TRX_PHASE_TIMERS
 __device__ unsigned long long g_phase_cycles[8];
 #define TRX_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
