@@ -155,11 +155,16 @@ int trx_set_rows_per_wave(int rows);
  *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of
  *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
  *    model is analytic (the two agree to ~1e-13 in flux);
+ *  - trx_set_stencil(0) (default 1): no centre-value stencil -- on a uniform time grid whose spacing is
+ *    at most 0.3 exposures (stamps within 4 ulp of t0 + j dt) a cell far from every limb contact takes
+ *    its exposure average from the instantaneous flux at the centres of its 13 nearest cells (one
+ *    model evaluation per cell; error bound 1e-15, trx_kernels.hip) instead of 3-4 Gauss nodes;
  *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
  *    exposure centre's solution;
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
  *    for each cell instead of the flux. */
 int trx_set_supersample_tiers(int on);
+int trx_set_stencil(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
 /*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 272) are

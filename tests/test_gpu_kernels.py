@@ -232,12 +232,14 @@ def test_packed_cell_kernel_raw_model_and_census():
     counts = {}
     try:
         L.trx_set_debug_node_counts(1)
+        L.trx_set_stencil(0)          # (this grid is uniform at 0.26 exposures: the one-row variant would use it)
         for below in (0, 1 << 30):
             L.trx_set_cell_packing_below(below)
             counts[below] = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), _lib.dev(rows), 0.0204, 20,
                                            want_secdepth=False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
+        L.trx_set_stencil(1)
         L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
     assert np.array_equal(counts[0], counts[1 << 30])
 
@@ -529,9 +531,22 @@ def test_node_census_knob_reports_the_plan_of_every_cell():
         n = _lib.flux_grid(0, 0, _lib.dev(t), rows, synth.EXPTIME, 20, False)[0].cpu().numpy()
     finally:
         L.trx_set_debug_node_counts(0)
-    assert set(np.unique(n)) <= {0.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 20.0} and {0.0, 3.0, 20.0} <= set(np.unique(n))
+    # 1 = a centre-value stencil cell (this grid is uniform at 0.18 exposures), n + 1 = a Gauss cell
+    # that also lends its centre value to a stencil neighbour
+    assert set(np.unique(n)) <= {0.0, 1.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 20.0}
+    assert {0.0, 1.0, 3.0, 20.0} <= set(np.unique(n))
     assert np.all(flux[n == 0] == 1.0) and np.all(n[flux < 1.0] > 0)
-    assert 1.0 < n.mean() < 4.0
+    assert 0.8 < n.mean() < 2.0
+    L.trx_set_debug_node_counts(1)
+    L.trx_set_stencil(0)
+    try:
+        n0 = _lib.flux_grid(0, 0, _lib.dev(t), rows, synth.EXPTIME, 20, False)[0].cpu().numpy()
+    finally:
+        L.trx_set_debug_node_counts(0)
+        L.trx_set_stencil(1)
+    assert set(np.unique(n0)) <= {0.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 20.0} and {0.0, 3.0, 20.0} <= set(np.unique(n0))
+    assert np.array_equal(n0 == 0, n == 0) and np.array_equal(n0 == 20, n == 20)
+    assert np.all(n0[n == 1] <= 4) and 1.5 < n0.mean() < 4.0 and n.mean() < 0.8 * n0.mean()
 
 
 @pytest.mark.parametrize("S,exptime", [(1, 0.0), (1, 0.02), (2, 0.02), (3, 0.00139), (8, 0.02), (64, 0.02), (65, 0.02)])
@@ -572,3 +587,46 @@ def test_scratch_is_per_stream_and_can_be_released():
             _cmp_h(h.cpu().numpy(), want_s)
         else:
             _cmp_h(h.cpu().numpy()[:500], want_l)
+
+
+@pytest.mark.parametrize("n_time,exptime,S", [(2000, 0.00139, 20), (1500, 0.00139, 20), (900, 0.0204, 20), (700, 0.0204, 50),
+                                              (2600, 0.00139, 12), (3000, 0.00139, 20)])
+def test_centre_value_stencil_on_dense_uniform_grids(n_time, exptime, S):
+    """On a uniform grid of 1/7 .. 0.3 exposures per cell the one-row variant takes cells far from every
+    limb contact from the centre values of their 13 nearest cells (trx_kernels.hip, kStM).  Against the
+    same kernel with the stencil off and with every sub-exposure evaluated: flux within 3e-13, exactly 1
+    and NaN in the same places; against the oracle within the usual 5e-13; grids outside the band,
+    jittered stamps and short curves do not use it."""
+    rng = np.random.default_rng(300 + n_time)
+    rows = _raw_stress_rows(rng, 1200)
+    u_target = {2000: 0.18, 1500: 0.25, 900: 0.2, 700: 0.29, 2600: 0.1, 3000: 0.34}[n_time]
+    dt = u_target * exptime
+    t = np.linspace(-0.5 * dt * (n_time - 1), 0.5 * dt * (n_time - 1), n_time)
+    in_band = 1 / 7 <= u_target <= 0.3
+    L = _lib.lib()
+    t_d, r_d = _lib.dev(t), _lib.dev(rows)
+    g = {}
+    try:
+        for name, st, tiers, cnt in (("on", 1, 1, 0), ("off", 0, 1, 0), ("all", 0, 0, 0), ("n", 1, 1, 1)):
+            L.trx_set_stencil(st); L.trx_set_supersample_tiers(tiers); L.trx_set_debug_node_counts(cnt)
+            g[name] = _lib.flux_grid(_lib.MODEL_RAW, 0, t_d, r_d, exptime, S, want_secdepth=False)[0].cpu().numpy()
+        # a jittered copy of the grid: no stencil
+        tj = t.copy(); tj[n_time // 2] += 1e-9
+        L.trx_set_stencil(1); L.trx_set_supersample_tiers(1); L.trx_set_debug_node_counts(1)
+        nj = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(tj), r_d, exptime, S, want_secdepth=False)[0].cpu().numpy()
+    finally:
+        L.trx_set_stencil(1); L.trx_set_supersample_tiers(1); L.trx_set_debug_node_counts(0)
+    share = float((g["n"] == 1).mean())
+    assert not (nj == 1).any()
+    if in_band and S >= 8:
+        assert share > 0.03, share
+    else:
+        assert share == 0.0
+    for other in ("off", "all"):
+        d = np.abs(g["on"] - g[other])
+        assert np.nanmax(d) < 3e-13, (other, np.nanmax(d))
+        assert np.array_equal(np.isnan(g["on"]), np.isnan(g[other]))
+        assert np.array_equal(g["on"] == 1.0, g[other] == 1.0)
+    k1 = rows[0] <= 1.0
+    want = O.evaluate_pv(t, rows[:7, k1][:, :200].T, rows[7:, k1][:, :200].T, exptime, S)
+    assert np.abs(g["on"][k1][:200] - want).max() < ATOL_FLUX

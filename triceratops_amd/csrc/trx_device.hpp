@@ -615,11 +615,12 @@ struct CellPlan {
     int n = 0, tier = -1;
     double sE = 0.0, cE = 1.0, Mprev = 0.0;     // eccentric-anomaly state carried along the nodes
     bool anchored = false;                       // state holds a solution (at the exposure centre)
+    bool st_ok = false;                          // no limb contact within the stencil radius (cells_kernel)
 };
 
 template <bool CHECK_WINDOW = true>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
-                                              const TierTable& tt, bool use_tiers)
+                                              const TierTable& tt, bool use_tiers, double st_radius = 0.0)
 {
     CellPlan p;
     const double phase = c.nmot * (t - c.t0);
@@ -659,6 +660,11 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
         const bool ok = tt.n[q] > 0 && G >= 1.25 * fma(g2 * tau, tau, g1 * tau) &&
                         om * tau <= 0.15 && Y > fabs(Yp) * tau;
         if (ok) { p.tier = q; p.n = tt.n[q]; }
+    }
+    // the same test at the radius the centre-value stencil of a dense uniform time grid needs
+    if (st_radius > 0.0) {
+        const double tau = st_radius * hx;
+        p.st_ok = G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
     }
     // whole exposure off the disc: every sub-exposure is exactly 1
     const double tau1 = 1.5 * hx;

@@ -72,6 +72,7 @@ struct RowsArgs {
     long nbatch;
     int use_tiers, debug_nodes;
     int need_sec;      // rowc_kernel: run the secondary-eclipse scan (EB rows whose depth is used)
+    int use_stencil;   // rowc_kernel: look for a dense uniform time grid (centre-value stencil, cells_kernel<LONG>)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     TierTable tiers;
@@ -162,6 +163,26 @@ constexpr int kCellsMaxRows = 22;
 constexpr int kCellsWindow = TRX_CELLS_WINDOW;     // cells per window pass (in-window list in LDS)
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
+// Launch header behind the row blocks in scratch: [0] chi^2 of the flat model, [1] stencil radius
+// (0 = no stencil), [2 .. 2 + 2 kStM] stencil weights.
+//
+// Centre-value stencil (dense uniform time grids; cells_kernel<LONG>).  The reference averages the
+// model over S sub-exposures spanning `exptime`.  On a uniform grid whose spacing dt is a fraction
+// of the exposure (BASELINE config 1: dt = 0.18 exptime) neighbouring exposures overlap, and where
+// the model is analytic the instantaneous flux at the exposure CENTRES of 2 kStM + 1 neighbouring
+// cells determines it over the whole exposure: the S-point average of the degree-2 kStM interpolant
+// through those centre values is a fixed weighted sum, W_i = (1/S) sum_s l_i(x_s), l_i the Lagrange
+// basis on the integer nodes -kStM .. kStM and x_s the sub-exposure offsets in units of dt.  One
+// model evaluation per cell instead of 3-4 Gauss nodes.  Error (Cauchy): for a model analytic in a
+// disc of radius rho around the cell's centre, |error| <= M max_s prod_i |x_s - i| (dt / (rho - kStM
+// dt))^(2 kStM + 1), M the largest flux deficit on the disc (<= 1); the radius below makes that
+// 1e-15.  plan_cell tests it exactly like a Gauss tier (no limb contact, real or complex, inside
+// the disc).  Anything else -- non-uniform stamps, coarse grids, cells near a contact, the first
+// and last kStM cells of a chunk -- takes the Gauss nodes as before.
+constexpr int kStM = 6;
+constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrDoubles = 16;
+static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
+
 // Row constants of 64 rows per workgroup, every lane of the first wave on a row of its own, written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
 // 256 threads per 64 rows: the first wave derives the constants (lanes = rows), then the 64 x 25
 // (row, point) cells of the secondary-eclipse scan are dealt to all four waves -- the scan is an
@@ -191,7 +212,68 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
             acc += (d * d) / a.s2;
         }
         acc = wave_sum(acc);
-        if ((lane & 63) == 0) a.rowc[n * kRowDoubles] = acc;
+        if ((lane & 63) == 0) a.rowc[n * kRowDoubles + kHdrFlat] = acc;
+    }
+    if (blockIdx.x == 0 && (lane >> 6) == 2) {
+        // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
+        double* hdr = a.rowc + n * kRowDoubles;
+        const int l = lane & 63, nt = a.n_time;
+        bool ok = a.use_stencil && nt >= 64 && a.S >= 2 && a.exptime > 0.0;
+        double dt = 0.0, t0 = 0.0;
+        if (ok) {
+            t0 = a.time[0];
+            dt = (a.time[nt - 1] - t0) / (double)(nt - 1);
+            double dev = 0.0, big = 0.0;
+            for (int j = l; j < nt; j += 64) {
+                const double t = a.time[j];
+                dev = fmax(dev, fabs(t - fma((double)j, dt, t0)));
+                big = fmax(big, fabs(t));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                dev = fmax(dev, __shfl_xor(dev, o, 64));
+                big = fmax(big, __shfl_xor(big, o, 64));
+            }
+            // stamps within 4 ulp of t0 + j dt (np.linspace is); NaN stamps fail the comparison
+            ok = dt > 0.0 && dev <= 4.0 * 2.220446049250313e-16 * fmax(big, dt);
+        }
+        // spacing in units of the exposure: at most 0.3 (the exposures must overlap well), and the
+        // sub-exposures must stay in the middle of the node span, |x_s| <= 0.5 / u <= kStM / 2 + 0.5,
+        // where equispaced interpolation is well conditioned (beyond it the weights grow and alternate)
+        const double u = ok ? dt / a.exptime : 1.0;
+        ok = ok && u <= 0.3 && 0.5 / u <= 0.5 * kStM + 0.5;
+        double w = 0.0, pmax = 0.0;
+        if (ok && l <= 2 * kStM + 1) {
+            // lanes 0 .. 2 kStM: the weight of node i = l - kStM; lane 2 kStM + 1: max_s prod |x_s - i|
+            const int i = l - kStM;
+            for (int sidx = 1; sidx <= a.S; ++sidx) {
+                const double x = (((double)sidx - 0.5) * a.rS - 0.5) / u;
+                double num = 1.0, den = 1.0;
+                for (int k = -kStM; k <= kStM; ++k) {
+                    if (l == 2 * kStM + 1) num *= fabs(x - (double)k);
+                    else if (k != i) { num *= x - (double)k; den *= (double)(i - k); }
+                }
+                if (l == 2 * kStM + 1) pmax = fmax(pmax, num);
+                else w += num / den;
+            }
+            w *= a.rS;
+        }
+        pmax = __shfl(pmax, 2 * kStM + 1, 64);
+        // conditioning of the rule: sum |W_i| (1 for a positive rule); refuse anything above 3
+        double wabs = (l <= 2 * kStM) ? fabs(w) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wabs += __shfl_xor(wabs, o, 64);
+        ok = ok && wabs <= 3.0;
+        if (l <= 2 * kStM) hdr[kHdrStW + l] = ok ? w : 0.0;
+        if (l == 0) {
+            // rho / (exptime / 2) = 2 u (kStM + (pmax / 1e-15)^(1 / (2 kStM + 1))), 10 % on top
+            double radius = 0.0;
+            if (ok) {
+                radius = 1.1 * 2.0 * u * ((double)kStM + pow(pmax * 1e15, 1.0 / (2.0 * kStM + 1.0)));
+                if (!(radius > 0.0 && radius <= 40.0)) radius = 0.0;
+            }
+            hdr[kHdrStRadius] = radius;
+        }
     }
     if (lane < nb) {
         const double* p = a.params + base + lane;
@@ -284,10 +366,13 @@ struct CellState {
     double sE[64], cE[64];                  // eccentric anomaly at the exposure centre
     double t[64];                           // exposure centre
     double facc[64];                        // the cell's sum over its nodes
+    double fc[64];                          // instantaneous flux at the exposure centre (stencil)
+    double stw[16];                         // stencil weights of the launch
     signed char tier[64];                   // node set (-1 = all S sub-exposures)
     unsigned char row[64], anchored[64];
     unsigned char pad[64];
 };
+constexpr int kCentreNode = 1023;           // pair table: "the exposure centre itself" in the node field
 
 // exclusive prefix sum over the lanes of a non-negative count < 2^BITS, and the wave total
 template <int BITS>
@@ -351,7 +436,11 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         }
     }
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
-    const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? a.rowc[n * kRowDoubles] : 0.0;
+    const double* hdr = a.rowc + n * kRowDoubles;
+    const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
+    // centre-value stencil of a dense uniform grid (rowc_kernel): radius in half exposures, 0 = off
+    const double st_radius = (LONG && n_time > 0) ? uniform(hdr[kHdrStRadius]) : 0.0;
+    if (LONG && lane <= 2 * kStM) cs.stw[lane] = hdr[kHdrStW + lane];
 
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -450,7 +539,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 CellPlan pl;
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
-                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0);
+                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (LONG && sweep == 0) ? st_radius : 0.0);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
                         kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
@@ -463,7 +552,27 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                     if (heavy) { winlist[nheavy + lanes_below(mh)] = (unsigned short)rel; pl.n = 0; valid = false; }
                     nheavy += __popcll(mh);
                 }
-                const int tier = pl.tier, nodes = valid ? pl.n : 0;
+                const int tier = pl.tier;
+                int nodes = valid ? pl.n : 0;
+                // Centre-value stencil (LONG, dense uniform grid): a cell whose kStM neighbours on either
+                // side sit next to it in this chunk, all of them planned cells of this sweep, takes its
+                // exposure average from their centre values -- ONE pair, the centre, instead of its
+                // Gauss nodes; every cell within kStM of such a cell adds its centre to its own pairs.
+                bool st = false, centre = false;
+                if (LONG && sweep == 0 && st_radius > 0.0) {
+                    const int jm = __shfl(j, lane - kStM, 64), jp = __shfl(j, lane + kStM, 64);
+                    const unsigned long long mok = __ballot(valid);
+                    const bool inner = lane >= kStM && lane + kStM < 64;
+                    const unsigned long long need = ((1ull << (2 * kStM + 1)) - 1ull) << (inner ? lane - kStM : 0);
+                    st = inner && valid && pl.n > 0 && pl.st_ok && jm == j - kStM && jp == j + kStM &&
+                         (mok & need) == need;
+                    const unsigned long long mst = __ballot(st);
+                    unsigned long long dil = mst;
+#pragma unroll
+                    for (int i = 1; i <= kStM; ++i) dil |= (mst << i) | (mst >> i);
+                    centre = valid && ((dil >> lane) & 1ull);
+                    if (st) nodes = 0;
+                }
                 cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
                 cs.t[lane] = t;
                 cs.facc[lane] = 0.0;
@@ -475,15 +584,17 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
                 // takes as many nodes of every cell as fit the pair table (a first-sweep chunk in
                 // one pass; 64 contact cells x S = 20 sub-exposures in two).
-                const int ncells = __popcll(__ballot(nodes > 0));
-                int per = ncells > 0 ? kCellsPairs / ncells : kCellsPairs;
-                per = per > 1023 ? 1023 : per;
-                for (int s0 = 0; __any(s0 < nodes); s0 += per) {
+                const int ncells = __popcll(__ballot(nodes > 0 || centre));
+                int per = ncells > 0 ? kCellsPairs / ncells - 1 : kCellsPairs;
+                per = per > 1000 ? 1000 : (per < 1 ? 1 : per);
+                for (int s0 = 0; __any(s0 < nodes || (s0 == 0 && centre)); s0 += per) {
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
+                    const int extra = (s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
                     int total;
-                    const int off = lane_prefix<10>(cnt, total);
+                    const int off = lane_prefix<10>(cnt + extra, total);
                     for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
+                    if (extra) pdesc[off + cnt] = (unsigned short)(lane | (kCentreNode << 6));
                     __syncthreads();
                     // one pair per lane: the orbit stepped from the cell's centre solution (|dM| <=
                     // half an exposure), the Mandel-Agol flux, and the node's term added to the
@@ -493,18 +604,22 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         const int p = p0 + lane;
                         if (p < total) {
                             const int d = (int)pdesc[p];
-                            const int h = d & 63, s = s0 + (d >> 6);
+                            const int h = d & 63;
+                            const bool at_centre = LONG && (d >> 6) == kCentreNode;
+                            const int s = at_centre ? 0 : s0 + (d >> 6);
                             const RowC& c = LONG ? cu : rows[cs.row[h]];
                             const int ht = (int)cs.tier[h];
                             const double tc = cs.t[h];
-                            const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
-                                                         : tier_xw[ht * kTierMaxNodes + s];
-                            const double Mc = c.nmot * (tc - c.t0) + c.Mtr;
-                            const double M = c.nmot * ((tc + a.exptime * frac) - c.t0) + c.Mtr;
                             double sE = cs.sE[h], cE = cs.cE[h];
-                            bool have = false;
-                            if (STEP && cs.anchored[h]) have = kepler_step(M - Mc, c.e, sE, cE);
-                            if (!have) kepler_full(M, c.e, sE, cE);
+                            if (!at_centre) {
+                                const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
+                                                             : tier_xw[ht * kTierMaxNodes + s];
+                                const double Mc = c.nmot * (tc - c.t0) + c.Mtr;
+                                const double M = c.nmot * ((tc + a.exptime * frac) - c.t0) + c.Mtr;
+                                bool have = false;
+                                if (STEP && cs.anchored[h]) have = kepler_step(M - Mc, c.e, sE, cE);
+                                if (!have) kepler_full(M, c.e, sE, cE);
+                            }
                             const double ce = cE - c.e;
                             const double X = fma(c.ax, ce, c.bx * sE);
                             const double Y = fma(c.ay, ce, c.by * sE);
@@ -518,9 +633,13 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                             } else if (z2 != z2) {
                                 f = z2;
                             }
-                            const double term = (ht < 0) ? f : tier_xw[(kTiers + ht) * kTierMaxNodes + s] * (1.0 - f);
-                            if (ht < 0 || term != 0.0)
-                                __hip_atomic_fetch_add(&cs.facc[h], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (at_centre) {
+                                cs.fc[h] = f;
+                            } else {
+                                const double term = (ht < 0) ? f : tier_xw[(kTiers + ht) * kTierMaxNodes + s] * (1.0 - f);
+                                if (ht < 0 || term != 0.0)
+                                    __hip_atomic_fetch_add(&cs.facc[h], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     }
                     __syncthreads();
@@ -529,11 +648,17 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 TRX_TICK(t_rest);
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
-                    const double fsum = cs.facc[lane];
+                    double fsum = cs.facc[lane];
+                    if (LONG && st) {
+                        // the S-point average of the interpolant through the 2 kStM + 1 centre values
+                        fsum = 0.0;
+#pragma unroll
+                        for (int i = -kStM; i <= kStM; ++i) fsum = fma(cs.stw[i + kStM], 1.0 - cs.fc[lane + i], fsum);
+                    }
                     double m = (pl.n == 0) ? 1.0 : ((tier < 0) ? fsum / a.dS : 1.0 - fsum);
                     if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
                     if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
-                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)pl.n;    // bench/test knob
+                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)(nodes + (centre ? 1 : 0));    // bench/test knob: evaluations of this cell
                     if (MODE == MODE_GRID) {
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
@@ -880,6 +1005,7 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
+std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
 std::atomic<int> g_debug_nodes{0};  // grid mode writes the number of model evaluations per cell instead of the flux
 bool compute_tiers(TierTable& T, int S)
 {
@@ -1013,6 +1139,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const long want_grid = 8 * ((a.nbatch + 7) / 8);
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
+    a.use_stencil = (long_rows && a.use_tiers && g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
@@ -1031,7 +1158,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    const size_t scratch_bytes = ((size_t)a.n * kRowDoubles + 1) * sizeof(double);
+    const size_t scratch_bytes = ((size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
     const bool capturing = capture == hipStreamCaptureStatusActive;
@@ -1141,7 +1268,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1153,7 +1280,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
     RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1293,6 +1420,13 @@ int trx_set_cell_packing_below(int n_time)
 {
     if (n_time < 0) return fail(TRX_ERR_ARG, "n_time threshold must be >= 0%s (got %ld)", "", (long)n_time);
     g_cells_below = n_time;
+    return TRX_OK;
+}
+
+/* diagnostics (include/trx.h): 0 = Gauss nodes everywhere, no centre-value stencil */
+int trx_set_stencil(int on)
+{
+    g_stencil = on ? 1 : 0;
     return TRX_OK;
 }
 
