@@ -141,8 +141,10 @@ def collect_pmc(args):
                 return None
             if p.returncode != 0:
                 return None
-            # one likelihood launch = rowc_kernel (row constants to scratch) + cells_kernel<lnl>: both counted
-            per, prologue = {}, 0.0
+            # one likelihood launch = rowc_kernel (row constants to scratch) + cells_kernel<lnl> in its two
+            # instantiations (without / with the centre-value stencil: the one that does not apply returns
+            # at once); everything is counted, the launches are the dispatches of the first instantiation
+            per, total = set(), 0.0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
@@ -150,12 +152,14 @@ def collect_pmc(args):
                             continue
                         name = row["Kernel_Name"].replace(" ", "")
                         if "cells_kernel<0" in name:
-                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                            total += float(row["Counter_Value"])
+                            if ",false>(" in name:
+                                per.add(row["Dispatch_Id"])
                         elif "rowc_kernel" in name:
-                            prologue += float(row["Counter_Value"])
+                            total += float(row["Counter_Value"])
             if not per:
                 return None
-            got[counter] = ((float(np.sum(list(per.values()))) + prologue) / len(per), len(per))
+            got[counter] = (total / len(per), len(per))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 on the read side; KB units

@@ -533,10 +533,11 @@ def test_node_census_knob_reports_the_plan_of_every_cell():
         L.trx_set_debug_node_counts(0)
     # 1 = a centre-value stencil cell (this grid is uniform at 0.18 exposures), n + 1 = a Gauss cell
     # that also lends its centre value to a stencil neighbour
-    assert set(np.unique(n)) <= {0.0, 1.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 20.0}
-    assert {0.0, 1.0, 3.0, 20.0} <= set(np.unique(n))
+    # (or a cell at a chunk edge whose centre two overlapping chunks evaluate)
+    assert set(np.unique(n)) <= {0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0, 20.0}
+    assert {0.0, 1.0, 20.0} <= set(np.unique(n))
     assert np.all(flux[n == 0] == 1.0) and np.all(n[flux < 1.0] > 0)
-    assert 0.8 < n.mean() < 2.0
+    assert 0.5 < n.mean() < 2.0
     L.trx_set_debug_node_counts(1)
     L.trx_set_stencil(0)
     try:
@@ -547,6 +548,7 @@ def test_node_census_knob_reports_the_plan_of_every_cell():
     assert set(np.unique(n0)) <= {0.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 20.0} and {0.0, 3.0, 20.0} <= set(np.unique(n0))
     assert np.array_equal(n0 == 0, n == 0) and np.array_equal(n0 == 20, n == 20)
     assert np.all(n0[n == 1] <= 4) and 1.5 < n0.mean() < 4.0 and n.mean() < 0.8 * n0.mean()
+    assert (n == 1).mean() > 0.1
 
 
 @pytest.mark.parametrize("S,exptime", [(1, 0.0), (1, 0.02), (2, 0.02), (3, 0.00139), (8, 0.02), (64, 0.02), (65, 0.02)])
@@ -630,3 +632,31 @@ def test_centre_value_stencil_on_dense_uniform_grids(n_time, exptime, S):
     k1 = rows[0] <= 1.0
     want = O.evaluate_pv(t, rows[:7, k1][:, :200].T, rows[7:, k1][:, :200].T, exptime, S)
     assert np.abs(g["on"][k1][:200] - want).max() < ATOL_FLUX
+
+
+def test_stencil_memo_is_only_a_hint():
+    """The library remembers per light curve (device pointer, length, exposure) whether the stencil
+    applied and enqueues only the matching kernel instantiation next time.  The time stamps behind a
+    remembered pointer may change: results must not depend on the memo."""
+    rng = np.random.default_rng(11)
+    rows = _raw_stress_rows(rng, 600)
+    exptime, S, n_time = 0.00139, 20, 1200
+    dt = 0.2 * exptime
+    uniform_t = np.linspace(-0.5 * dt * (n_time - 1), 0.5 * dt * (n_time - 1), n_time)
+    jittered = np.sort(uniform_t + rng.uniform(-0.3, 0.3, n_time) * dt)
+    L = _lib.lib()
+    t_d, r_d = _lib.dev(uniform_t), _lib.dev(rows)
+    ref = {}
+    L.trx_set_stencil(0)
+    try:
+        for name, t in (("u", uniform_t), ("j", jittered)):
+            ref[name] = _lib.flux_grid(_lib.MODEL_RAW, 0, _lib.dev(t), r_d, exptime, S, want_secdepth=False)[0].cpu().numpy()
+    finally:
+        L.trx_set_stencil(1)
+    for name, t in (("u", uniform_t), ("u", uniform_t), ("j", jittered), ("j", jittered), ("u", uniform_t), ("u", uniform_t)):
+        t_d.copy_(_lib.dev(t))                       # same device buffer, new stamps
+        got = _lib.flux_grid(_lib.MODEL_RAW, 0, t_d, r_d, exptime, S, want_secdepth=False)[0].cpu().numpy()
+        assert np.nanmax(np.abs(got - ref[name])) < 3e-13, name
+        assert np.array_equal(np.isnan(got), np.isnan(ref[name]))
+        if name == "j":
+            assert np.array_equal(got, ref[name], equal_nan=True) or np.nanmax(np.abs(got - ref[name])) < 1e-13

@@ -72,7 +72,10 @@ struct RowsArgs {
     long nbatch;
     int use_tiers, debug_nodes;
     int need_sec;      // rowc_kernel: run the secondary-eclipse scan (EB rows whose depth is used)
-    int use_stencil;   // rowc_kernel: look for a dense uniform time grid (centre-value stencil, cells_kernel<LONG>)
+    int use_stencil;   // 0: no stencil.  rowc_kernel looks for a dense uniform time grid (centre-value stencil,
+                       // cells_kernel<LONG>); 1: both instantiations of cells_kernel are enqueued and the one
+                       // that does not apply returns; 2: only the instantiation the memo predicts is enqueued
+    int* memo;         // rowc_kernel: where to leave the verdict for later launches on this light curve (or null)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     TierTable tiers;
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
                 if (!(radius > 0.0 && radius <= 40.0)) radius = 0.0;
             }
             hdr[kHdrStRadius] = radius;
+            if (a.memo) *a.memo = (radius > 0.0) ? 2 : 1;
         }
     }
     if (lane < nb) {
@@ -366,11 +370,14 @@ struct CellState {
     double sE[64], cE[64];                  // eccentric anomaly at the exposure centre
     double t[64];                           // exposure centre
     double facc[64];                        // the cell's sum over its nodes
-    double fc[64];                          // instantaneous flux at the exposure centre (stencil)
-    double stw[16];                         // stencil weights of the launch
     signed char tier[64];                   // node set (-1 = all S sub-exposures)
     unsigned char row[64], anchored[64];
     unsigned char pad[64];
+};
+// centre-value stencil (LONG only): the chunk's centre fluxes and the launch's weights
+struct StencilState {
+    double fc[64];
+    double stw[16];
 };
 constexpr int kCentreNode = 1023;           // pair table: "the exposure centre itself" in the node field
 
@@ -394,8 +401,10 @@ __device__ __forceinline__ int lane_prefix(int cnt, int& total)
 // LONG = true:  one row per wave (light curves of kCellsLongFrom points and more): row constants in
 //               scalar registers, time stamps and fluxes read from global memory (a chunk's cells
 //               are mostly neighbours), chi^2 summed directly per lane and reduced once per row.
-template <int MODE, bool STEP, bool FP32, bool LONG>
-__global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+// ST: the launch uses the centre-value stencil (decided on the device by rowc_kernel: the kernel
+// below picks the instantiation, so a launch without it runs exactly the code it ran before)
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
+__device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_radius)
 {
     extern __shared__ double lds[];
     const int B = LONG ? 1 : a.B;
@@ -406,6 +415,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
+    StencilState& ss = *reinterpret_cast<StencilState*>(&cs + 1);        // LONG only (behind the cell state)
     // short curves: the light curve itself in LDS -- every chunk reads time stamps and fluxes of
     // arbitrary cells, and a global load right before its use costs more than the chunk's other
     // "rest" work
@@ -438,9 +448,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
     const double* hdr = a.rowc + n * kRowDoubles;
     const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
-    // centre-value stencil of a dense uniform grid (rowc_kernel): radius in half exposures, 0 = off
-    const double st_radius = (LONG && n_time > 0) ? uniform(hdr[kHdrStRadius]) : 0.0;
-    if (LONG && lane <= 2 * kStM) cs.stw[lane] = hdr[kHdrStW + lane];
+    if (ST && lane <= 2 * kStM) ss.stw[lane] = hdr[kHdrStW + lane];
 
     const long per_xcd = (a.nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
@@ -468,12 +476,14 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         __syncthreads();
         // LONG: the row constants are wave-uniform -- held in scalar registers they cost no VGPRs
         // and no LDS reads in the pair loop
+        // (the window, dilution and exclusion constants are used once per 64 cells: those stay in LDS)
         RowC cu;
         if (LONG) {
-            const double* src = reinterpret_cast<const double*>(&rows[0]);
-            double* dst = reinterpret_cast<double*>(&cu);
-#pragma unroll
-            for (int q = 0; q < kRowDoubles; ++q) dst[q] = uniform(src[q]);
+            const RowC& r0 = rows[0];
+            cu.k = uniform(r0.k); cu.t0 = uniform(r0.t0); cu.nmot = uniform(r0.nmot); cu.e = uniform(r0.e);
+            cu.Mtr = uniform(r0.Mtr); cu.ax = uniform(r0.ax); cu.ay = uniform(r0.ay); cu.bx = uniform(r0.bx);
+            cu.by = uniform(r0.by); cu.cosi = uniform(r0.cosi); cu.cle = uniform(r0.cle); cu.cld = uniform(r0.cld);
+            cu.ced = uniform(r0.ced);
         }
         double lacc = 0.0;                 // LONG: this lane's share of the row's chi^2
         bool nonflat = false;              // LONG: a cell of this lane has a model value other than 1
@@ -500,9 +510,10 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                     const double phase = c.nmot * (tl[j] - c.t0);
                     const double dMc = reduce_2pi(phase);
                     const double slack = 1e-15 * fabs(phase);
-                    inw = in_window(c.wlo - slack, c.whi + slack, dMc);
+                    const RowC& cw = rows[rr];                       // (LONG: rr = 0)
+                    inw = in_window(cw.wlo - slack, cw.whi + slack, dMc);
                     // no occultation anywhere in the exposure: the model is 1, diluted
-                    if (MODE == MODE_GRID && !inw)
+                    if (MODE == MODE_GRID && (!inw || a.debug_nodes))
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
                     if (LONG && MODE == MODE_LNL && !inw) {
                         const double d = fl[j] - 1.0;
@@ -522,10 +533,27 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             int nheavy = 0;
             for (int sweep = 0; sweep < 2; ++sweep) {
             const int count = sweep ? nheavy : nw;
-            for (int w0 = 0; w0 < count; w0 += 64) {
+            // With the centre-value stencil the chunks of the first sweep overlap by 2 kStM cells: a
+            // chunk finalises its lanes [lo, hi) and only lends the centre values of the kStM lanes on
+            // either side, so the cells at a chunk's edges find their neighbours in the next one.
+            const bool halo = ST && sweep == 0;
+            int carry_rel = 0;
+            for (int w0 = 0, step = 64; w0 < count; w0 += step) {
                 TRX_TICK(t_plan);
+                bool owned = true;
                 bool valid = (w0 + lane) < count;
-                const int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
+                int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
+                if (ST && halo) {
+                    const bool last_chunk = w0 + 64 >= count;
+                    const int lo = (w0 > 0) ? kStM : 0, hi = last_chunk ? 64 : 64 - kStM;
+                    step = last_chunk ? 64 : hi - kStM;
+                    owned = lane >= lo && lane < hi;
+                    // the leading halo lanes are the previous chunk's last owned cells, whose list entries
+                    // the contact cells filed since may have overwritten: taken from that chunk's lanes
+                    const int prev_rel = __shfl(carry_rel, 64 - 2 * kStM + lane, 64);
+                    if (w0 > 0 && lane < kStM) rel = prev_rel;
+                    carry_rel = rel;
+                }
                 const int cell = win0 + rel;
                 int rr = 0, j = cell;
                 if (!LONG) {
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 CellPlan pl;
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
-                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (LONG && sweep == 0) ? st_radius : 0.0);
+                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
                         kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
@@ -548,23 +576,24 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 }
                 if (sweep == 0 && a.use_tiers) {
                     const bool heavy = valid && pl.tier < 0 && pl.n > 0;
-                    const unsigned long long mh = __ballot(heavy);
-                    if (heavy) { winlist[nheavy + lanes_below(mh)] = (unsigned short)rel; pl.n = 0; valid = false; }
+                    const unsigned long long mh = __ballot(heavy && owned);       // filed once, by its owner
+                    if (heavy && owned) winlist[nheavy + lanes_below(mh)] = (unsigned short)rel;
+                    if (heavy) { pl.n = 0; valid = false; }
                     nheavy += __popcll(mh);
                 }
                 const int tier = pl.tier;
-                int nodes = valid ? pl.n : 0;
+                int nodes = (valid && owned) ? pl.n : 0;
                 // Centre-value stencil (LONG, dense uniform grid): a cell whose kStM neighbours on either
                 // side sit next to it in this chunk, all of them planned cells of this sweep, takes its
                 // exposure average from their centre values -- ONE pair, the centre, instead of its
                 // Gauss nodes; every cell within kStM of such a cell adds its centre to its own pairs.
                 bool st = false, centre = false;
-                if (LONG && sweep == 0 && st_radius > 0.0) {
+                if (ST && sweep == 0) {
                     const int jm = __shfl(j, lane - kStM, 64), jp = __shfl(j, lane + kStM, 64);
                     const unsigned long long mok = __ballot(valid);
                     const bool inner = lane >= kStM && lane + kStM < 64;
                     const unsigned long long need = ((1ull << (2 * kStM + 1)) - 1ull) << (inner ? lane - kStM : 0);
-                    st = inner && valid && pl.n > 0 && pl.st_ok && jm == j - kStM && jp == j + kStM &&
+                    st = inner && owned && valid && pl.n > 0 && pl.st_ok && jm == j - kStM && jp == j + kStM &&
                          (mok & need) == need;
                     const unsigned long long mst = __ballot(st);
                     unsigned long long dil = mst;
@@ -584,13 +613,13 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
                 // takes as many nodes of every cell as fit the pair table (a first-sweep chunk in
                 // one pass; 64 contact cells x S = 20 sub-exposures in two).
-                const int ncells = __popcll(__ballot(nodes > 0 || centre));
-                int per = ncells > 0 ? kCellsPairs / ncells - 1 : kCellsPairs;
+                const int ncells = __popcll(__ballot(nodes > 0 || (ST && centre)));
+                int per = ncells > 0 ? kCellsPairs / ncells - (ST ? 1 : 0) : kCellsPairs;
                 per = per > 1000 ? 1000 : (per < 1 ? 1 : per);
-                for (int s0 = 0; __any(s0 < nodes || (s0 == 0 && centre)); s0 += per) {
+                for (int s0 = 0; __any(s0 < nodes || (ST && s0 == 0 && centre)); s0 += per) {
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
-                    const int extra = (s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
+                    const int extra = (ST && s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
                     int total;
                     const int off = lane_prefix<10>(cnt + extra, total);
                     for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
@@ -605,7 +634,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                         if (p < total) {
                             const int d = (int)pdesc[p];
                             const int h = d & 63;
-                            const bool at_centre = LONG && (d >> 6) == kCentreNode;
+                            const bool at_centre = ST && (d >> 6) == kCentreNode;
                             const int s = at_centre ? 0 : s0 + (d >> 6);
                             const RowC& c = LONG ? cu : rows[cs.row[h]];
                             const int ht = (int)cs.tier[h];
@@ -634,7 +663,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                                 f = z2;
                             }
                             if (at_centre) {
-                                cs.fc[h] = f;
+                                ss.fc[h] = f;
                             } else {
                                 const double term = (ht < 0) ? f : tier_xw[(kTiers + ht) * kTierMaxNodes + s] * (1.0 - f);
                                 if (ht < 0 || term != 0.0)
@@ -646,19 +675,24 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 }
                 TRX_TOCK(3, t_a);
                 TRX_TICK(t_rest);
-                if (valid) {
+                if (MODE == MODE_GRID && a.debug_nodes) {
+                    // bench / test knob: the model evaluations every cell cost, its own and those a
+                    // neighbouring chunk spent on its centre value (the cells were zeroed by pass 1)
+                    const int spent = nodes + ((ST && centre) ? 1 : 0);
+                    if (spent > 0) atomicAdd(&a.out[(size_t)base * n_time + cell], (double)spent);
+                } else if (valid && owned) {
                     const RowC& c = LONG ? cu : rows[rr];
                     double fsum = cs.facc[lane];
-                    if (LONG && st) {
+                    if (ST && st) {
                         // the S-point average of the interpolant through the 2 kStM + 1 centre values
                         fsum = 0.0;
 #pragma unroll
-                        for (int i = -kStM; i <= kStM; ++i) fsum = fma(cs.stw[i + kStM], 1.0 - cs.fc[lane + i], fsum);
+                        for (int i = -kStM; i <= kStM; ++i) fsum = fma(ss.stw[i + kStM], 1.0 - ss.fc[lane + i], fsum);
                     }
                     double m = (pl.n == 0) ? 1.0 : ((tier < 0) ? fsum / a.dS : 1.0 - fsum);
-                    if (eblike) m = (m + c.xeb) / (1.0 + c.xeb);
-                    if (a.model != TRX_MODEL_RAW) m = (m + c.fdil) / (1.0 + c.fdil);
-                    if (MODE == MODE_GRID && a.debug_nodes) m = (double)(nodes + (centre ? 1 : 0));    // bench/test knob: evaluations of this cell
+                    const RowC& cd = rows[rr];
+                    if (eblike) m = (m + cd.xeb) / (1.0 + cd.xeb);
+                    if (a.model != TRX_MODEL_RAW) m = (m + cd.fdil) / (1.0 + cd.fdil);
                     if (MODE == MODE_GRID) {
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
@@ -691,7 +725,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
                 // terms in different orders)
                 const double direct = wave_sum(lacc);
                 double h = (hmout[0] == 1.0 || n_time == 0) ? 0.5 * (__any(nonflat) ? direct : flat_sum) : NAN;
-                if (a.model == TRX_MODEL_EB && cu.excl != 0.0) h = INFINITY;      // :535-538
+                if (a.model == TRX_MODEL_EB && rows[0].excl != 0.0) h = INFINITY;   // :535-538
                 if (lane == 0) a.out[base] = h;
             } else if (lane < nb) {
                 double h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
@@ -706,6 +740,27 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], tm[i]);
 #endif
+}
+
+// Whether a launch uses the stencil is decided on the device (rowc_kernel looks at the time stamps),
+// so a launch that may use it enqueues BOTH instantiations and the one that does not apply returns
+// at once; each gets its own register allocation, and a launch without the stencil runs exactly
+// the code it ran before.  The empty launch still costs ~20 us of dispatch, so rowc_kernel leaves
+// its verdict in a host-visible memo keyed by the light curve (pointer, length, exposure): later
+// launches enqueue only the instantiation it predicts.  A stale memo (the address now holds another
+// light curve) is harmless -- the stencil instantiation falls back to the Gauss nodes when the
+// device finds no uniform grid, the other one never uses the stencil.
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
+__global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+{
+    double st_radius = 0.0;
+    if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
+        // centre-value stencil of a dense uniform grid: radius in half exposures, 0 = off
+        st_radius = uniform(a.rowc[a.n * kRowDoubles + kHdrStRadius]);
+        if (a.use_stencil == 1 && (st_radius > 0.0) != ST) return;
+        if (!ST) st_radius = 0.0;
+    }
+    cells_body<MODE, STEP, FP32, LONG, ST>(a, st_radius);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1110,6 +1165,39 @@ bool fill_tiers(TierTable& T, int S)
     return ok;
 }
 
+// ---- stencil memo (see cells_kernel) ------------------------------------------------------
+struct StencilMemo {
+    static constexpr int kSlots = 256;
+    struct Key { const void* time; int n_time, S, dev; double exptime; };
+    std::mutex mu;
+    int* flags = nullptr;            // pinned, host- and device-visible: 0 unknown, 1 no stencil, 2 stencil
+    Key keys[kSlots];
+    int used = 0, next = 0;
+    // the slot of this light curve (a fresh one starts as unknown), or null if pinned memory is not to be had
+    int* slot(const Key& k)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!flags) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&flags), kSlots * sizeof(int),
+                              hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                flags = nullptr;
+                return nullptr;
+            }
+            for (int i = 0; i < kSlots; ++i) flags[i] = 0;
+        }
+        for (int i = 0; i < used; ++i)
+            if (keys[i].time == k.time && keys[i].n_time == k.n_time && keys[i].S == k.S && keys[i].dev == k.dev &&
+                keys[i].exptime == k.exptime)
+                return flags + i;
+        const int i = (used < kSlots) ? used++ : (next++ % kSlots);
+        keys[i] = k;
+        flags[i] = 0;
+        return flags + i;
+    }
+};
+StencilMemo g_stencil_memo;
+
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
 std::atomic<int> g_cells_below{272};
 
@@ -1139,17 +1227,28 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const long want_grid = 8 * ((a.nbatch + 7) / 8);
     const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.use_stencil = (long_rows && a.use_tiers && g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
+    a.use_stencil = (long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
+                     g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
+    int verdict = 0;                       // of an earlier launch on this light curve: 1 no stencil, 2 stencil
+    if (a.use_stencil) {
+        int dev = 0;
+        TRX_HIP(hipGetDevice(&dev));
+        a.memo = g_stencil_memo.slot({a.time, a.n_time, a.S, dev, a.exptime});
+        if (a.memo) verdict = *static_cast<volatile int*>(a.memo);
+        if (verdict == 1 || verdict == 2) a.use_stencil = 2;
+    }
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
-    const size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
-                      + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
+    size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
+                + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
+    if (long_rows) head += sizeof(StencilState);
     static_assert((kCellsPairs + kCellsWindow) % 4 == 0 && sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
     a.tl_off = (int)(head / sizeof(double));
     size_t lds = head + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
     if (lds > 64 * 1024) {             // a long curve forced through the batched variant by a test knob
         long_rows = true;
+        head += sizeof(StencilState);
         lds = head;
         a.B = 1;
         a.nbatch = a.n;
@@ -1170,13 +1269,20 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
     const unsigned g2 = long_rows ? (unsigned)(8 * ((a.n + 7) / 8) < max_grid ? 8 * ((a.n + 7) / 8) : max_grid) : grid;
     if (long_rows) {
-        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true>), dim3(g2), dim3(64), lds, st, a);
-        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true>), dim3(g2), dim3(64), lds, st, a);
-        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true>), dim3(g2), dim3(64), lds, st, a);
+        if (verdict != 2) {
+            if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, false>), dim3(g2), dim3(64), lds, st, a);
+            else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true, false>), dim3(g2), dim3(64), lds, st, a);
+            else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, false>), dim3(g2), dim3(64), lds, st, a);
+        }
+        if (a.use_stencil && verdict != 1) {
+            if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, true>), dim3(g2), dim3(64), lds, st, a);
+            else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true, true>), dim3(g2), dim3(64), lds, st, a);
+            else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, true>), dim3(g2), dim3(64), lds, st, a);
+        }
     } else {
-        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, false>), dim3(g2), dim3(64), lds, st, a);
-        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, false>), dim3(g2), dim3(64), lds, st, a);
-        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false>), dim3(g2), dim3(64), lds, st, a);
+        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, false, false>), dim3(g2), dim3(64), lds, st, a);
+        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, false, false>), dim3(g2), dim3(64), lds, st, a);
+        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false, false>), dim3(g2), dim3(64), lds, st, a);
     }
     const hipError_t launched = hipGetLastError();
     if (capturing) TRX_HIP(hipFreeAsync(scratch, st));
@@ -1267,8 +1373,9 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     if (model == TRX_MODEL_RAW) return fail(TRX_ERR_ARG, "TRX_MODEL_RAW has no likelihood%s", "", 0);
     if (n == 0) return TRX_OK;
     if (!out_halfchi2 || (n_time > 0 && !flux)) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
-    RowsArgs a{model, flags, time, flux, n_time, sigma, params, n, exptime, nsupersample,
-               out_halfchi2, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+    RowsArgs a{};
+    a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
+    a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1279,8 +1386,10 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     if (int rc = check_rows(model, time, n_time, params, n, nsupersample)) return rc;
     if (n == 0) return TRX_OK;
     if (n_time > 0 && !out_flux) return fail(TRX_ERR_ARG, "null pointer%s", "", 0);
-    RowsArgs a{model, flags, time, nullptr, n_time, 1.0, params, n, exptime, nsupersample,
-               out_flux, out_secdepth, 0, 0, 0, g_debug_nodes.load(std::memory_order_relaxed), 0, 0, 0, nullptr, {}, 0.0, 0.0, 0.0};
+    RowsArgs a{};
+    a.model = model; a.flags = flags; a.time = time; a.n_time = n_time; a.sigma = 1.0;
+    a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_flux; a.out_sec = out_secdepth;
+    a.debug_nodes = g_debug_nodes.load(std::memory_order_relaxed);
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
