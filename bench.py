@@ -141,25 +141,23 @@ def collect_pmc(args):
                 return None
             if p.returncode != 0:
                 return None
-            # one likelihood launch = rowc_kernel (row constants to scratch) + cells_kernel<lnl> in its two
-            # instantiations (without / with the centre-value stencil: the one that does not apply returns
-            # at once); everything is counted, the launches are the dispatches of the first instantiation
-            per, total = set(), 0.0
+            # one likelihood launch = rowc_kernel (row constants to scratch) + cells_kernel<lnl> (one or both
+            # of its instantiations without / with the centre-value stencil; the one that does not apply
+            # returns at once): everything is counted and divided by the launches of the child's one step
+            from triceratops_amd import synth as _synth
+            launches, seen, total = len(_synth.FAMILIES), 0, 0.0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         if row["Counter_Name"] != counter:
                             continue
                         name = row["Kernel_Name"].replace(" ", "")
-                        if "cells_kernel<0" in name:
+                        if "cells_kernel<0" in name or "rowc_kernel" in name:
                             total += float(row["Counter_Value"])
-                            if ",false>(" in name:
-                                per.add(row["Dispatch_Id"])
-                        elif "rowc_kernel" in name:
-                            total += float(row["Counter_Value"])
-            if not per:
+                            seen += "cells_kernel<0" in name
+            if seen < launches:
                 return None
-            got[counter] = (total / len(per), len(per))
+            got[counter] = (total / launches, launches)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 on the read side; KB units
@@ -412,6 +410,21 @@ def run_grid(ctx):
             tf_all = plain_flop * cells_per_launch / (ms_all * 1e-3) / 1e12
             roof["all_subexposures"] = {"mean_launch_ms": ms_all, "tflops": tf_all, "frac": tf_all / FP64_VALU_PEAK_TF,
                                         "evals_per_s": cells_per_launch / (ms_all * 1e-3)}
+            # ... and with the centre-value stencil off (Gauss nodes in every cell): its own census and time
+            L_.trx_set_stencil(0)
+            try:
+                ev_g, _ = census(lambda i: rows_d[i], fams, t_d)
+                step(collective=False)
+                torch.cuda.synchronize(device)
+                e3 = events()
+                step(e3, collective=False)
+                torch.cuda.synchronize(device)
+            finally:
+                L_.trx_set_stencil(1)
+            ms_g = float(np.mean([a.elapsed_time(b) for (a, b) in e3]))
+            tf_g = ev_g * (F_ORBIT + F_MA) * cells_per_launch / (ms_g * 1e-3) / 1e12
+            roof["gauss_nodes_only"] = {"mean_launch_ms": ms_g, "model_evaluations_per_cell": ev_g, "tflops": tf_g,
+                                        "frac": tf_g / FP64_VALU_PEAK_TF, "evals_per_s": cells_per_launch / (ms_g * 1e-3)}
         tr = ctx["traffic"]
         if tr is None:
             tr = committed_traffic(n_time, n_rows)
@@ -425,8 +438,11 @@ def run_grid(ctx):
     roof["note"] = ("dominant kernel cells_kernel<lnl, one row per wave> (+ its prologue rowc_kernel, 2 %% of the launch) is fp64-VALU bound (no MFMA shape, ~0.05 B/eval of HBM "
                     "traffic). achieved = executed model evaluations (census of this run) x %d plain operations / "
                     "launch time. plain_algorithm_* prices the launch as if all %d sub-exposures of every cell "
-                    "had been evaluated; the kernel reaches those averages (to 1e-13) from 3-9 Gauss nodes, so "
-                    "that figure is an algorithmic-equivalence number, not a roofline fraction"
+                    "had been evaluated; the kernel reaches those averages (to 1e-13) from 3-9 Gauss nodes, and on "
+                    "this dense uniform grid from ONE evaluation per cell plus a 13-point stencil over the "
+                    "neighbours' centre values wherever no limb contact is near -- so that figure is an "
+                    "algorithmic-equivalence number, not a roofline fraction, and `frac` falls when a shortcut "
+                    "removes executed work (gauss_nodes_only: the same run with the stencil off)"
                     % (int(F_ORBIT + F_MA), synth.NSAMPLES))
 
     cpu = None

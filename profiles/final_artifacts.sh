@@ -14,6 +14,7 @@ python profiles/cells_batch_sweep.py 100000 50 100 200 > $O/${T}_cells_batch_swe
 python profiles/cells_batch_sweep.py 30000 100 >> $O/${T}_cells_batch_sweep.txt 2>&1
 python profiles/cells_batch_sweep.py 300000 100 >> $O/${T}_cells_batch_sweep.txt 2>&1
 python profiles/e2e_threads.py > $O/${T}_e2e_threads.txt 2>&1
+python profiles/stencil_check.py 2000 3000 > $O/${T}_stencil.txt 2>&1
 bash profiles/stats_e2e.sh ${T}e2e blend > $O/${T}_e2e_kernel_stats.txt 2>&1
 bash profiles/pmc_cells.sh ${T}2000 2000 100000 rows > /dev/null 2>&1
 bash profiles/pmc_cells.sh ${T}100 100 100000 cells > /dev/null 2>&1
