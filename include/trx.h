@@ -22,7 +22,7 @@
  *     trx_release_scratch() frees it all.  Do not enqueue on ONE stream from two host threads
  *     at once.  trx_lnl_batch, trx_flux_grid, trx_lnz_scenario and the reductions can be captured
  *     into a hipGraph (while `stream` is capturing, the scratch is a pair of graph memory nodes).
- *     The library's only other state is
+ *     The library's only other state is the stencil memo described under Diagnostics and
  *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
  *     read-only afterwards) and (ii) the process-wide tuning / diagnostics switches declared
  *     at the end of this header (atomics read once per enqueue; meant for benchmarks and
@@ -151,14 +151,17 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
  * 0 = automatic. */
 int trx_set_rows_per_wave(int rows);
 
-/* Diagnostics (process-wide switches, default 1 / 1 / 0; no reference counterpart):
+/* Diagnostics (process-wide switches, default 1 / 1 / 1 / 0; no reference counterpart):
  *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of
  *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
  *    model is analytic (the two agree to ~1e-13 in flux);
- *  - trx_set_stencil(0) (default 1): no centre-value stencil -- on a uniform time grid whose spacing is
- *    at most 0.3 exposures (stamps within 4 ulp of t0 + j dt) a cell far from every limb contact takes
- *    its exposure average from the instantaneous flux at the centres of its 13 nearest cells (one
- *    model evaluation per cell; error bound 1e-15, trx_kernels.hip) instead of 3-4 Gauss nodes;
+ *  - trx_set_stencil(0): no centre-value stencil -- on a uniform time grid of 1/7 .. 0.3 exposures per
+ *    cell (stamps within 4 ulp of t0 + j dt, light curves of 272 points and more) a cell far from
+ *    every limb contact takes its exposure average from the instantaneous flux at the centres of its
+ *    13 nearest cells (one model evaluation per cell; error bound 1e-15, trx_kernels.hip) instead of
+ *    3-4 Gauss nodes; the two agree to ~2e-14 in flux.  Whether a launch qualifies is decided on the
+ *    device; the library keeps the verdict per light curve (time pointer, length, exposure) in a small
+ *    pinned memo so that later launches enqueue one kernel instead of two (a hint only);
  *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
  *    exposure centre's solution;
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned

@@ -1229,8 +1229,11 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     a.use_stencil = (long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool capturing = capture == hipStreamCaptureStatusActive;
     int verdict = 0;                       // of an earlier launch on this light curve: 1 no stencil, 2 stencil
-    if (a.use_stencil) {
+    if (a.use_stencil && !capturing) {     // (a captured launch always carries both instantiations)
         int dev = 0;
         TRX_HIP(hipGetDevice(&dev));
         a.memo = g_stencil_memo.slot({a.time, a.n_time, a.S, dev, a.exptime});
@@ -1258,9 +1261,6 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
     const size_t scratch_bytes = ((size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
-    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
-    const bool capturing = capture == hipStreamCaptureStatusActive;
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     a.rowc = static_cast<double*>(scratch);
