@@ -195,6 +195,7 @@ static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
 {
     __shared__ RowC srows[64];
+    __shared__ RowC rows_out[64];
     __shared__ double secmin[64];
     __shared__ int secnan[64];
     const int lane = threadIdx.x;
@@ -334,9 +335,18 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
         c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
         c.excl = 0.0;
         fdil = c.fdil;
+        // through LDS to memory: 64 x 18 doubles leave the block as one contiguous 9 KB run (a lane
+        // writing its own 144-byte block made every store instruction touch 64 cache lines)
         const double* src = reinterpret_cast<const double*>(&c);
+        double* stage = reinterpret_cast<double*>(&rows_out[lane]);
 #pragma unroll
-        for (int q = 0; q < kRowDoubles; ++q) dst[q] = src[q];
+        for (int q = 0; q < kRowDoubles; ++q) stage[q] = src[q];
+    }
+    __syncthreads();
+    {
+        const double* src = reinterpret_cast<const double*>(rows_out);
+        double* out = a.rowc + base * kRowDoubles;
+        for (int i = lane; i < nb * kRowDoubles; i += 256) out[i] = src[i];
     }
     // the scan decides the exclusion rule of lnL_EB_p (likelihoods.py:535-538) and the secdepth
     // output of simulate_EB_transit_p; lnL_EB_twin_p (:542-587) uses neither
