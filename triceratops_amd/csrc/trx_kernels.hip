@@ -6,15 +6,17 @@
 //                             workgroup, lanes = rows; for EB rows the 25-point secondary-eclipse
 //                             scan with lanes = (row, point) -> depth / exclusion flag.  Output:
 //                             one 18-double block per row in stream-ordered scratch.
-//   cells_kernel<MODE, STEP, FP32, LONG>
+//   cells_kernel<MODE, STEP, FP32, LONG, ST>
 //                             the light-curve model and its chi^2.  One wavefront (64-thread
 //                             workgroup) per row (LONG) or per batch of rows (short curves); the
 //                             transit-window test files the in-window (row, time) cells in LDS,
 //                             each lane plans one cell (none, 3-9 Gauss nodes or all S
 //                             sub-exposures), and the (cell, node) pairs of 64 cells are dealt to
 //                             all lanes: orbit step from the cell's centre solution, Mandel-Agol
-//                             flux, term added to the cell's sum in LDS.  Result: chi^2/2 per row
-//                             (MODE_LNL) or the model row (MODE_GRID).
+//                             flux, term added to the cell's sum in LDS.  ST: on a dense uniform time
+//                             grid a cell far from the limb contacts takes its exposure average from
+//                             the centre values of its 13 nearest cells (one evaluation per cell).
+//                             Result: chi^2/2 per row (MODE_LNL) or the model row (MODE_GRID).
 //   chi2_grid_kernel          row reduction over a materialised (n, n_time) grid, HBM bound.
 //   lme_partial_kernel / lme_final_kernel
 //                             log-mean-exp: single pass online (max, sum exp) per thread,
