@@ -57,6 +57,10 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, long i
     return u0;
 }
 
+// x ** y for x >= 0 as exp(y ln x): ~|y ln x| ulp (a few 1e-15 relative here) instead of libm's
+// correctly rounded pow, whose double-double arithmetic is a third of this kernel's instructions
+__device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
+
 // Gamma(alpha, 1) by Marsaglia & Tsang (2000); alpha < 1 through Gamma(alpha + 1) U^(1/alpha).
 // Each attempt takes two counter blocks (a Box-Muller normal + the acceptance uniform).
 __device__ __forceinline__ double philox_gamma(unsigned long long seed, long i, unsigned slot, double alpha)
@@ -75,7 +79,7 @@ __device__ __forceinline__ double philox_gamma(unsigned long long seed, long i, 
         const double lu = log(1.0 - u2);              // log of a uniform in (0, 1]
         if (lu < 0.5 * x2 + d * (1.0 - v + log(v))) { g = d * v; break; }
     }
-    if (alpha < 1.0) g *= pow(1.0 - philox_uniform(seed, i, slot), 1.0 / alpha);   // sub-draw 0: the boost uniform
+    if (alpha < 1.0) g *= pow_pos(1.0 - philox_uniform(seed, i, slot), 1.0 / alpha);   // sub-draw 0: the boost uniform
     return g;
 }
 
@@ -116,24 +120,27 @@ __device__ __forceinline__ void stellar_relations(const Tables& T, double M, dou
 // funcs.flux_relation (funcs.py:121-140): 10 ** spline(M)
 __device__ __forceinline__ double flux_rel(const Tables& T, int which, double M)
 {
-    return pow(10.0, spline_eval(T.spl[which], M));
+    return exp(2.302585092994046 * spline_eval(T.spl[which], M));
 }
 
 // inverse CDF of a broken power law (priors.py:16-116, 168-383), constants from the host
 __device__ __forceinline__ double plaw_inv(const trx_power_law& L, double x)
 {
     if (L.ones) return 1.0;
-    double out = x;
     const double t0 = x / L.norm;
-    for (int j = 0; j < L.nseg; ++j) {
+    double arg = 0.0, ip = 0.0;
+    bool hit = false;
+    for (int j = 0; j < L.nseg; ++j) {       // the last matching segment wins, one power for all lanes
         const bool sel = (j == 0) ? (x <= L.hi[j]) : (x > L.lo[j] && x <= L.hi[j]);
         if (sel) {
             double t = (t0 - L.cum[j]) * L.p1[j];
             if (L.amp[j] != 0.0) t = t / L.amp[j];
-            out = pow(t + L.base[j], L.ip[j]);
+            arg = t + L.base[j];
+            ip = L.ip[j];
+            hit = true;
         }
     }
-    return out;
+    return hit ? pow_pos(arg, ip) : x;
 }
 
 // np.interp for increasing xp, end values held outside
@@ -157,7 +164,7 @@ __device__ __forceinline__ double bound_rate(const trx_draw_args& a, const Table
 {
     const double seps = a.dist_pc * interp(T.cc_con, T.cc_sep, a.n_cc, dm);
     const double s_au = seps * kAu;
-    const double lp = log10(pow(a.kepler_c * (s_au * s_au * s_au), 0.5) / 86400.0);
+    const double lp = log10(sqrt(a.kepler_c * (s_au * s_au * s_au)) / 86400.0);
     const double f1 = a.f1, f2 = a.f2, f3 = a.f3;
     const double alpha = 0.018, dlogP = 0.7;
     const double k = f2 - f1 - alpha * dlogP;
@@ -190,7 +197,7 @@ __device__ __forceinline__ double ratio(double f) { return f / (1.0 - f); }
 __device__ __forceinline__ double sma(double M_tot, double P_days)
 {
     const double ps = P_days * 86400.0;
-    return pow((kG * M_tot * kMsun) / (4.0 * kPi * kPi) * (ps * ps), 1.0 / 3.0);
+    return cbrt((kG * M_tot * kMsun) / (4.0 * kPi * kPi) * (ps * ps));
 }
 
 // marginal_likelihoods.py:111-123: inc >= inc_min, inc_min = 90 where Ptra > 1 (vector path);
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
             }
         } else {
             dEcc = rnd(a.uEcc, 5u);
-            ecc = pow(dEcc, a.ecc_pow);                                     // priors.py:146-155
+            ecc = pow_pos(dEcc, a.ecc_pow);                                 // priors.py:146-155
             dQ = rnd(a.uQ, 4u);
             const double q = plaw_inv(a.law_q, dQ);
             const double m = q * Mh;
