@@ -156,7 +156,7 @@ int trx_set_rows_per_wave(int rows);
  *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
  *    model is analytic (the two agree to ~1e-13 in flux);
  *  - trx_set_stencil(0): no centre-value stencil -- on a uniform time grid of 1/7 .. 0.3 exposures per
- *    cell (stamps within 4 ulp of t0 + j dt, light curves of 272 points and more) a cell far from
+ *    cell (stamps within 4 ulp of t0 + j dt, light curves of 320 points and more) a cell far from
  *    every limb contact takes its exposure average from the instantaneous flux at the centres of its
  *    13 nearest cells (one model evaluation per cell; error bound 1e-15, trx_kernels.hip) instead of
  *    3-4 Gauss nodes; the two agree to ~2e-14 in flux.  Whether a launch qualifies is decided on the
@@ -170,7 +170,7 @@ int trx_set_supersample_tiers(int on);
 int trx_set_stencil(int on);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
-/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 272) are
+/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 320) are
  *    processed in batches of rows per wave (the (row, time) cells of ~640 cells' worth of rows walked
  *    64 at a time across row boundaries, light curve staged in LDS), longer ones one row per wave;
  *    0 = never.  Model values agree to rounding between the two; chi^2 differs by summation order. */

@@ -36,7 +36,7 @@ class TrxError(RuntimeError):
 # puts TRX_FLAG_FP32_MODEL here (BASELINE config 5); the plain wrappers below take explicit flags
 EXTRA_FLAGS = 0
 # library default of trx_set_cell_packing_below (tests and A/B scripts restore it)
-CELL_PACKING_BELOW = 272
+CELL_PACKING_BELOW = 320
 # work counters of the scenario layer (bench.py reads them): rows and (row, time) cells that
 # went through trx_lnz_scenario since the last reset
 STATS = {"rows": 0, "cells": 0, "launches": 0}

@@ -136,9 +136,9 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 //   * rowc_kernel derives the row constants of 64 rows per workgroup -- lanes = rows, then lanes =
 //     (row, point) for the secondary-eclipse scan -- and stores the 18-double blocks in device
 //     scratch (144 B per row, stream-ordered allocation inside the call);
-//   * cells_kernel takes one row (LONG, 272 points and more) or a batch of B <= 22 rows per wave.
+//   * cells_kernel takes one row (LONG, 320 points and more) or a batch of B <= 22 rows per wave.
 //     The (row, time) cells form ONE index space, cell = r * n_time + j, walked in windows of
-//     kCellsWindow cells: pass 1 applies the transit-window test to 64 cells at a time (across row
+//     cells_window() cells: pass 1 applies the transit-window test to 64 cells at a time (across row
 //     boundaries), settles the out-of-window cells (model exactly 1) and files the in-window ones,
 //     in order, in a list in LDS; pass 2 takes that list 64 cells at a time: each lane plans its
 //     cell (Kepler solve at the exposure centre + node count), then the (cell, node) PAIRS of the
@@ -165,7 +165,11 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 #define TRX_CELLS_WINDOW 1024
 #endif
 constexpr int kCellsMaxRows = 22;
-constexpr int kCellsWindow = TRX_CELLS_WINDOW;     // cells per window pass (in-window list in LDS)
+// cells per window pass (in-window list in LDS): 1024 with one row per wave; 768 for batches, whose
+// ~640 cells fit one window -- the smaller list lets one more wave onto a CU at 200-300 points
+// (18.5 -> 17.5 ms per 18 launches at 200 points; 1000-point rows lose 2 % with it)
+constexpr int kCellsWindowLong = TRX_CELLS_WINDOW, kCellsWindowBatch = 768;
+__host__ __device__ constexpr int cells_window(bool long_rows) { return long_rows ? kCellsWindowLong : kCellsWindowBatch; }
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
 // Launch header behind the row blocks in scratch: [0] chi^2 of the flat model, [1] stencil radius
@@ -425,6 +429,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     double* hmout = hacc + B;                                         // [B] diluted model of an unocculted cell: 1, or NaN
     double* tier_xw = hmout + B;
     unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
+    constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
     StencilState& ss = *reinterpret_cast<StencilState*>(&cs + 1);        // LONG only (behind the cell state)
@@ -1219,7 +1224,7 @@ struct StencilMemo {
 StencilMemo g_stencil_memo;
 
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{272};
+std::atomic<int> g_cells_below{320};
 
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
@@ -1264,14 +1269,15 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
     size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
-                + (kCellsPairs + kCellsWindow) * sizeof(unsigned short) + sizeof(CellState);
+                + (kCellsPairs + cells_window(long_rows)) * sizeof(unsigned short) + sizeof(CellState);
     if (long_rows) head += sizeof(StencilState);
-    static_assert((kCellsPairs + kCellsWindow) % 4 == 0 && sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
+    static_assert((kCellsPairs + kCellsWindowLong) % 4 == 0 && (kCellsPairs + kCellsWindowBatch) % 4 == 0 &&
+                  sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
     a.tl_off = (int)(head / sizeof(double));
     size_t lds = head + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
     if (lds > 64 * 1024) {             // a long curve forced through the batched variant by a test knob
         long_rows = true;
-        head += sizeof(StencilState);
+        head += sizeof(StencilState) + (kCellsWindowLong - kCellsWindowBatch) * sizeof(unsigned short);
         lds = head;
         a.B = 1;
         a.nbatch = a.n;
