@@ -301,6 +301,9 @@ def run_grid(ctx):
     import torch
     import torch.distributed as dist
     from triceratops_amd import _lib, synth
+    # every row this mode counts is evaluated: the likelihood calls do not skip the rows that lnL_EB_p's
+    # secondary-eclipse rule excludes anyway (the default, which the e2e leg below runs with)
+    _lib.lib().trx_set_skip_excluded(0)
     args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
     if args.all_subexposures:
         _lib.lib().trx_set_supersample_tiers(0)
@@ -450,6 +453,7 @@ def run_grid(ctx):
         cpu = cpu_baseline(t, flux, rows_h, fams, args.cpu_seconds)
     e2e = None
     if ctx["extras"] and not args.no_e2e and world == 1:
+        _lib.lib().trx_set_skip_excluded(1)          # the product's default
         e2e = e2e_calc_probs(args.threads or 4)
 
     return {
@@ -503,12 +507,19 @@ def run_batch(ctx):
         step(jobs, 10 + w)
     _sync(ctx)
     _lib.reset_stats()
+    import ctypes
+    skipped = ctypes.c_ulonglong(0)
+    _lib.check(_lib.lib().trx_skipped_rows(None, 1))          # clears the device counter
     t0 = time.perf_counter()
     for s in range(args.steps):
         out = step(jobs, 100 + s)
     _sync(ctx)
     elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
     stats = dict(_lib.STATS)
+    # rows whose light curve was not evaluated: lnL_EB_p's secondary-eclipse rule gives them +inf anyway
+    _lib.check(_lib.lib().trx_skipped_rows(ctypes.byref(skipped), 1))
+    stats["skipped_rows"] = int(skipped.value)
+    stats["cells"] -= stats["skipped_rows"] * args.n_time
     fpps = [float(tg.FPP) for tg in out]         # of the last timed step (the targets are updated in place)
     n_scen = sum(len(tg.lnZ) for tg in out)
     # Not timed: one more step with events around every likelihood launch and sampled parameter blocks
@@ -519,7 +530,7 @@ def run_batch(ctx):
     _sync(ctx)
     trace, _lib.TRACE = _lib.TRACE, None
     # cells evaluated over all ranks
-    cells = torch.tensor([float(stats["cells"]), float(stats["rows"])], dtype=torch.float64,
+    cells = torch.tensor([float(stats["cells"]), float(stats["rows"]), float(stats["skipped_rows"])], dtype=torch.float64,
                          device="cpu" if ctx["debug_one"] or world == 1 else device)
     if world > 1:
         import torch.distributed as dist
@@ -543,7 +554,9 @@ def run_batch(ctx):
         ev_cells += float(c.sum())
         tot += float(c.numel())
     evals_per_cell = ev_cells / max(tot, 1.0)
-    achieved = evals_per_cell * (F_ORBIT + F_MA) * cells_rank0 / max(kern_s, 1e-12) / 1e12
+    # the traced launches skip the excluded rows too: scale by the evaluated share of the timed steps
+    evaluated_share = float(stats["cells"]) / max(float(stats["cells"]) + float(stats["skipped_rows"]) * args.n_time, 1.0)
+    achieved = evals_per_cell * (F_ORBIT + F_MA) * cells_rank0 * evaluated_share / max(kern_s, 1e-12) / 1e12
     return {
         "metric": "light-curve-point x sample evals/sec", "value": float(cells[0]) / elapsed,
         "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -552,11 +565,12 @@ def run_batch(ctx):
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
                                "light curves, calc_probs_many with device-side sampling, %d host threads per rank; "
-                               "value counts the (draw, time) cells that pass the geometry mask and reach the model"
+                               "value counts the (draw, time) cells that pass the geometry mask and are evaluated (the draws that lnL_EB_p's secondary-eclipse rule excludes are not: rows_not_evaluated_per_step)"
                                % (args.tois, args.batch_n, args.n_time, args.threads),
                    "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
                    "evaluated_cells_per_step": float(cells[0]) / args.steps,
-                   "evaluated_rows_per_step": float(cells[1]) / args.steps,
+                   "evaluated_rows_per_step": (float(cells[1]) - float(cells[2])) / args.steps,
+                   "rows_not_evaluated_per_step": float(cells[2]) / args.steps,
                    "nominal_evals_per_s": nominal / elapsed,
                    "calc_probs_per_s": args.tois * args.steps / elapsed,
                    "parallelism": "lnZ_* units dealt to %d ranks by cost (LPT), one all_gather of the tables" % world},

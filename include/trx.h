@@ -151,7 +151,7 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
  * 0 = automatic. */
 int trx_set_rows_per_wave(int rows);
 
-/* Diagnostics (process-wide switches, default 1 / 1 / 1 / 0; no reference counterpart):
+/* Diagnostics (process-wide switches, default 1 / 1 / 1 / 1 / 0; no reference counterpart):
  *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of
  *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
  *    model is analytic (the two agree to ~1e-13 in flux);
@@ -162,12 +162,20 @@ int trx_set_rows_per_wave(int rows);
  *    3-4 Gauss nodes; the two agree to ~2e-14 in flux.  Whether a launch qualifies is decided on the
  *    device; the library keeps the verdict per light curve (time pointer, length, exposure) in a small
  *    pinned memo so that later launches enqueue one kernel instead of two (a hint only);
+ *  - trx_set_skip_excluded(0): lnL_EB_p gives +inf to a draw whose secondary eclipse is deeper than
+ *    1.5 sigma whatever its light curve (likelihoods.py:535-538); by default trx_lnl_batch /
+ *    trx_lnz_scenario / trx_scenario_evidence do not evaluate the light curve of such a row (half of the
+ *    EB draws of a typical run).  0 = evaluate it all the same (benchmarks that count every row).
+ *    trx_skipped_rows(&n, reset) reads (and clears) the number of rows skipped on the current device
+ *    (it synchronises the device);
  *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
  *    exposure centre's solution;
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
  *    for each cell instead of the flux. */
 int trx_set_supersample_tiers(int on);
 int trx_set_stencil(int on);
+int trx_set_skip_excluded(int on);
+int trx_skipped_rows(unsigned long long* out, int reset);
 int trx_set_kepler_stepping(int on);
 int trx_set_debug_node_counts(int on);
 /*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 320) are

@@ -6,6 +6,7 @@ from triceratops_amd import _lib, synth
 n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 times = [int(x) for x in sys.argv[2:]] or [100, 200]
 L = _lib.lib()
+L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
 L.trx_set_cell_packing_below(1 << 30)
 for n_time in times:
     rng = np.random.default_rng(synth.SEED)

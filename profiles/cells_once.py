@@ -8,6 +8,7 @@ n_time = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 which = sys.argv[3] if len(sys.argv) > 3 else "cells"
 L = _lib.lib()
+L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
 L.trx_set_cell_packing_below((1 << 30) if which == "cells" else 0)
 rng = np.random.default_rng(synth.SEED)
 t = synth.time_grid(n_time); t_d = _lib.dev(t)

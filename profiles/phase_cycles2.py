@@ -11,6 +11,7 @@ t = synth.time_grid(n_time); t_d = _lib.dev(t)
 curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)
 f_d = _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy()))
 L = _lib.lib()
+L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
 L.trx_debug_phase_cycles.argtypes = [ctypes.c_void_p]
 out = (ctypes.c_ulonglong * 8)()
 names = {0: ["row blocks", "window pass", "plans", "pairs", "-", "rest", "-", "total"],

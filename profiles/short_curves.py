@@ -9,6 +9,7 @@ from triceratops_amd import _lib, synth
 
 n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 L = _lib.lib()
+L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
 print("# %s, %d rows per family, 18 families; evals/s = n_time x rows x 18 / time of the 18 launches" % (
     os.path.basename(_lib.LIB_PATH), n_rows))
 for n_time in ([int(x) for x in sys.argv[2:]] or (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000)):

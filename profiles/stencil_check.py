@@ -8,6 +8,7 @@ from triceratops_amd import _lib, synth
 n_time = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 nr = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 L = _lib.lib()
+L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
 rng = np.random.default_rng(synth.SEED)
 t = synth.time_grid(n_time); t_d = _lib.dev(t)
 curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)

@@ -660,3 +660,33 @@ def test_stencil_memo_is_only_a_hint():
         assert np.array_equal(np.isnan(got), np.isnan(ref[name]))
         if name == "j":
             assert np.array_equal(got, ref[name], equal_nan=True) or np.nanmax(np.abs(got - ref[name])) < 1e-13
+
+
+def test_rows_excluded_by_the_secondary_rule_are_skipped_not_changed():
+    """lnL_EB_p gives +inf to a draw with a deep secondary eclipse whatever its light curve: the kernels do
+    not evaluate such rows (default) -- same results as evaluating them, and the counter says how many"""
+    import ctypes
+    L = _lib.lib()
+    for n_time in (120, 900):
+        rng, t, flux = _lc(n_time, seed=5)
+        rows = synth.eb_rows(rng, 5000, False, True)
+        t_d, f_d, r_d = _lib.dev(t), _lib.dev(flux), _lib.dev(rows)
+        n = ctypes.c_ulonglong(0)
+        res = {}
+        try:
+            for on in (1, 0):
+                L.trx_set_skip_excluded(on)
+                _lib.check(L.trx_skipped_rows(None, 1))
+                res[on] = _lib.lnl_batch(1, 0, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20).cpu().numpy()
+                _lib.check(L.trx_skipped_rows(ctypes.byref(n), 1))
+                res["n%d" % on] = int(n.value)
+        finally:
+            L.trx_set_skip_excluded(1)
+        assert np.array_equal(res[1], res[0])
+        assert res["n0"] == 0 and res["n1"] == int(np.isinf(res[1]).sum()) > 1000
+        # twin rows and grids are never skipped
+        _lib.check(L.trx_skipped_rows(None, 1))
+        _lib.lnl_batch(2, 0, t_d, f_d, synth.SIGMA, _lib.dev(synth.eb_rows(rng, 500, True)), synth.EXPTIME, 20)
+        _lib.flux_grid(1, 0, t_d, r_d[:, :200].contiguous(), synth.EXPTIME, 20)
+        _lib.check(L.trx_skipped_rows(ctypes.byref(n), 1))
+        assert n.value == 0

@@ -77,6 +77,7 @@ struct RowsArgs {
     int use_stencil;   // 0: no stencil.  rowc_kernel looks for a dense uniform time grid (centre-value stencil,
                        // cells_kernel<LONG>); 1: both instantiations of cells_kernel are enqueued and the one
                        // that does not apply returns; 2: only the instantiation the memo predicts is enqueued
+    int skip_excl;     // cells_kernel<lnl>: rows the EB secondary rule excludes (+inf whatever the model) are not evaluated
     int* memo;         // rowc_kernel: where to leave the verdict for later launches on this light curve (or null)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
@@ -113,6 +114,10 @@ __device__ unsigned long long g_phase_cycles[8];
 #define TRX_TICK(var)
 #define TRX_TOCK(slot, from)
 #endif
+
+// rows whose light curve was not evaluated because lnL_EB_p's secondary-eclipse rule excludes them
+// anyway (statistics for benchmarks: trx_skipped_rows)
+__device__ unsigned long long g_skipped_rows;
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
 __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
@@ -491,6 +496,18 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             hmout[lane] = m1;
         }
         __syncthreads();
+        // lnL_EB_p returns +inf for a draw whose secondary eclipse is deeper than 1.5 sigma, whatever its
+        // light curve looks like (likelihoods.py:535-538): such rows are not evaluated at all
+        unsigned long long skipmask = 0;
+        if (MODE == MODE_LNL && a.skip_excl && a.model == TRX_MODEL_EB) {
+            skipmask = __ballot(lane < nb && rows[lane].excl != 0.0);
+            if (lane == 0 && skipmask) atomicAdd(&g_skipped_rows, (unsigned long long)__popcll(skipmask));
+            if (LONG && skipmask) {                  // the wave's only row: done
+                if (lane == 0) a.out[base] = INFINITY;
+                __syncthreads();
+                continue;
+            }
+        }
         // LONG: the row constants are wave-uniform -- held in scalar registers they cost no VGPRs
         // and no LDS reads in the pair loop
         // (the window, dilution and exclusion constants are used once per 64 cells: those stay in LDS)
@@ -528,7 +545,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     const double dMc = reduce_2pi(phase);
                     const double slack = 1e-15 * fabs(phase);
                     const RowC& cw = rows[rr];                       // (LONG: rr = 0)
-                    inw = in_window(cw.wlo - slack, cw.whi + slack, dMc);
+                    inw = in_window(cw.wlo - slack, cw.whi + slack, dMc) && !((skipmask >> rr) & 1ull);
                     // no occultation anywhere in the exposure: the model is 1, diluted
                     if (MODE == MODE_GRID && (!inw || a.debug_nodes))
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
@@ -1085,6 +1102,7 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
+std::atomic<int> g_skip_excluded{1};  // rows excluded by the EB secondary rule are not evaluated (likelihood calls)
 std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
 std::atomic<int> g_debug_nodes{0};  // grid mode writes the number of model evaluations per cell instead of the flux
 bool compute_tiers(TierTable& T, int S)
@@ -1265,6 +1283,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         if (a.memo) verdict = *static_cast<volatile int*>(a.memo);
         if (verdict == 1 || verdict == 2) a.use_stencil = 2;
     }
+    a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed);
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
@@ -1555,6 +1574,25 @@ int trx_set_cell_packing_below(int n_time)
 {
     if (n_time < 0) return fail(TRX_ERR_ARG, "n_time threshold must be >= 0%s (got %ld)", "", (long)n_time);
     g_cells_below = n_time;
+    return TRX_OK;
+}
+
+/* diagnostics (include/trx.h): 0 = evaluate the light curve of every row, also of those the EB rule excludes */
+int trx_set_skip_excluded(int on)
+{
+    g_skip_excluded = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* statistics (include/trx.h): rows skipped on the current device since the last reset */
+int trx_skipped_rows(unsigned long long* out, int reset)
+{
+    TRX_HIP(hipDeviceSynchronize());
+    if (out) TRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_skipped_rows), sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero = 0;
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_skipped_rows), &zero, sizeof(zero)));
+    }
     return TRX_OK;
 }
 
