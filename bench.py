@@ -131,9 +131,12 @@ def collect_pmc(args):
     got = {}
     tmp = tempfile.mkdtemp(prefix="trx_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # third pass: the fp64 instructions the launch issues (wave instructions; one pass holds all four)
+        insts = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "INSTS"):
             out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
+            names = list(insts) if counter == "INSTS" else [counter]
+            cmd = [exe, "--pmc"] + names + ["--kernel-trace", "--output-format", "csv", "-d", out, "--"] + child
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True,
                                    text=True, timeout=420)
@@ -145,25 +148,38 @@ def collect_pmc(args):
             # of its instantiations without / with the centre-value stencil; the one that does not apply
             # returns at once): everything is counted and divided by the launches of the child's one step
             from triceratops_amd import synth as _synth
-            launches, seen, total = len(_synth.FAMILIES), 0, 0.0
+            launches, seen, totals = len(_synth.FAMILIES), 0, {k: 0.0 for k in names}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] != counter:
+                        if row["Counter_Name"] not in totals:
                             continue
                         name = row["Kernel_Name"].replace(" ", "")
                         if "cells_kernel<0" in name or "rowc_kernel" in name:
-                            total += float(row["Counter_Value"])
-                            seen += "cells_kernel<0" in name
+                            totals[row["Counter_Name"]] += float(row["Counter_Value"])
+                            seen += ("cells_kernel<0" in name) and row["Counter_Name"] == names[0]
             if seen < launches:
+                if counter == "INSTS":
+                    continue                      # the traffic passes stand on their own
                 return None
-            got[counter] = (total / launches, launches)
+            if counter == "INSTS":
+                got[counter] = {k: v / launches for k, v in totals.items()}
+            else:
+                got[counter] = (totals[counter] / launches, launches)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 on the read side; KB units
     bytes_ = (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    issued = None
+    if "INSTS" in got:
+        i_ = got["INSTS"]
+        issued = {"fma_f64": i_["SQ_INSTS_VALU_FMA_F64"], "mul_f64": i_["SQ_INSTS_VALU_MUL_F64"],
+                  "add_f64": i_["SQ_INSTS_VALU_ADD_F64"], "trans_f64": i_["SQ_INSTS_VALU_TRANS_F64"],
+                  # wave instructions x 64 lanes, an fma = 2 flops; idle lanes of a wave are counted as issued
+                  "flop_per_launch": 64.0 * (2.0 * i_["SQ_INSTS_VALU_FMA_F64"] + i_["SQ_INSTS_VALU_MUL_F64"]
+                                             + i_["SQ_INSTS_VALU_ADD_F64"])}
     return {"bytes_per_launch": bytes_, "fetch_size_kb": got["FETCH_SIZE"][0], "write_size_kb": got["WRITE_SIZE"][0],
-            "launches": got["FETCH_SIZE"][1],
+            "launches": got["FETCH_SIZE"][1], "issued": issued,
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command, in this run; "
                       "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 read-side factor, MI355X_MICROARCH.md)"}
 
@@ -433,6 +449,13 @@ def run_grid(ctx):
             tr = committed_traffic(n_time, n_rows)
         roof["traffic"] = tr["bytes_per_launch"] if tr else None
         roof["traffic_detail"] = tr
+        if tr and tr.get("issued"):
+            # the hardware's view beside the executed-work fraction: fp64 flops the launch ISSUES (PMC child run
+            # of this command), whatever they were spent on
+            tf_i = tr["issued"]["flop_per_launch"] / mean_launch_s / 1e12
+            roof["issued_fp64"] = {"tflops": tf_i, "frac": tf_i / FP64_VALU_PEAK_TF,
+                                   "wave_instructions_per_launch": {k: tr["issued"][k] for k in
+                                                                    ("fma_f64", "mul_f64", "add_f64", "trans_f64")}}
         kernels = hbm_kernels(ctx, f_d, n_time)
     else:
         # no census in this run: price every cell at ONE model evaluation (a lower bound of the executed work)
