@@ -15,6 +15,12 @@ def set_sampling(mode):
     _set(mode)
 
 
+def get_sampling():
+    """the current sampling mode ('numpy', 'numpy-device' or 'device')"""
+    from .marginal_likelihoods import _sampling
+    return _sampling["mode"]
+
+
 def set_precision(mode):
     """'fp64' (default) or 'fp32' (BASELINE config 5: fp32 flux model, fp64 orbit / chi^2 /
     log-mean-exp accumulators) for everything evaluated through lnZ_* and calc_probs."""
