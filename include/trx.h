@@ -19,8 +19,9 @@
  *     (device, stream) inside the library -- 144 B per row for the per-row constants, the draw
  *     block of trx_scenario_evidence -- which serves call after call on that stream and only
  *     grows (the stream is synchronised before a buffer is replaced by a larger one);
- *     trx_release_scratch() frees it all.  Do not enqueue on ONE stream from two host threads
- *     at once.  trx_lnl_batch, trx_flux_grid, trx_lnz_scenario and the reductions can be captured
+ *     trx_release_scratch() frees it all.  Two host threads that enqueue on ONE stream take turns (a
+ *     per-stream lock is held while a call enqueues its kernels; the stream's order does the rest).
+ *     trx_lnl_batch, trx_flux_grid, trx_lnz_scenario and the reductions can be captured
  *     into a hipGraph (while `stream` is capturing, the scratch is a pair of graph memory nodes).
  *     The library's only other state is the stencil memo described under Diagnostics and
  *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
@@ -291,8 +292,9 @@ size_t trx_draw_args_size(void);   /* sizeof(trx_draw_args): lets a foreign bind
  *             of trx_draw_args.cols; draw 0 when no draw passes the mask), then lnZ, then the
  *             number of draws that passed the mask
  *   out_flag  HOST, [1]: trx_draw_args.flag
- * The call synchronises `stream` twice (the masked counts size the likelihood launches; the
- * result) and returns with `out` filled. */
+ * Nothing inside the call waits for the device: the masked counts stay there (the likelihood kernels
+ * read them from device memory and their grids are sized for a guess), so trx_scenario_evidence is the
+ * enqueue below followed by ONE hipStreamSynchronize, after which `out` is filled. */
 #define TRX_SCENARIO_OUT 16
 typedef struct {
     const trx_draw_args* draw;
@@ -306,6 +308,15 @@ typedef struct {
     int* out_flag;
 } trx_scenario_args;
 int trx_scenario_evidence(const trx_scenario_args* args, void* stream);
+/* The same call without the final synchronisation: everything is enqueued on `stream` and the function
+ * returns.  args->out / args->out_flag are ignored; the record arrives in
+ *   out   HOST, [2 * TRX_SCENARIO_OUT + 1] doubles: the branch records as above, then the flag as a double.
+ * Give pinned memory (hipHostMalloc / torch pin_memory) so that the copy is asynchronous; `out` is valid once
+ * the stream has passed the call (hipStreamSynchronize, an event).  `args` and everything it points to on the
+ * host may be reused as soon as the function returns; the device tables it names must stay alive until the
+ * stream has passed the call.  A caller can enqueue every lnZ_* call of a calc_probs on a few streams and wait
+ * once. */
+int trx_scenario_enqueue(const trx_scenario_args* args, double* out, void* stream);
 size_t trx_scenario_args_size(void);
 
 /* Frees the per-stream scratch described above (every device); all streams must be idle. */

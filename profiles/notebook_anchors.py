@@ -14,11 +14,14 @@ import anchors  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 sampling = sys.argv[2] if len(sys.argv) > 2 else "device"
+raw_out = sys.argv[3] if len(sys.argv) > 3 else None      # .npz with every run's lnZ / prob / FPP / R_p
+raw = {}
 np.set_printoptions(linewidth=200, precision=4)
 for case in anchors.CASES:
     t0 = time.perf_counter()
     lnZ, prob, fpp, rp = anchors.run_many(case, range(1000, 1000 + n_seeds), sampling=sampling)
     dt = time.perf_counter() - t0
+    raw.update({case + "_lnZ": lnZ, case + "_prob": prob, case + "_FPP": fpp, case + "_Rp": rp})
     nb_prob, nb_fpp, nb_rp = anchors.notebook(case)
     print("==== %s: %d runs, N = 1e6, %s sampling, %.2f s per run" % (case, n_seeds, sampling, dt / n_seeds))
     print("%-7s %12s %12s %12s %12s   %12s" % ("", "mean lnZ", "std lnZ", "mean prob", "std prob", "notebook prob"))
@@ -42,3 +45,5 @@ for case in anchors.CASES:
         print("FPP notebook 20 runs: %.4f +- %.4f" % tuple(anchors.A["toi465_FPP20_cc"]))
     print("best-fit TP R_p: ours mean %.3f std %.3f  notebook %.3f" % (rp.mean(), rp.std(), nb_rp))
     sys.stdout.flush()
+if raw_out:
+    np.savez_compressed(raw_out, **raw)

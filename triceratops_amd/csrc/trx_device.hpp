@@ -720,4 +720,37 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
     return acc / dS;
 }
 
+// ---------------------------------------------------------------------------------------
+// log-mean-exp partial state: running max m (finite or -inf), s = sum exp(x - m), pinf = saw +inf.
+// NaN and -inf carry zero weight (_numerics.py:48).
+struct Lme {
+    double m, s;
+    int pinf;
+};
+
+__device__ __forceinline__ void lme_merge(Lme& a, const Lme& b)
+{
+    a.pinf |= b.pinf;
+    if (b.m == -INFINITY) return;
+    if (a.m == -INFINITY) { a.m = b.m; a.s = b.s; return; }
+    if (b.m > a.m) { a.s = fma(a.s, exp(a.m - b.m), b.s); a.m = b.m; }
+    else           { a.s = fma(b.s, exp(b.m - a.m), a.s); }
+}
+
+// blocks a vector of n log-weights is reduced by (the partition decides the bits of the sum)
+__host__ __device__ inline int lme_blocks(long n)
+{
+    const long want = (n + 256L * 8 - 1) / (256L * 8);
+    return (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+}
+
+// torch.argmin's order: NaN before everything, then the smallest value; ties -> the lowest index
+__device__ __forceinline__ bool argmin_before(double a, long ia, double b, long ib)
+{
+    const bool na = a != a, nb = b != b;
+    if (na != nb) return na;
+    if (!na && a != b) return a < b;
+    return ia < ib;
+}
+
 }  // namespace trx

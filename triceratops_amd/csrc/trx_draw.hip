@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "../../include/trx.h"
+#include "trx_internal.hpp"
 
 namespace {
 
@@ -211,9 +212,14 @@ __device__ __forceinline__ bool transits(double Ptra, double inc, bool parallel)
     return parallel ? hit : (hit && ok);
 }
 
-__global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
+// blk_cnt != null (trx_scenario_evidence): workgroup b takes the `per` consecutive draws from b * per and
+// leaves the number of its draws that passed the mask(s) in blk_cnt[b] (and blk_cnt[gridDim.x + b] for the
+// twin branch) -- the first half of the ordered compaction (compact_kernel, trx_scenario.hip).  A draw's
+// numbers depend on its index only, so the mapping of draws to threads changes no result.
+__global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restrict__ blk_cnt, long per)
 {
     __shared__ Tables T;
+    __shared__ int wave_cnt[2][4];
     {
         double* dst = reinterpret_cast<double*>(&T);
         const int nspl = TRX_DRAW_N_SPLINES * TRX_DRAW_SPLINE_DOUBLES;
@@ -224,7 +230,14 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
     __syncthreads();
     const long N = a.N;
     const bool parallel = a.parallel != 0;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    int hits = 0, hits_twin = 0;
+    long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x, i_end = N, i_step = (long)gridDim.x * blockDim.x;
+    if (blk_cnt) {
+        i_first = (long)blockIdx.x * per + threadIdx.x;
+        i_end = ((long)(blockIdx.x + 1) * per < N) ? (long)(blockIdx.x + 1) * per : N;
+        i_step = blockDim.x;
+    }
+    for (long i = i_first; i < i_end; i += i_step) {
         // a random input: the staged array, or the kernel's own Philox stream
         auto rnd = [&](const double* staged, unsigned slot) -> double {
             return staged ? staged[i] : philox_uniform(a.seed, i, slot);
@@ -303,7 +316,9 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
             const double size = rp * kRearth + Rh * kRsun;
             const double Ptra = size / sm * ((1.0 + ecc * sinw) / (1.0 - ecc * ecc));
             const bool coll = size > sm * (1.0 - ecc);
-            a.mask[i] = (transits(Ptra, inc, parallel) && !coll && extra) ? 1 : 0;
+            const bool m0 = transits(Ptra, inc, parallel) && !coll && extra;
+            a.mask[i] = m0 ? 1 : 0;
+            hits += m0 ? 1 : 0;
             col[0 * N] = rp; col[1 * N] = P; col[2 * N] = inc; col[3 * N] = sm; col[4 * N] = Rh;
             col[5 * N] = u1; col[6 * N] = u2; col[7 * N] = ecc; col[8 * N] = w; col[9 * N] = frc;
             col[10 * N] = Mh;
@@ -344,6 +359,8 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
             if (!parallel) m2 = m2 && (Ptra <= 1.0);      // the loop `continue`s before the twin test
             a.mask[i] = m1 ? 1 : 0;
             a.mask_twin[i] = m2 ? 1 : 0;
+            hits += m1 ? 1 : 0;
+            hits_twin += m2 ? 1 : 0;
             col[0 * N] = r; col[1 * N] = fr; col[2 * N] = P; col[3 * N] = inc; col[4 * N] = sm;
             col[5 * N] = Rh; col[6 * N] = u1; col[7 * N] = u2; col[8 * N] = ecc; col[9 * N] = w;
             col[10 * N] = frc; col[11 * N] = sm2; col[12 * N] = m; col[13 * N] = Mh;
@@ -397,17 +414,28 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a)
             dd[5 * N] = dEcc; dd[6 * N] = dW; dd[7 * N] = (double)k; dd[8 * N] = dBeta;
         }
     }
+    if (blk_cnt) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            hits += __shfl_xor(hits, o, 64);
+            hits_twin += __shfl_xor(hits_twin, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { wave_cnt[0][threadIdx.x >> 6] = hits; wave_cnt[1][threadIdx.x >> 6] = hits_twin; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            blk_cnt[blockIdx.x] = wave_cnt[0][0] + wave_cnt[0][1] + wave_cnt[0][2] + wave_cnt[0][3];
+            blk_cnt[gridDim.x + blockIdx.x] = wave_cnt[1][0] + wave_cnt[1][1] + wave_cnt[1][2] + wave_cnt[1][3];
+        }
+    }
 }
 
 }  // namespace
 
 extern "C" size_t trx_draw_args_size(void) { return sizeof(trx_draw_args); }
 
-extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
+namespace {
+int check_draw_args(const trx_draw_args& a)
 {
-    if (!args || args->N < 0) return TRX_ERR_ARG;
-    if (args->N == 0) return TRX_OK;
-    const trx_draw_args& a = *args;
     if (!a.cols || !a.mask || !a.splines || !a.flag) return TRX_ERR_ARG;
     if (!a.planet && !a.mask_twin) return TRX_ERR_ARG;
     if (!a.use_philox) {         // every random input the scenario consumes must be staged
@@ -419,8 +447,34 @@ extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
     }
     if ((a.comp == TRX_COMP_FIELD || a.host == TRX_HOST_FIELD) && (!a.f_fr || (!a.idx && a.n_field_draw < 1))) return TRX_ERR_ARG;
     if (a.n_cc < 0 || a.n_cc > TRX_DRAW_MAX_CC || a.n_lut < 0 || a.n_lut > TRX_DRAW_MAX_LUT) return TRX_ERR_ARG;
+    return TRX_OK;
+}
+}  // namespace
+
+extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
+{
+    if (!args || args->N < 0) return TRX_ERR_ARG;
+    if (args->N == 0) return TRX_OK;
+    const trx_draw_args& a = *args;
+    if (int rc = check_draw_args(a)) return rc;
     long blocks = (a.N + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       (int*)nullptr, 0L);
+    return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
+}
+
+// The draw kernel with per-workgroup mask counts (trx_internal.hpp): workgroup b takes draws
+// [b * per, (b + 1) * per), blk_cnt holds [2][groups] counts afterwards.
+int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* groups_out, hipStream_t st)
+{
+    if (a.N < 1 || !blk_cnt) return TRX_ERR_ARG;
+    if (int rc = check_draw_args(a)) return rc;
+    long per = (a.N + kDrawMaxGroups - 1) / kDrawMaxGroups;
+    per = ((per + 255) / 256) * 256;
+    const int groups = (int)((a.N + per - 1) / per);
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)groups), dim3(256), 0, st, a, blk_cnt, per);
+    *per_out = per;
+    *groups_out = groups;
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "../../include/trx.h"
+
 namespace trx {
 
 // Per-(device, stream) scratch owned by the library.  Work on one stream is ordered, so a buffer can
@@ -10,9 +12,44 @@ namespace trx {
 // synchronised first, then hipFree + hipMalloc), and it is released by trx_release_scratch().
 //   slot 0  row-constant blocks of a likelihood call (rowc_kernel -> cells_kernel)
 //   slot 1  trx_scenario_evidence: buffers sized by the number of draws
-//   slot 2  trx_scenario_evidence: buffers sized by the number of masked draws
+//   slot 2  (unused since round 3: the masked draws are read in place)
 //   slot 3  (host, pinned) small results on their way back
 constexpr int kScratchSlots = 4;
 hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out);
+
+// Held while a call enqueues its kernels on `st`: two host threads that share a stream take turns, so
+// the kernels of one call (rowc_kernel -> cells_kernel -> reductions, all on the stream's scratch) are
+// enqueued back to back and the stream's order does the rest.  Re-entrant on the owning thread.
+class StreamLock {
+public:
+    explicit StreamLock(hipStream_t st);
+    ~StreamLock();
+    StreamLock(const StreamLock&) = delete;
+    StreamLock& operator=(const StreamLock&) = delete;
+
+private:
+    void* mu_;
+};
+
+// The likelihood of the draws that passed a geometry mask, read in place from the draw kernel's
+// [n_param][src_stride] block: row r = draw src_idx[r], r < *n_dev (both left on the device by earlier
+// kernels of the stream; n_upper bounds the count).  twin: the EB_TWIN rows (2 P, a of 2 P).
+int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
+              const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
+              int twin, double exptime, int nsupersample, double* out_halfchi2, hipStream_t st);
+
+// First pass of the evidence and of the best-draw search over those chi^2/2 values: per-block
+// (max, sum exp, saw +inf) partials in ws[3 * 2048] and (value, position) argmin partials in
+// amin_pv / amin_pi [2048]; lme_blocks(*n_dev) of them are valid.
+int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
+              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, hipStream_t st);
+
+// trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
+// [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)
+constexpr int kDrawMaxGroups = 4096;
+int draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* groups_out, hipStream_t st);
+
+// fail() of trx_kernels.hip for the other translation units (thread-local message of trx_last_error)
+int fail_hip(hipError_t e);
 
 }  // namespace trx

@@ -81,6 +81,17 @@ struct RowsArgs {
     int* memo;         // rowc_kernel: where to leave the verdict for later launches on this light curve (or null)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
+    // Rows counted on the device (trx_scenario_evidence: the draws that passed the geometry mask): when
+    // n_dev is set the kernels read the row count from it and `n` is only its upper bound (grid, scratch);
+    // the rows-per-wave of the batched variant and the batch count follow from the count on the device
+    // (same rule as on the host: batch_rows), `B` being the LDS layout's maximum.
+    const long* n_dev;
+    // Row r of the block is draw src_idx[r] of a [n_param][src_stride] block (the draw kernel's columns):
+    // the masked draws are read in place instead of being gathered into a block of their own.
+    const int* src_idx;
+    long src_stride;
+    int twin_cols;     // EB_TWIN rows of the draw kernel's block: P = 2 * column 2, a = column 11
+    int forced_B;      // trx_set_rows_per_wave
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -177,6 +188,21 @@ constexpr int kCellsWindowLong = TRX_CELLS_WINDOW, kCellsWindowBatch = 768;
 __host__ __device__ constexpr int cells_window(bool long_rows) { return long_rows ? kCellsWindowLong : kCellsWindowBatch; }
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
+// Rows per wave of the batched variant: about 640 cells per wave, at most kCellsMaxRows rows.  Measured
+// (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 -- larger
+// batches fill the chunks better, but the batches of a launch differ in work (rows with long transits),
+// and with fewer, longer waves the last round over the chip's wave slots leaves more of them idle.
+// Few rows: fill the chip's 4096 wave slots first.  `n` < 0: the largest value any n gives (LDS layout).
+__host__ __device__ inline int batch_rows(long n, int n_time, int forced)
+{
+    int B = (640 + n_time / 2) / (n_time > 0 ? n_time : 1);
+    B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
+    if (forced > 0) return forced > kCellsMaxRows ? kCellsMaxRows : forced;
+    if (n >= 0)
+        while (B > 1 && n / B < 10000) B = (B + 1) / 2;
+    return B;
+}
+
 // Launch header behind the row blocks in scratch: [0] chi^2 of the flat model, [1] stencil radius
 // (0 = no stencil), [2 .. 2 + 2 kStM] stencil weights.
 //
@@ -203,22 +229,18 @@ static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 // eighth of an EB row's work at 100 points, and one wave per 64 rows leaves the chip a third full.
 // Only the secondary orbits are staged in LDS (9 KB); the scan's minimum is taken with LDS atomics
 // (min ignores NaN, so NaN is flagged separately).
-__global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
+__device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, const long blk, RowC* srows, RowC* rows_out,
+                                           double* secmin, int* secnan)
 {
-    __shared__ RowC srows[64];
-    __shared__ RowC rows_out[64];
-    __shared__ double secmin[64];
-    __shared__ int secnan[64];
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
     const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
-    const long n = a.n;
-    const long base = (long)blockIdx.x * 64;
-    const int nb = (int)((n - base < 64) ? (n - base) : 64);
+    const long base = blk * 64;
+    const int nb = (int)((n - base < 64) ? (n - base < 0 ? 0 : n - base) : 64);
     double ysec = 0.0, fdil = 0.0;
     double* dst = a.rowc + (base + lane) * kRowDoubles;
-    if (blockIdx.x == 0 && a.flux && (lane >> 6) == 3) {
+    if (blk == 0 && a.flux && (lane >> 6) == 3) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
         double acc = 0.0;
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
         acc = wave_sum(acc);
         if ((lane & 63) == 0) a.rowc[n * kRowDoubles + kHdrFlat] = acc;
     }
-    if (blockIdx.x == 0 && (lane >> 6) == 2) {
+    if (blk == 0 && (lane >> 6) == 2) {
         // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
         double* hdr = a.rowc + n * kRowDoubles;
         const int l = lane & 63, nt = a.n_time;
@@ -292,24 +314,30 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
         }
     }
     if (lane < nb) {
-        const double* p = a.params + base + lane;
+        // row r = column r of the [n_param][n] block, or draw src_idx[r] of a [n_param][src_stride] one
+        const double* p = a.params + (a.src_idx ? (long)a.src_idx[base + lane] : base + lane);
+        const long ps = a.src_idx ? a.src_stride : n;
         RowC c;
         double u1, u2;
         if (a.model == TRX_MODEL_RAW) {
-            u1 = p[7 * n]; u2 = p[8 * n];
-            orbit_init(c, p[0], p[1 * n], p[2 * n], p[3 * n], p[4 * n], p[5 * n], p[6 * n], a.exptime);
+            u1 = p[7 * ps]; u2 = p[8 * ps];
+            orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
             c.xeb = 0.0; c.fdil = 0.0;
         } else {
             double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
             if (a.model == TRX_MODEL_TP) {
                 const double R_p = p[0];
-                per = p[1 * n]; inc = p[2 * n]; acm = p[3 * n]; R_s = p[4 * n];
-                u1 = p[5 * n]; u2 = p[6 * n]; e = p[7 * n]; argp = p[8 * n]; comp_fr = p[9 * n];
+                per = p[1 * ps]; inc = p[2 * ps]; acm = p[3 * ps]; R_s = p[4 * ps];
+                u1 = p[5 * ps]; u2 = p[6 * ps]; e = p[7 * ps]; argp = p[8 * ps]; comp_fr = p[9 * ps];
                 k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
             } else {
-                const double R_EB = p[0], eb_fr = p[1 * n];
-                per = p[2 * n]; inc = p[3 * n]; acm = p[4 * n]; R_s = p[5 * n];
-                u1 = p[6 * n]; u2 = p[7 * n]; e = p[8 * n]; argp = p[9 * n]; comp_fr = p[10 * n];
+                const double R_EB = p[0], eb_fr = p[1 * ps];
+                per = p[2 * ps]; inc = p[3 * ps]; acm = p[4 * ps]; R_s = p[5 * ps];
+                u1 = p[6 * ps]; u2 = p[7 * ps]; e = p[8 * ps]; argp = p[9 * ps]; comp_fr = p[10 * ps];
+                if (a.twin_cols) {                   // marginal_likelihoods.py:300-339: twice the period and its a
+                    per = per * 2.0;
+                    acm = p[11 * ps];
+                }
                 feb = eb_fr / (1.0 - eb_fr);                            // :401
                 k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
                 ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
@@ -384,6 +412,22 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
         if (a.out_sec) a.out_sec[base + lane] = secdepth;
     }
 }
+
+__global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
+{
+    __shared__ RowC srows[64];
+    __shared__ RowC rows_out[64];
+    __shared__ double secmin[64];
+    __shared__ int secnan[64];
+    const long n = a.n_dev ? *a.n_dev : a.n;
+    const long nblk = (n + 63) / 64;
+    // one block of 64 rows per workgroup; with the row count on the device the grid is a guess and the
+    // workgroups stride over the blocks (block 0 always runs: it writes the launch header)
+    for (long blk = blockIdx.x; blk < (nblk > 0 ? nblk : 1); blk += gridDim.x) {
+        rowc_block(a, n, blk, srows, rows_out, secmin, secnan);
+        __syncthreads();
+    }
+}
 static_assert(offsetof(RowC, excl) == (kRowDoubles - 1) * sizeof(double), "excl is the last field of RowC");
 
 // per-cell state of the chunk in flight (lane = cell), read by the lanes its pairs are dealt to
@@ -428,11 +472,11 @@ template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
 __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_radius)
 {
     extern __shared__ double lds[];
-    const int B = LONG ? 1 : a.B;
+    const int Bl = LONG ? 1 : a.B;                                    // rows the LDS layout holds
     RowC* rows = reinterpret_cast<RowC*>(lds);
-    double* hacc = lds + (size_t)B * kRowDoubles;                     // [B] chi^2 corrections per row
-    double* hmout = hacc + B;                                         // [B] diluted model of an unocculted cell: 1, or NaN
-    double* tier_xw = hmout + B;
+    double* hacc = lds + (size_t)Bl * kRowDoubles;                    // [Bl] chi^2 corrections per row
+    double* hmout = hacc + Bl;                                        // [Bl] diluted model of an unocculted cell: 1, or NaN
+    double* tier_xw = hmout + Bl;
     unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
     constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
@@ -452,10 +496,21 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     }
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
-    const long n = a.n;
     const double s2 = a.s2;
     const int n_time = a.n_time;
     const float inv_nt = 1.0f / (float)n_time;
+    // the row count: known to the host, or left on the device by an earlier kernel of the stream (the
+    // rows per wave and the batch count then follow here, by the host's rule)
+    long n = a.n, nbatch = a.nbatch;
+    int B = Bl;
+    if (a.n_dev) {
+        n = *a.n_dev;
+        if (!LONG) {
+            B = batch_rows(n, n_time, a.forced_B);
+            B = B < Bl ? B : Bl;
+        }
+        nbatch = (n + B - 1) / B;
+    }
 #ifdef TRX_PHASE_TIMERS
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     TRX_TICK(t_all);
@@ -472,10 +527,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
     if (ST && lane <= 2 * kStM) ss.stw[lane] = hdr[kHdrStW + lane];
 
-    const long per_xcd = (a.nbatch + 7) / 8;
+    const long per_xcd = (nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
         const long batch = (v & 7) * per_xcd + (v >> 3);
-        if ((v >> 3) >= per_xcd || batch >= a.nbatch) continue;
+        if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
         const long base = batch * B;
         const int nb = (int)((n - base < B) ? (n - base) : B);
         TRX_TICK(t_pro);
@@ -787,10 +842,20 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
 __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
 {
+    if (a.n_dev) {
+        // the grid was sized for an upper bound of the row count: the blocks beyond the batches leave at once
+        const long nd = *a.n_dev;
+        int B = 1;
+        if (!LONG) {
+            B = batch_rows(nd, a.n_time, a.forced_B);
+            B = B < a.B ? B : a.B;
+        }
+        if ((long)blockIdx.x >= 8 * (((nd + B - 1) / B + 7) / 8)) return;
+    }
     double st_radius = 0.0;
     if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
         // centre-value stencil of a dense uniform grid: radius in half exposures, 0 = off
-        st_radius = uniform(a.rowc[a.n * kRowDoubles + kHdrStRadius]);
+        st_radius = uniform(a.rowc[(a.n_dev ? *a.n_dev : a.n) * kRowDoubles + kHdrStRadius]);
         if (a.use_stencil == 1 && (st_radius > 0.0) != ST) return;
         if (!ST) st_radius = 0.0;
     }
@@ -837,19 +902,7 @@ __global__ __launch_bounds__(256) void chi2_grid_kernel(const double* __restrict
 // ---------------------------------------------------------------------------------------
 // log-mean-exp.  Partial state per thread: running max m (finite or -inf), s = sum exp(x - m),
 // pinf = saw +inf.  NaN and -inf carry zero weight (_numerics.py:48).
-struct Lme {
-    double m, s;
-    int pinf;
-};
-
-__device__ __forceinline__ void lme_merge(Lme& a, const Lme& b)
-{
-    a.pinf |= b.pinf;
-    if (b.m == -INFINITY) return;
-    if (a.m == -INFINITY) { a.m = b.m; a.s = b.s; return; }
-    if (b.m > a.m) { a.s = fma(a.s, exp(a.m - b.m), b.s); a.m = b.m; }
-    else           { a.s = fma(b.s, exp(b.m - a.m), a.s); }
-}
+// (struct Lme, lme_merge: trx_device.hpp)
 
 // x_i = c0 - h_i + lnprior_i (fused lnZ tail) when h != null, else x_i = logw_i
 __device__ __forceinline__ double lme_value(const double* logw, const double* h,
@@ -902,15 +955,32 @@ __device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double 
 #define TRX_LME_QUEUE 8
 #endif
 
+
+// SCEN (trx_scenario_evidence): the element count comes from the device (n_dev; the grid was sized for
+// its upper bound and the blocks beyond lme_blocks(n) leave at once), lnprior is indexed by the draw
+// (src_idx: the masked draws are not gathered), and the pass also finds the first minimum of h
+// (argmin partials behind the 3 * 2048 sums of the workspace).
+template <bool SCEN>
 __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
                                                           const double* __restrict__ h,
                                                           const double* __restrict__ lnprior,
                                                           double c0, long n, int vec_ok,
-                                                          double* __restrict__ ws)
+                                                          double* __restrict__ ws,
+                                                          const long* __restrict__ n_dev,
+                                                          const int* __restrict__ src_idx,
+                                                          double* __restrict__ amin_pv, long* __restrict__ amin_pi)
 {
     typedef double dvec2 __attribute__((ext_vector_type(2)));
     Lme st{-INFINITY, 0.0, 0};
-    long stride = (long)gridDim.x * blockDim.x;
+    unsigned nblocks = gridDim.x;
+    if (SCEN) {
+        n = *n_dev;
+        nblocks = (unsigned)lme_blocks(n);
+        if (blockIdx.x >= nblocks) return;
+    }
+    double amin_v = INFINITY;          // SCEN: this thread's first minimum of h
+    long amin_i = -1;
+    long stride = (long)nblocks * blockDim.x;
     long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {
         // 16 B per lane per load, TRX_LME_LOADS independent loads per trip (issuing the next
@@ -929,7 +999,7 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         // apart: 6.35 TB/s on the 3.2 GB stress vector against 5.75 with the usual grid-stride loop,
         // where a block's consecutive loads are gridDim x 4 KB apart (profiles/r02_lme_variants.txt).
         const long nv_all = n >> 1;
-        const long seg = ((nv_all + gridDim.x - 1) / gridDim.x + 255) & ~255L;
+        const long seg = ((nv_all + nblocks - 1) / nblocks + 255) & ~255L;
         const long seg0 = (long)blockIdx.x * seg;
         const long nv = (seg0 + seg < nv_all) ? (seg0 + seg) : nv_all;
         stride = blockDim.x;
@@ -956,7 +1026,9 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                 long j = v0 + u * stride;
                 j = (j < nv) ? j : (nv - 1);
                 a[u] = __builtin_nontemporal_load(&src[j]);
-                if (pri) p[u] = __builtin_nontemporal_load(&pri[j]);
+                if (SCEN) {
+                    if (lnprior) { p[u].x = lnprior[src_idx[2 * j]]; p[u].y = lnprior[src_idx[2 * j + 1]]; }
+                } else if (pri) p[u] = __builtin_nontemporal_load(&pri[j]);
             }
         };
         dvec2 cur[kL], curp[kL], nxt[kL], nxtp[kL];
@@ -968,11 +1040,16 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
 #pragma unroll
             for (int u = 0; u < kL; ++u) {
                 dvec2 a = cur[u];
+                const bool ok = v + u * stride < nv;
+                if (SCEN && ok) {
+                    const long e = 2 * (v + u * stride);
+                    if (amin_i < 0 || argmin_before(a.x, e, amin_v, amin_i)) { amin_v = a.x; amin_i = e; }
+                    if (argmin_before(a.y, e + 1, amin_v, amin_i)) { amin_v = a.y; amin_i = e + 1; }
+                }
                 if (h) {
                     a = c0 - a;
                     if (pri) a += curp[u];
                 }
-                const bool ok = v + u * stride < nv;
                 x[2 * u] = ok ? a.x : -INFINITY;
                 x[2 * u + 1] = ok ? a.y : -INFINITY;
             }
@@ -1017,7 +1094,17 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         }
         flush();
         if (st.m == INFINITY) { st.pinf = 1; st.m = -INFINITY; st.s = 0.0; }
-        if ((n & 1) && tid == 0) lme_fold4(st, lme_value(logw, h, lnprior, c0, n - 1), -INFINITY, -INFINITY, -INFINITY);
+        if ((n & 1) && tid == 0) {
+            if (SCEN) {
+                const double hv = h[n - 1];
+                if (amin_i < 0 || argmin_before(hv, n - 1, amin_v, amin_i)) { amin_v = hv; amin_i = n - 1; }
+                double x = c0 - hv;
+                if (lnprior) x += lnprior[src_idx[n - 1]];
+                lme_fold4(st, x, -INFINITY, -INFINITY, -INFINITY);
+            } else {
+                lme_fold4(st, lme_value(logw, h, lnprior, c0, n - 1), -INFINITY, -INFINITY, -INFINITY);
+            }
+        }
     } else {
         for (long i0 = tid * 4; i0 < n; i0 += stride * 4) {
             double x[4];
@@ -1038,8 +1125,21 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
     }
     __shared__ double sm[4], ss[4];
     __shared__ int sp[4];
+    __shared__ double av[4];
+    __shared__ long ai[4];
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sm[wave] = st.m; ss[wave] = st.s; sp[wave] = st.pinf; }
+    if (SCEN) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(amin_v, o, 64);
+            const long oi = __shfl_xor(amin_i, o, 64);
+            if (oi >= 0 && (amin_i < 0 || argmin_before(ov, oi, amin_v, amin_i))) { amin_v = ov; amin_i = oi; }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sm[wave] = st.m; ss[wave] = st.s; sp[wave] = st.pinf;
+        if (SCEN) { av[wave] = amin_v; ai[wave] = amin_i; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         Lme t{sm[0], ss[0], sp[0]};
@@ -1047,6 +1147,14 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         ws[3 * blockIdx.x + 0] = t.m;
         ws[3 * blockIdx.x + 1] = t.s;
         ws[3 * blockIdx.x + 2] = (double)t.pinf;
+        if (SCEN) {
+            double bv = av[0];
+            long bi = ai[0];
+            for (int w = 1; w < 4; ++w)
+                if (ai[w] >= 0 && (bi < 0 || argmin_before(av[w], ai[w], bv, bi))) { bv = av[w]; bi = ai[w]; }
+            amin_pv[blockIdx.x] = bv;
+            amin_pi[blockIdx.x] = bi;
+        }
     }
 }
 
@@ -1247,28 +1355,28 @@ std::atomic<int> g_cells_below{320};
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
 {
+    trx::StreamLock turn(st);            // rowc_kernel and cells_kernel of one call share the stream's scratch
     RowsArgs a = a0;
-    // short curves: about 640 cells per wave, at most kCellsMaxRows rows.  Measured
-    // (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 --
-    // larger batches fill the chunks better, but the batches of a launch differ in work (rows with
-    // long transits), and with fewer, longer waves the last round over the chip's wave slots leaves
-    // more of them idle.
-    int B = 1;
-    if (!long_rows) {
-        B = (640 + a.n_time / 2) / a.n_time;
-        B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
-        const int forced = g_rows_per_wave.load(std::memory_order_relaxed);
-        if (forced > 0) B = forced > kCellsMaxRows ? kCellsMaxRows : forced;
-        else while (B > 1 && a.n / B < 10000) B = (B + 1) / 2;    // few rows: fill the chip's 4096 wave slots first
-    }
-    a.B = B;
+    // rows per wave (batch_rows); with the row count on the device the LDS layout takes the largest value
+    a.forced_B = g_rows_per_wave.load(std::memory_order_relaxed);
+    a.B = long_rows ? 1 : batch_rows(a.n_dev ? -1 : a.n, a.n_time, a.forced_B);
     a.s2 = a.sigma * a.sigma;
     a.dS = (double)a.S;
     a.rS = 1.0 / a.dS;
     a.nbatch = (a.n + a.B - 1) / a.B;
     const long max_grid = 1L << 20;
-    const long want_grid = 8 * ((a.nbatch + 7) / 8);
-    const unsigned grid = (unsigned)(want_grid < max_grid ? want_grid : max_grid);
+    // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
+    // keeps 2-11 % of them, so the grid takes a quarter of the bound -- blocks
+    // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
+    auto grid_for = [&](long batches) -> unsigned {
+        if (a.n_dev) {
+            batches = (batches + 3) / 4;
+            batches = batches < 4096 ? 4096 : batches;
+        }
+        const long want = 8 * ((batches + 7) / 8);
+        return (unsigned)(want < max_grid ? want : max_grid);
+    };
+    const unsigned grid = grid_for(a.nbatch);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     a.use_stencil = (long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
@@ -1309,10 +1417,14 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     a.rowc = static_cast<double*>(scratch);
-    hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)((a.n + 63) / 64)), dim3(256), 0, st, a);
+    {
+        long rb = (a.n + 63) / 64;
+        if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
+        hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)rb), dim3(256), 0, st, a);
+    }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
-    const unsigned g2 = long_rows ? (unsigned)(8 * ((a.n + 7) / 8) < max_grid ? 8 * ((a.n + 7) / 8) : max_grid) : grid;
+    const unsigned g2 = long_rows ? grid_for(a.n) : grid;
     if (long_rows) {
         if (verdict != 2) {
             if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, false>), dim3(g2), dim3(64), lds, st, a);
@@ -1347,13 +1459,13 @@ int launch_lme(const double* logw, const double* h, const double* lnprior, doubl
 {
     if (workspace_bytes < trx_workspace_bytes() || !workspace)
         return fail(TRX_ERR_WORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)trx_workspace_bytes());
-    long want = (n + 256L * 8 - 1) / (256L * 8);
-    int blocks = (int)(want < 1 ? 1 : (want > kLmeMaxBlocks ? kLmeMaxBlocks : want));
+    const int blocks = lme_blocks(n);
+    static_assert(kLmeMaxBlocks == 2048, "lme_blocks");
     double* ws = static_cast<double*>(workspace);
     const uintptr_t al = (uintptr_t)(h ? h : logw) | (uintptr_t)lnprior;
     const int vec_ok = (al % 16 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(lme_partial_kernel, dim3(blocks), dim3(256), 0, st, logw, h, lnprior, c0, n,
-                       vec_ok, ws);
+    hipLaunchKernelGGL(lme_partial_kernel<false>, dim3(blocks), dim3(256), 0, st, logw, h, lnprior, c0, n,
+                       vec_ok, ws, (const long*)nullptr, (const int*)nullptr, (double*)nullptr, (long*)nullptr);
     TRX_HIP(hipGetLastError());
     hipLaunchKernelGGL(lme_final_kernel, dim3(1), dim3(64), 0, st, ws, blocks, n_total, out);
     TRX_HIP(hipGetLastError());
@@ -1377,18 +1489,28 @@ namespace {
 struct ScratchEntry {
     void* p[kScratchSlots] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[kScratchSlots] = {0, 0, 0, 0};
+    std::recursive_mutex mu;             // StreamLock: one call at a time enqueues on the stream
 };
 std::mutex g_scratch_mu;
-std::map<std::pair<int, hipStream_t>, ScratchEntry> g_scratch;
+std::map<std::pair<int, hipStream_t>, ScratchEntry> g_scratch;      // (node addresses are stable)
+
+ScratchEntry* scratch_entry(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    return &g_scratch[std::make_pair(dev, st)];
+}
 }  // namespace
+
+StreamLock::StreamLock(hipStream_t st) : mu_(&scratch_entry(st)->mu) { static_cast<std::recursive_mutex*>(mu_)->lock(); }
+StreamLock::~StreamLock() { static_cast<std::recursive_mutex*>(mu_)->unlock(); }
 
 hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
 {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    ScratchEntry& en = g_scratch[std::make_pair(dev, st)];
+    ScratchEntry& en = *scratch_entry(st);
+    std::lock_guard<std::recursive_mutex> lock(en.mu);
+    hipError_t e = hipSuccess;
     if (en.cap[slot] < bytes) {
         // earlier launches on this stream may still read the old buffer
         if (en.p[slot]) {
@@ -1404,6 +1526,34 @@ hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
     }
     *out = en.p[slot];
     return hipSuccess;
+}
+
+int fail_hip(hipError_t e) { return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipGetErrorString(e), (long)e); }
+
+int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
+              const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
+              int twin, double exptime, int nsupersample, double* out_halfchi2, hipStream_t st)
+{
+    if (int rc = check_rows(model, time, n_time, cols, n_upper, nsupersample)) return rc;
+    if (model == TRX_MODEL_RAW || !n_dev || !src_idx || !out_halfchi2 || n_upper < 1 || (n_time > 0 && !flux))
+        return fail(TRX_ERR_ARG, "lnl_draws: bad argument%s", "", 0);
+    RowsArgs a{};
+    a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
+    a.params = cols; a.n = n_upper; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
+    a.n_dev = n_dev; a.src_idx = src_idx; a.src_stride = src_stride; a.twin_cols = twin;
+    return launch_rows<MODE_LNL>(a, st);
+}
+
+int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
+              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, hipStream_t st)
+{
+    if (!halfchi2 || !n_dev || !src_idx || !ws || !amin_pv || !amin_pi || ((uintptr_t)halfchi2 % 16) != 0)
+        return fail(TRX_ERR_ARG, "lme_draws: bad argument%s", "", 0);
+    const double c0 = -0.5 * log(kTwoPi) - lnsigma;   // marginal_likelihoods.py:130 etc.
+    hipLaunchKernelGGL(lme_partial_kernel<true>, dim3(lme_blocks(n_upper)), dim3(256), 0, st, (const double*)nullptr,
+                       halfchi2, lnprior, c0, n_upper, 1, ws, n_dev, src_idx, amin_pv, amin_pi);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
 }
 }  // namespace trx
 

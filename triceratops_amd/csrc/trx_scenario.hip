@@ -1,34 +1,41 @@
-// trx_scenario_evidence (include/trx.h): one lnZ_* call of calc_probs, end to end on the device.
+// trx_scenario_evidence / trx_scenario_enqueue (include/trx.h): one lnZ_* call of calc_probs, end to end
+// on the device, with no host synchronisation inside the call.
 //
-// The Python host of round 2 strung a lnZ_* call together from ~30 launches (draw kernel, torch
-// nonzero / index_select / argmin / cat, likelihood, log-mean-exp) and two host syncs; with the
-// kernels where they are now that glue -- 25 torch operators and their Python dispatch under the
-// GIL -- is what bounds calc_probs_many on many host threads.  Here the whole call is one C entry
-// point: draw kernel -> ordered compaction of the geometry mask(s) (rocPRIM select) -> gather of
-// the masked parameter block -> rowc_kernel + cells_kernel -> log-mean-exp -> first-minimum of
-// chi^2 -> the best draw's columns, lnZ and the masked count in ONE small device-to-host copy.
-// Two stream syncs per call (the masked counts size the likelihood launches; the result), no
-// Python in between: ctypes releases the GIL for the duration of the call.  Every buffer lives in
-// the stream's scratch (trx_internal.hpp): hipMallocAsync / hipFreeAsync cost ~60 us per call on
-// this stack (profiles/r02_g_native_call.txt), 14 buffers a call more than the kernels saved.
-//
-// It returns what calc_probs keeps of a scenario (triceratops.py:804-817 ...: the best draw and
-// lnZ); the 100-row best-fit table of a direct lnZ_* call stays on the torch path of fused.py.
+// Round 2's version strung the call together from 12 (planet) or 23 (binary) launches and synchronised
+// the stream twice: the number of draws that pass the geometry mask sized the likelihood launch, so the
+// host had to read it.  Here the count never leaves the device:
+//   draw_kernel         the per-draw half of the scenario (trx_draw.hip); workgroup b takes draws
+//                       [b per, (b + 1) per) and also leaves its mask counts
+//   compact_kernel      ordered compaction of the mask(s): a workgroup sums the counts of the workgroups
+//                       before it and appends the indices of its own masked draws, ascending (the order
+//                       numpy's / torch's nonzero gives) -> idx[branch][], n[branch]
+//   rowc_kernel         } the likelihood of the masked draws, read IN PLACE from the draw kernel's columns
+//   cells_kernel        } through idx (no gathered parameter block); the row count is read from n[branch]
+//                         on the device and the grids are sized for a guess (trx_kernels.hip)
+//   lme_partial_kernel  first pass of the log-mean-exp and of the search for the smallest chi^2, one pass
+//   final_kernel        the evidence, the best draw (first of equals, NaN first: numpy's / torch's
+//                       argmin), its columns, the masked count and the limb-darkening flag -> one record
+// 6 launches for a planet scenario, 9 for a binary one (two branches), one 264-byte copy to the host,
+// NO sync: a caller can enqueue every lnZ_* call of a calc_probs on a few streams and wait once
+// (trx_scenario_enqueue); trx_scenario_evidence is the same followed by one hipStreamSynchronize.
+// Every buffer lives in the stream's scratch (trx_internal.hpp).  Results are bit for bit those of the
+// torch-operator chain of fused.py (same kernels on the same rows in the same order).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <math.h>
-
 #include <string.h>
 
 #include "../../include/trx.h"
+#include "trx_device.hpp"
 #include "trx_internal.hpp"
 
 namespace {
 
+using trx::Lme;
+
 #define TRXS_HIP(call)                                   \
     do {                                                 \
         hipError_t e_ = (call);                          \
-        if (e_ != hipSuccess) return TRX_ERR_HIP;        \
+        if (e_ != hipSuccess) return trx::fail_hip(e_);  \
     } while (0)
 
 // bump allocator over one of the stream's scratch buffers (trx_internal.hpp): sizes first, then pointers
@@ -45,118 +52,117 @@ struct Arena {
     T* at(size_t off) const { return reinterpret_cast<T*>(base + off); }
 };
 
-// block[p][i] = cols[p][idx[i]] for the nblk likelihood parameters; the twin branch runs at twice
-// the period with the semi-major axis of that period (marginal_likelihoods.py:300-339: row 2 = P,
-// row 4 = a, a at 2 P_orb is column 11 of the draw kernel's block)
-__global__ __launch_bounds__(256) void gather_block_kernel(const double* __restrict__ cols, long N,
-                                                           const long* __restrict__ idx, const long* __restrict__ count,
-                                                           int nblk, int twin, const double* __restrict__ lnprior,
-                                                           double* __restrict__ block, double* __restrict__ lp)
-{
-    const long n = *count;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const long src = idx[i];
-        for (int p = 0; p < nblk; ++p) {
-            double v = cols[(long)p * N + src];
-            if (twin && p == 2) v *= 2.0;
-            if (twin && p == 4) v = cols[11L * N + src];
-            block[(long)p * n + i] = v;
-        }
-        if (lp) lp[i] = lnprior[src];
-    }
-}
+constexpr int kLmeParts = 2048;            // lme_blocks() never exceeds it
 
-// torch.argmin's order: NaN before everything, then the smallest value; ties -> the lowest index
-__device__ __forceinline__ bool before(double a, long ia, double b, long ib)
+// Ordered compaction, second half.  grid = (groups, branches); workgroup (b, br) owns the draws
+// [b per, (b + 1) per): their offset in the list is the sum of the counts of the workgroups before it
+// (<= 4096 numbers, summed here: no scan kernel, no cross-workgroup hand-off), their order the draw index.
+__global__ __launch_bounds__(256) void compact_kernel(const unsigned char* __restrict__ mask0,
+                                                      const unsigned char* __restrict__ mask1, long N, long per,
+                                                      const int* __restrict__ blk_cnt, int* __restrict__ idx0,
+                                                      int* __restrict__ idx1, long* __restrict__ n_out)
 {
-    const bool na = a != a, nb = b != b;
-    if (na != nb) return na;
-    if (!na && a != b) return a < b;
-    return ia < ib;
-}
-
-// The masked draw with the smallest chi^2, two stages: kArgminBlocks partial (value, position) pairs,
-// then one block over the partials; best[0] = its index into the N draws, draw 0 when no draw
-// passed the mask (the table row the torch path fills in then).
-constexpr int kArgminBlocks = 128;
-
-__device__ __forceinline__ void argmin_block(double v, long at, double* sv, long* si)
-{
-    sv[threadIdx.x] = v;
-    si[threadIdx.x] = at;
+    __shared__ long part[4];
+    __shared__ int wave_off[4];
+    const int br = blockIdx.y, groups = gridDim.x, b = blockIdx.x;
+    const unsigned char* mask = br ? mask1 : mask0;
+    int* idx = br ? idx1 : idx0;
+    const int* cnt = blk_cnt + (long)br * groups;
+    long before = 0;
+    for (int j = threadIdx.x; j < b; j += 256) before += cnt[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = before;
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const long j = si[threadIdx.x + o];
-            if (j >= 0 && (si[threadIdx.x] < 0 || before(sv[threadIdx.x + o], j, sv[threadIdx.x], si[threadIdx.x]))) {
-                sv[threadIdx.x] = sv[threadIdx.x + o];
-                si[threadIdx.x] = j;
-            }
-        }
+    long at = part[0] + part[1] + part[2] + part[3];
+    if (b == groups - 1 && threadIdx.x == 0) n_out[br] = at + cnt[b];
+    const long end = ((long)(b + 1) * per < N) ? (long)(b + 1) * per : N;
+    for (long i0 = (long)b * per; i0 < end; i0 += 256) {
+        const long i = i0 + threadIdx.x;
+        const bool hit = i < end && mask[i] != 0;
+        const unsigned long long m = __ballot(hit);
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        __syncthreads();                   // wave_off of the previous trip has been read
+        if ((threadIdx.x & 63) == 0) wave_off[threadIdx.x >> 6] = __popcll(m);
         __syncthreads();
+        const int w = threadIdx.x >> 6;
+        const int w0 = wave_off[0], w1 = wave_off[1], w2 = wave_off[2], w3 = wave_off[3];
+        const int first = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
+        if (hit) idx[at + first + below] = (int)i;
+        at += w0 + w1 + w2 + w3;
     }
 }
 
-__global__ __launch_bounds__(256) void argmin_partial_kernel(const double* __restrict__ h, const long* __restrict__ count,
-                                                             double* __restrict__ pv, long* __restrict__ pi)
+// One workgroup (one wavefront) per branch: the evidence from the log-mean-exp partials (the fold of
+// lme_final_kernel, trx_kernels.hip: lane l takes partials l, l + 64, ... in order, then a fixed butterfly),
+// the first minimum of chi^2 from the argmin partials, and the record
+//   res[br][0 .. ncol)  the best draw's columns (draw 0 when no draw passed the mask)
+//   res[br][ncol]       lnZ          res[br][ncol + 1]  the masked count
+//   res[2][0]           the limb-darkening flag of the draw kernel (written by branch 0)
+__global__ __launch_bounds__(64) void final_kernel(const double* __restrict__ ws, const double* __restrict__ amin_pv,
+                                                   const long* __restrict__ amin_pi, const long* __restrict__ n_dev,
+                                                   const int* __restrict__ idx0, const int* __restrict__ idx1,
+                                                   const double* __restrict__ cols, long N, int ncol, long n_total,
+                                                   const int* __restrict__ flag, double* __restrict__ res)
 {
-    __shared__ double sv[256];
-    __shared__ long si[256];
-    const long n = *count;
-    double v = INFINITY;
-    long at = -1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const double x = h[i];
-        if (at < 0 || before(x, i, v, at)) { v = x; at = i; }
+    const int br = blockIdx.x, lane = threadIdx.x;
+    const long n = n_dev[br];
+    const int nparts = trx::lme_blocks(n);
+    const double* w = ws + (size_t)br * 3 * kLmeParts;
+    const double* pv = amin_pv + (size_t)br * kLmeParts;
+    const long* pi = amin_pi + (size_t)br * kLmeParts;
+    const int* idx = br ? idx1 : idx0;
+    Lme t{-INFINITY, 0.0, 0};
+    double bv = INFINITY;
+    long bi = -1;
+    if (n > 0) {
+        for (int i = lane; i < nparts; i += 64) {
+            Lme o{w[3 * i], w[3 * i + 1], w[3 * i + 2] != 0.0};
+            trx::lme_merge(t, o);
+            const long oi = pi[i];
+            if (oi >= 0 && (bi < 0 || trx::argmin_before(pv[i], oi, bv, bi))) { bv = pv[i]; bi = oi; }
+        }
     }
-    argmin_block(v, at, sv, si);
-    if (threadIdx.x == 0) { pv[blockIdx.x] = sv[0]; pi[blockIdx.x] = si[0]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Lme other;
+        other.m = __shfl_xor(t.m, o, 64);
+        other.s = __shfl_xor(t.s, o, 64);
+        other.pinf = __shfl_xor(t.pinf, o, 64);
+        trx::lme_merge(t, other);
+        const double ov = __shfl_xor(bv, o, 64);
+        const long oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || trx::argmin_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    double lnz;
+    if (t.pinf) lnz = INFINITY;                                   // _numerics.py:46-47
+    else if (t.m == -INFINITY) lnz = -INFINITY;                   // :49-50
+    else lnz = log(t.s) + t.m - log((double)n_total);             // :51
+    const long best = (bi >= 0) ? (long)idx[bi] : 0;
+    double* r = res + (size_t)br * TRX_SCENARIO_OUT;
+    if (lane < ncol) r[lane] = cols[(long)lane * N + best];
+    if (lane == ncol) r[ncol] = lnz;
+    if (lane == ncol + 1) r[ncol + 1] = (double)n;
+    if (br == 0 && lane == 63) res[2 * TRX_SCENARIO_OUT] = (double)flag[0];
 }
 
-__global__ __launch_bounds__(kArgminBlocks) void argmin_final_kernel(const double* __restrict__ pv, const long* __restrict__ pi,
-                                                                     const long* __restrict__ idx, long* __restrict__ best)
+int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
 {
-    __shared__ double sv[kArgminBlocks];
-    __shared__ long si[kArgminBlocks];
-    argmin_block(pv[threadIdx.x], pi[threadIdx.x], sv, si);
-    if (threadIdx.x == 0) best[0] = (si[0] >= 0) ? idx[si[0]] : 0;
-}
-
-// res = [the best draw's ncol columns, lnZ, masked count]
-__global__ void collect_kernel(const double* __restrict__ cols, long N, int ncol, const long* __restrict__ best,
-                               const double* __restrict__ lnz, const long* __restrict__ count, double* __restrict__ res)
-{
-    const int c = threadIdx.x;
-    if (c < ncol) res[c] = cols[(long)c * N + best[0]];
-    if (c == ncol) res[ncol] = lnz[0];
-    if (c == ncol + 1) res[ncol + 1] = (double)count[0];
-}
-
-}  // namespace
-
-extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
-{
-    if (!s || !s->draw || !s->out || !s->out_flag) return TRX_ERR_ARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     trx_draw_args d = *s->draw;
     const long N = d.N;
     if (N < 1 || N > 0x7fffffffL) return TRX_ERR_ARG;
     const int planet = d.planet != 0;
-    const int ncol = planet ? 11 : 14, nblk = planet ? 10 : 11, nbr = planet ? 1 : 2;
-    const size_t ws_bytes = trx_workspace_bytes();
-    hipcub::CountingInputIterator<long> iota(0);
-    size_t tmp_bytes = 0;
-    TRXS_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, iota, (unsigned char*)nullptr, (long*)nullptr,
-                                           (long*)nullptr, (int)N, st));
+    const int ncol = planet ? 11 : 14, nbr = planet ? 1 : 2;
+    trx::StreamLock turn(st);              // the whole call is enqueued back to back on the stream's scratch
 
-    // buffers sized by N, in the stream's scratch (no allocator traffic once it has grown)
     Arena A;
     const size_t o_cols = A.reserve(sizeof(double) * ncol * N), o_mask = A.reserve(N), o_mask2 = A.reserve(planet ? 0 : N),
                  o_prior = A.reserve(s->want_prior ? sizeof(double) * N : 0), o_flag = A.reserve(sizeof(int)),
-                 o_cnt = A.reserve(4 * sizeof(long)), o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 2)),
-                 o_ws = A.reserve(ws_bytes), o_tmp = A.reserve(tmp_bytes), o_idx0 = A.reserve(sizeof(long) * N),
-                 o_idx1 = A.reserve(planet ? 0 : sizeof(long) * N),
-                 o_pv = A.reserve(sizeof(double) * kArgminBlocks), o_pi = A.reserve(sizeof(long) * kArgminBlocks);
+                 o_n = A.reserve(2 * sizeof(long)), o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1)),
+                 o_ws = A.reserve(sizeof(double) * 2 * 3 * kLmeParts), o_pv = A.reserve(sizeof(double) * 2 * kLmeParts),
+                 o_pi = A.reserve(sizeof(long) * 2 * kLmeParts), o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups),
+                 o_idx0 = A.reserve(sizeof(int) * N), o_idx1 = A.reserve(planet ? 0 : sizeof(int) * N),
+                 o_h0 = A.reserve(sizeof(double) * N), o_h1 = A.reserve(planet ? 0 : sizeof(double) * N);
     TRXS_HIP(trx::stream_scratch(st, 1, A.used, reinterpret_cast<void**>(&A.base)));
     d.cols = A.at<double>(o_cols);
     d.mask = A.at<unsigned char>(o_mask);
@@ -164,63 +170,53 @@ extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
     d.lnprior = s->want_prior ? A.at<double>(o_prior) : nullptr;
     d.flag = A.at<int>(o_flag);
     d.dump = nullptr;
-    long* cnt = A.at<long>(o_cnt);             // [2] masked counts, [2] best indices
-    double* res = A.at<double>(o_res);         // [2][TRX_SCENARIO_OUT] + lnz[2]
-    long* idx[2] = {A.at<long>(o_idx0), planet ? nullptr : A.at<long>(o_idx1)};
+    long* n_dev = A.at<long>(o_n);
+    double* res = A.at<double>(o_res);
+    int* idx[2] = {A.at<int>(o_idx0), planet ? nullptr : A.at<int>(o_idx1)};
+    double* h[2] = {A.at<double>(o_h0), planet ? nullptr : A.at<double>(o_h1)};
     TRXS_HIP(hipMemsetAsync(d.flag, 0, sizeof(int), st));
-    if (int rc = trx_draw_scenario(&d, st)) return rc;
-
-    // ordered compaction of the mask(s): the indices of the masked draws, ascending
-    for (int b = 0; b < nbr; ++b)
-        TRXS_HIP(hipcub::DeviceSelect::Flagged(A.at<char>(o_tmp), tmp_bytes, iota, b ? d.mask_twin : d.mask, idx[b],
-                                               cnt + b, (int)N, st));
-    char* pinned = nullptr;                    // results on their way back: pinned, so the copies are asynchronous
-    TRXS_HIP(trx::stream_scratch(st, 3, 512, reinterpret_cast<void**>(&pinned)));
-    long* n_host = reinterpret_cast<long*>(pinned);
-    double* out_host = reinterpret_cast<double*>(pinned + 64);
-    int* flag_host = reinterpret_cast<int*>(pinned + 64 + sizeof(double) * 2 * TRX_SCENARIO_OUT);
-    TRXS_HIP(hipMemcpyAsync(n_host, cnt, 2 * sizeof(long), hipMemcpyDeviceToHost, st));
-    TRXS_HIP(hipStreamSynchronize(st));
-    const long n_br[2] = {n_host[0], planet ? 0 : n_host[1]};
-
-    // buffers sized by the masked counts
-    Arena B;
-    size_t o_block[2], o_h[2], o_lp[2];
+    long per = 0;
+    int groups = 0;
+    if (int rc = trx::draw_counted(d, A.at<int>(o_cnt), &per, &groups, st)) return rc;
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)groups, (unsigned)nbr), dim3(256), 0, st, d.mask, d.mask_twin, N, per,
+                       A.at<int>(o_cnt), idx[0], idx[1], n_dev);
     for (int b = 0; b < nbr; ++b) {
-        o_block[b] = B.reserve(sizeof(double) * nblk * n_br[b]);
-        o_h[b] = B.reserve(sizeof(double) * (n_br[b] > 0 ? n_br[b] : 1));
-        o_lp[b] = B.reserve(s->want_prior ? sizeof(double) * n_br[b] : 0);
-    }
-    TRXS_HIP(trx::stream_scratch(st, 2, B.used, reinterpret_cast<void**>(&B.base)));
-    for (int b = 0; b < nbr; ++b) {
-        const long n = n_br[b];
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
-        double* block = B.at<double>(o_block[b]);
-        double* h = B.at<double>(o_h[b]);
-        double* lp = s->want_prior ? B.at<double>(o_lp[b]) : nullptr;
-        if (n > 0) {
-            const unsigned grid = (unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
-            hipLaunchKernelGGL(gather_block_kernel, dim3(grid), dim3(256), 0, st, d.cols, N, idx[b], cnt + b,
-                               nblk, b, d.lnprior, block, lp);
-        }
-        double* lnz = res + 2 * TRX_SCENARIO_OUT + b;
-        if (int rc = trx_lnz_scenario(model, s->flags, s->time, s->flux, s->n_time, s->sigma, block, n,
-                                      s->exptime, s->nsupersample, lp, N, s->lnsigma, h, lnz, A.at<char>(o_ws),
-                                      ws_bytes, st))
+        if (int rc = trx::lnl_draws(model, s->flags, s->time, s->flux, s->n_time, s->sigma, d.cols, N, n_dev + b, idx[b], N,
+                                    b, s->exptime, s->nsupersample, h[b], st))
             return rc;
-        hipLaunchKernelGGL(argmin_partial_kernel, dim3(kArgminBlocks), dim3(256), 0, st, h, cnt + b,
-                           A.at<double>(o_pv), A.at<long>(o_pi));
-        hipLaunchKernelGGL(argmin_final_kernel, dim3(1), dim3(kArgminBlocks), 0, st, A.at<double>(o_pv),
-                           A.at<long>(o_pi), idx[b], cnt + 2 + b);
-        hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(64), 0, st, d.cols, N, ncol, cnt + 2 + b, lnz, cnt + b,
-                           res + b * TRX_SCENARIO_OUT);
+        if (int rc = trx::lme_draws(h[b], d.lnprior, s->lnsigma, N, n_dev + b, idx[b],
+                                    A.at<double>(o_ws) + (size_t)b * 3 * kLmeParts, A.at<double>(o_pv) + (size_t)b * kLmeParts,
+                                    A.at<long>(o_pi) + (size_t)b * kLmeParts, st))
+            return rc;
     }
+    hipLaunchKernelGGL(final_kernel, dim3((unsigned)nbr), dim3(64), 0, st, A.at<double>(o_ws), A.at<double>(o_pv),
+                       A.at<long>(o_pi), n_dev, idx[0], idx[1], d.cols, N, ncol, N, d.flag, res);
     TRXS_HIP(hipGetLastError());
-    TRXS_HIP(hipMemcpyAsync(out_host, res, (size_t)nbr * TRX_SCENARIO_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
-    TRXS_HIP(hipMemcpyAsync(flag_host, d.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    TRXS_HIP(hipMemcpyAsync(out_host, res, sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), hipMemcpyDeviceToHost, st));
+    return TRX_OK;
+}
+
+}  // namespace
+
+extern "C" int trx_scenario_enqueue(const trx_scenario_args* s, double* out, void* stream)
+{
+    if (!s || !s->draw || !out) return TRX_ERR_ARG;
+    return enqueue(s, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
+{
+    if (!s || !s->draw || !s->out || !s->out_flag) return TRX_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    trx::StreamLock turn(st);              // the pinned staging record is the stream's, too
+    double* pinned = nullptr;              // pinned, so that the copy is asynchronous
+    TRXS_HIP(trx::stream_scratch(st, 3, sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), reinterpret_cast<void**>(&pinned)));
+    if (int rc = enqueue(s, pinned, st)) return rc;
     TRXS_HIP(hipStreamSynchronize(st));
-    memcpy(s->out, out_host, (size_t)nbr * TRX_SCENARIO_OUT * sizeof(double));
-    *s->out_flag = *flag_host;
+    const int nbr = s->draw->planet ? 1 : 2;
+    memcpy(s->out, pinned, (size_t)nbr * TRX_SCENARIO_OUT * sizeof(double));
+    *s->out_flag = (int)pinned[2 * TRX_SCENARIO_OUT];
     return TRX_OK;
 }
 

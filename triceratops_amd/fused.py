@@ -117,12 +117,73 @@ def _fn_scenario():
         _fn()
         L.trx_scenario_evidence.restype = ctypes.c_int
         L.trx_scenario_evidence.argtypes = [ctypes.POINTER(ScenarioArgs), _vp]
+        L.trx_scenario_enqueue.restype = ctypes.c_int
+        L.trx_scenario_enqueue.argtypes = [ctypes.POINTER(ScenarioArgs), _vp, _vp]
         L.trx_scenario_args_size.restype = ctypes.c_size_t
         if L.trx_scenario_args_size() != ctypes.sizeof(ScenarioArgs):
             raise _lib.TrxError("trx_scenario_args layout mismatch: library %d bytes, binding %d"
                                 % (L.trx_scenario_args_size(), ctypes.sizeof(ScenarioArgs)))
         _bound_scenario = True
-    return L.trx_scenario_evidence
+    return L.trx_scenario_enqueue
+
+
+# ---------------------------------------------------------------------------------------
+# Calls in flight.  trx_scenario_enqueue never waits for the device, so the lnZ_* calls of a
+# calc_probs can all be enqueued (on a few streams, from one host thread) before anything is read
+# back: between begin_deferred() and end_deferred() a native call returns a Pending instead of its
+# result dicts, and sharding.run_units resolves them after one synchronisation per stream.
+RECORD = 2 * SCENARIO_OUT + 1      # doubles per call: two branch records + the limb-darkening flag
+
+
+class Pending:
+    """one trx_scenario_enqueue call whose record has not been read yet"""
+
+    def __init__(self, scen, out, stream, keep, ncol, n_time):
+        self.scen, self.out, self.stream, self.keep, self.ncol, self.n_time = scen, out, stream, keep, ncol, n_time
+
+    def result(self):
+        """the call's result dict(s); the stream must have been synchronised"""
+        rec = self.out.numpy()
+        self.keep = None
+        if rec[2 * SCENARIO_OUT] != 0.0:
+            raise ValueError("can only convert an array of size 1 to a Python scalar")
+        planet, ncol = bool(self.scen.a.planet), self.ncol
+        res = []
+        for b in range(1 if planet else 2):
+            row = rec[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT]
+            n = int(row[ncol + 1])
+            with _stats_lock:
+                _lib.STATS["rows"] += n
+                _lib.STATS["cells"] += n * self.n_time
+                _lib.STATS["launches"] += 1
+            res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
+        return res[0] if planet else (res[0], res[1])
+
+
+_stats_lock = threading.Lock()
+
+
+def begin_deferred(n_calls):
+    """this thread's native lnZ_* calls return Pending objects until end_deferred(); n_calls bounds
+    their number (one pinned block holds all their records)"""
+    _tls.records = torch.empty((max(int(n_calls), 1), RECORD), dtype=F64).pin_memory()
+    _tls.next_record = 0
+
+
+def end_deferred():
+    _tls.records = None
+
+
+def _record_slot():
+    """(pinned record of the next call, deferred?)"""
+    recs = getattr(_tls, "records", None)
+    if recs is not None and _tls.next_record < recs.shape[0]:
+        _tls.next_record += 1
+        return recs[_tls.next_record - 1], True
+    one = getattr(_tls, "one_record", None)
+    if one is None:
+        one = _tls.one_record = torch.empty(RECORD, dtype=F64).pin_memory()
+    return one, False
 
 
 def _fn():
@@ -504,10 +565,9 @@ class _Scenario:
         return res[0] if a.planet else (res[0], res[1])
 
     def _run_native(self, is_host, ncol):
-        """the whole call in the library: draws, masks, compaction, likelihood, evidence, best draw"""
+        """the whole call in the library: draws, masks, compaction, likelihood, evidence, best draw --
+        enqueued without a host synchronisation (trx_scenario_enqueue)"""
         a, dev = self.a, self.dev
-        out = (ctypes.c_double * (2 * SCENARIO_OUT))()
-        flag = ctypes.c_int(0)
         sa = ScenarioArgs()
         sa.draw = ctypes.pointer(a)
         sa.time, sa.flux = self.time.data_ptr(), self.flux.data_ptr()
@@ -516,24 +576,20 @@ class _Scenario:
         sa.flags = ((FLAG_COMPANION_IS_HOST if is_host else 0) | (0 if self.parallel else FLAG_SCALAR_K)
                     | _lib.EXTRA_FLAGS)
         sa.want_prior = int(self.want_prior)
-        sa.out, sa.out_flag = out, ctypes.pointer(flag)
+        out, deferred = _record_slot()
         fn = _fn_scenario()
         with torch.cuda.device(dev):
-            rc = fn(ctypes.byref(sa), torch.cuda.current_stream(dev).cuda_stream)
+            stream = torch.cuda.current_stream(dev)
+            rc = fn(ctypes.byref(sa), out.data_ptr(), stream.cuda_stream)
         if rc:
-            raise _lib.TrxError("trx_scenario_evidence failed with status %d: %s"
+            raise _lib.TrxError("trx_scenario_enqueue failed with status %d: %s"
                                 % (rc, _lib.lib().trx_last_error().decode()))
-        if flag.value != 0:
-            raise ValueError("can only convert an array of size 1 to a Python scalar")
-        res = []
-        for b in range(1 if a.planet else 2):
-            row = np.array(out[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT])
-            n = int(row[ncol + 1])
-            _lib.STATS["rows"] += n
-            _lib.STATS["cells"] += n * sa.n_time
-            _lib.STATS["launches"] += 1
-            res.append(self._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
-        return res[0] if a.planet else (res[0], res[1])
+        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time)
+        self.keep = []
+        if deferred:
+            return pend
+        stream.synchronize()
+        return pend.result()
 
     def _best(self, h, idx, n):
         """indices of the N_BEST best draws (see device_pipeline._evidence for the tie rules)"""

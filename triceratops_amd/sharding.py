@@ -27,6 +27,11 @@ per_unit_seed = False
 # fill the GPU while the first waits for Python.  Implies per-unit seeding (the numbers a unit draws
 # depend on its seed only, so the result does not depend on the number of threads).
 threads = 1
+# HIP streams ONE host thread deals the lnZ_* calls of a calc_probs to (set_sampling("device")): a call
+# is enqueued without any host synchronisation (trx_scenario_enqueue), so the thread enqueues every
+# unit, the streams overlap the small kernels of one call with the large ones of another, and the
+# results are read after one wait.  The library keeps ~0.3 GB of scratch per stream at N = 1e6.
+streams = 3
 
 # relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
 # secondary-eclipse scan; companion/background hosts add per-draw stellar relations
@@ -95,12 +100,12 @@ def run_units(units, verbose=0):
         own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
                         for k in live], world)
         owner = {k: own[i] for i, k in enumerate(live)}
-    elif per_unit_seed or threads > 1:
-        base = int(np.random.randint(0, 2 ** 31 - 1))
-
     # calc_probs keeps the best draw of every scenario only: with the device generator the fused
     # path then selects it with one argmin instead of a top-100 sort (fused.TABLE_ROWS)
     from . import fused as _fused
+    if not dist and (per_unit_seed or (threads > 1 and _fused.threadable())):
+        # (threads only apply to the device generator: the numpy modes keep consuming the caller's stream)
+        base = int(np.random.randint(0, 2 ** 31 - 1))
     _fused.TABLE_ROWS = 1
     try:
         return _run_units(units, live, owner, base, dist, world, rank, verbose)
@@ -131,6 +136,8 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
     from . import fused as _fused
     mine_k = [k for k in live if owner[k] == rank]
 
+    pending = []                                  # (unit, fused.Pending): calls in flight
+
     def one(k):
         j0, names, snum, ID, fn, key = units[k][:6]
         if verbose == 1:
@@ -140,19 +147,44 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         if base is not None:
             unit_seed = (base + 7919 * (k + 1)) % (2 ** 32)
             _fused.set_thread_seed(unit_seed)        # the draw kernel's Philox key (thread-local)
-            if n_threads == 1:
+            if n_threads == 1 and not _fused.threadable():
                 np.random.seed(unit_seed)            # the numpy sampling modes
                 import torch
                 torch.manual_seed(unit_seed)         # staged draws from torch's generator
         try:
-            table[offs[k]:offs[k] + rows[k]] = _record(fn())
+            res = fn()
         finally:
             _fused.set_thread_seed(None)
+        if isinstance(res, _fused.Pending):
+            pending.append((k, res))                 # list.append is atomic: worker threads share it
+        else:
+            table[offs[k]:offs[k] + rows[k]] = _record(res)
 
-    n_threads = min(threads, len(mine_k)) if (base is not None and _fused.threadable()) else 1
-    if n_threads <= 1:
+    def resolve():
+        for k, p in pending:
+            table[offs[k]:offs[k] + rows[k]] = _record(p.result())
+
+    on_device = _fused.threadable()
+    n_threads = min(threads, len(mine_k)) if (base is not None and on_device) else 1
+    if n_threads <= 1 and not (on_device and mine_k):
         for k in mine_k:
             one(k)
+    elif n_threads <= 1:
+        # one host thread, a few streams: every call is enqueued, then one wait per stream
+        import torch
+        device = torch.cuda.current_device()
+        pool = _worker_streams(device, max(1, min(streams, len(mine_k))))
+        torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
+        _fused.begin_deferred(len(mine_k))
+        try:
+            for j, k in enumerate(mine_k):
+                with torch.cuda.stream(pool[j % len(pool)]):
+                    one(k)
+            for st in pool:
+                st.synchronize()
+            resolve()
+        finally:
+            _fused.end_deferred()
     else:
         import queue
         import threading
@@ -164,11 +196,12 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             todo.put(k)
         errors = []
 
-        streams = _worker_streams(device, n_threads)
+        pool_streams = _worker_streams(device, n_threads)
 
         def worker(stream):
             try:
                 torch.cuda.set_device(device)        # the current device is thread-local
+                _fused.begin_deferred(len(mine_k))
                 with torch.cuda.stream(stream):
                     while True:
                         try:
@@ -179,15 +212,18 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                 stream.synchronize()
             except BaseException as exc:              # re-raised in the caller's thread
                 errors.append(exc)
+            finally:
+                _fused.end_deferred()
 
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
-        pool = [threading.Thread(target=worker, args=(streams[i],)) for i in range(n_threads)]
+        pool = [threading.Thread(target=worker, args=(pool_streams[i],)) for i in range(n_threads)]
         for t in pool:
             t.start()
         for t in pool:
             t.join()
         if errors:
             raise errors[0]
+        resolve()
 
     if dist:
         import torch
