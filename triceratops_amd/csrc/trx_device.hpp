@@ -464,7 +464,9 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
     double rho = rcp_nr1(fma(-e, cE, 1.0));
     double d = dM * rho;
     if (!(fabs(d) < 0.08)) return false;
-    d = fma(-0.5 * e * sE * rho * d, d, d);     // second-order start: one Newton step then suffices
+    // second-order start: one Newton step then suffices (a third-order start, tried in round 3, changes
+    // nothing: the lanes of a trip nearly always settle in one step already)
+    d = fma(-0.5 * e * sE * rho * d, d, d);
     double ds = 0.0, dc = 0.0, step = 0.0;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
@@ -490,6 +492,40 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
     return true;
 }
 
+// The same step for |d| up to 0.3 rad (two more Taylor terms each): from the row's solution at
+// inferior conjunction to an exposure centre inside the transit window -- a tenth of an orbit at most
+// for the reference's periods -- instead of a full solve per cell (plan_cell), and to the points of the
+// secondary-eclipse scan (rowc_kernel).
+__device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE, double& cE)
+{
+    double rho = rcp_nr1(fma(-e, cE, 1.0));
+    double d = dM * rho;
+    if (!(fabs(d) < 0.3)) return false;
+    d = fma(-0.5 * e * sE * rho * d, d, d);
+    double ds = 0.0, dc = 0.0, step = 0.0;
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+        const double d2 = d * d;
+        const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 6227020800.0,
+                              -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 87178291200.0,
+                              1.0 / 479001600.0), -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5);
+        ds = fma(sE, c1, cE * sd);
+        dc = fma(cE, c1, -sE * sd);
+        const double g = fma(-e, ds, d) - dM;
+        const double gp = fma(-e, cE + dc, 1.0);
+        rho = rho * fma(-gp, rho, 2.0);
+        step = g * rho;
+        d -= step;
+        if (__all(fabs(step) < 1e-9)) break;
+    }
+    if (!(fabs(step) < 1e-7)) return false;       // (a lane that did not settle: full solve)
+    const double s1 = sE + ds, c1 = cE + dc;
+    sE = fma(-step, c1, s1);
+    cE = fma(step, s1, c1);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // Per-row constants staged in LDS (one row = one Monte-Carlo draw).
 struct RowC {
@@ -498,6 +534,7 @@ struct RowC {
     double wlo, whi;          // mean-anomaly window (relative to conjunction), margins included
     double cle, cld, ced;     // limb-darkening weights
     double xeb, fdil;         // dilution: m = (m + xeb)/(1 + xeb) [EB]; m = (m + fdil)/(1 + fdil)
+    double sEt, cEt;          // sin, cos of the eccentric anomaly at inferior conjunction (where M = Mtr)
     double excl;              // 1.0 when the EB secondary rule excludes the draw (+inf), else 0
 };
 constexpr int kRowDoubles = sizeof(RowC) / sizeof(double);
@@ -521,6 +558,8 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
     c.nmot = kTwoPi / per;
     c.e = e;
     c.Mtr = Etr - e * sEt;
+    c.sEt = sEt;
+    c.cEt = cEt;
     c.ax = a * cw;
     c.bx = -a * rt * sw;
     c.ay = a * sw;
@@ -635,7 +674,20 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     // orbit at the exposure centre: position, velocity and the quadratic model of z^2(t)
     const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
     p.Mprev = phase + c.Mtr;
+#ifndef TRX_PLAN_FULL_SOLVE
+    // the in-window cells sit within a fraction of a radian of inferior conjunction: Newton steps from
+    // the row's solution there (RowC::sEt, cEt) instead of a full solve; wave-uniform fallback
+    p.sE = c.sEt;
+    p.cE = c.cEt;
+    const bool stepped = kepler_step_wide(reduce_2pi(phase), c.e, p.sE, p.cE);
+    if (!__all(stepped)) {
+        double sF, cF;
+        kepler_full(p.Mprev, c.e, sF, cF);
+        if (!stepped) { p.sE = sF; p.cE = cF; }
+    }
+#else
     kepler_full(p.Mprev, c.e, p.sE, p.cE);
+#endif
     p.anchored = true;
     const double rho = rcp_fast(fma(-c.e, p.cE, 1.0));
     const double ce = p.cE - c.e;
@@ -679,7 +731,11 @@ __device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, 
 {
     const double M = c.nmot * ((t + exptime * frac) - c.t0) + c.Mtr;
     bool have = false;
-    if (stepping && p.anchored) have = kepler_step(M - p.Mprev, c.e, p.sE, p.cE);
+    if (stepping && p.anchored) {
+        double sT = p.sE, cT = p.cE;
+        have = kepler_step_wide(reduce_2pi(M - p.Mprev), c.e, sT, cT);
+        if (have) { p.sE = sT; p.cE = cT; }
+    }
     if (!have) kepler_full(M, c.e, p.sE, p.cE);
     p.anchored = true;
     p.Mprev = M;
@@ -707,6 +763,11 @@ __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, do
     if (p.n == 0) return 1.0;
     const double opp = 1.0 + c.k, opp2 = opp * opp;
     double acc = 0.0;
+#ifndef TRX_PLAN_FULL_SOLVE
+    // start from the row's solution at conjunction (node_z2 steps from it when the point is near enough)
+    p.sE = c.sEt; p.cE = c.cEt; p.Mprev = c.Mtr; p.anchored = true;
+    stepping = true;
+#endif
 #pragma unroll 1
     for (int s = 1; s <= S; ++s) {
         double Y;

@@ -573,6 +573,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             cu.Mtr = uniform(r0.Mtr); cu.ax = uniform(r0.ax); cu.ay = uniform(r0.ay); cu.bx = uniform(r0.bx);
             cu.by = uniform(r0.by); cu.cosi = uniform(r0.cosi); cu.cle = uniform(r0.cle); cu.cld = uniform(r0.cld);
             cu.ced = uniform(r0.ced);
+            cu.sEt = uniform(r0.sEt); cu.cEt = uniform(r0.cEt);
         }
         double lacc = 0.0;                 // LONG: this lane's share of the row's chi^2
         bool nonflat = false;              // LONG: a cell of this lane has a model value other than 1

@@ -16,6 +16,8 @@ Random numbers: the lnZ_* functions draw from the global numpy stream like the r
               0's stream broadcast to all ranks, so the result does not depend on the partition
               or on the world size (per_unit_seed=True gives the same numbers on one GPU).
 """
+import os
+
 import numpy as np
 
 RECORD_COLS = ("M_s", "R_s", "u1", "u2", "P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB",
@@ -31,7 +33,9 @@ threads = 1
 # is enqueued without any host synchronisation (trx_scenario_enqueue), so the thread enqueues every
 # unit, the streams overlap the small kernels of one call with the large ones of another, and the
 # results are read after one wait.  The library keeps ~0.3 GB of scratch per stream at N = 1e6.
-streams = 3
+streams = int(os.environ.get("TRX_STREAMS", "3"))
+# host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
+timing = {"enqueue_s": 0.0, "wait_s": 0.0}
 
 # relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
 # secondary-eclipse scan; companion/background hosts add per-draw stellar relations
@@ -177,11 +181,15 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
         _fused.begin_deferred(len(mine_k))
         try:
+            import time
+            t0 = time.perf_counter()
             for j, k in enumerate(mine_k):
                 with torch.cuda.stream(pool[j % len(pool)]):
                     one(k)
+            timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
                 st.synchronize()
+            timing["wait_s"] = time.perf_counter() - t0 - timing["enqueue_s"]
             resolve()
         finally:
             _fused.end_deferred()
