@@ -146,37 +146,49 @@ def test_threaded_units_give_the_same_results_as_one_thread():
 
 
 def test_native_scenario_call_equals_the_torch_operator_path():
-    """trx_scenario_evidence (draws -> compaction -> likelihood -> evidence -> best draw in one library
-    call) against the chain of torch operators around trx_draw_scenario / trx_lnz_scenario on the same
-    Philox keys: every lnZ, every best-fit column and FPP / NFPP bit for bit, on all 18 scenarios of
-    several TOIs, with a contrast curve, in fp64 and in the mixed-precision mode"""
+    """trx_scenario_enqueue (draws -> compaction -> likelihood -> evidence -> best draw in one library
+    call, no host sync) against the chain of torch operators around trx_draw_scenario / trx_lnz_scenario on
+    the same Philox keys, on all 18 scenarios of several TOIs, with a contrast curve, in fp64 and in the
+    mixed-precision mode.  With every row evaluated to the end (trx_set_bounded_evaluation(0)): every lnZ,
+    every best-fit column and FPP / NFPP bit for bit.  With the bounded evaluation (the default): the same
+    best draws, lnZ to 1e-12 (the probe cells of a row are summed first: another order of the same terms)."""
     import triceratops_amd
     from triceratops_amd import fused, sharding
     triceratops_amd.set_sampling("device")
     sharding.per_unit_seed = True
-    cols = ("M_s", "R_s", "P_orb", "inc", "b", "R_p", "ecc", "w", "M_EB", "R_EB", "prob")
-    attrs = ("lnZ", "u1", "u2", "fluxratio_EB", "fluxratio_comp", "star_num")
+    cols = ("M_s", "R_s", "P_orb", "inc", "b", "R_p", "ecc", "w", "M_EB", "R_EB")
+    attrs = ("u1", "u2", "fluxratio_EB", "fluxratio_comp", "star_num")
+    L = _lib.lib()
     try:
         for precision in ("fp64", "fp32"):
             triceratops_amd.set_precision(precision)
             got = {}
-            for native in (True, False):
-                fused.NATIVE = native
+            for mode in ("native", "native-unbounded", "torch"):
+                fused.NATIVE = mode != "torch"
+                L.trx_set_bounded_evaluation(0 if mode == "native-unbounded" else 1)
                 np.random.seed(5)
                 torch.manual_seed(5)
                 _lib.reset_stats()
                 out = triceratops_amd.calc_probs_many(_jobs(4, 200_000))
-                got[native] = (out, dict(_lib.STATS))
-            for x, y in zip(got[True][0], got[False][0]):
+                got[mode] = (out, dict(_lib.STATS))
+            for x, y, z in zip(got["native-unbounded"][0], got["torch"][0], got["native"][0]):
                 assert x.FPP == y.FPP and x.NFPP == y.NFPP
+                assert np.array_equal(x.lnZ, y.lnZ, equal_nan=True) and np.array_equal(x.probs["prob"].values, y.probs["prob"].values)
+                fin = np.isfinite(y.lnZ)
+                assert np.array_equal(fin, np.isfinite(z.lnZ))
+                assert np.allclose(z.lnZ[fin], y.lnZ[fin], rtol=1e-12, atol=0)
+                assert abs(z.FPP - y.FPP) < 1e-12 and abs(z.NFPP - y.NFPP) < 1e-12
                 for c in cols:
                     assert np.array_equal(x.probs[c].values, y.probs[c].values, equal_nan=True), (precision, c)
+                    assert np.array_equal(z.probs[c].values, y.probs[c].values, equal_nan=True), (precision, c)
                 for c in attrs:
                     assert np.array_equal(np.asarray(getattr(x, c)), np.asarray(getattr(y, c)), equal_nan=True), (precision, c)
-            assert got[True][1]["rows"] == got[False][1]["rows"] > 0
-            assert got[True][1]["cells"] == got[False][1]["cells"]
+                    assert np.array_equal(np.asarray(getattr(z, c)), np.asarray(getattr(y, c)), equal_nan=True), (precision, c)
+            assert got["native"][1]["rows"] == got["torch"][1]["rows"] > 0
+            assert got["native"][1]["cells"] == got["torch"][1]["cells"]
     finally:
         fused.NATIVE = True
+        L.trx_set_bounded_evaluation(1)
         sharding.per_unit_seed = False
         triceratops_amd.set_precision("fp64")
         triceratops_amd.set_sampling("numpy")

@@ -1,0 +1,92 @@
+"""Bounded evaluation (cells_kernel<PRUNE>, include/trx.h: trx_set_bounded_evaluation).
+
+trx_scenario_evidence keeps two things of the rows it evaluates: lnZ, the log-mean-exp of
+c0 - chi^2/2 + lnprior (marginal_likelihoods.py:117-154), and the row with the smallest chi^2.  A row whose
+chi^2 over the cells done so far shows that it can be neither is abandoned and reports that lower bound.
+trx_set_debug_bounded_lnl(1) applies the same rule to trx_lnl_batch (as for an evidence without prior), which
+makes the rule checkable row by row against the full evaluation."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from triceratops_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _light_curve(n_time, rng, irregular=False):
+    t = synth.time_grid(n_time)
+    if irregular:
+        t = np.sort(t + rng.uniform(-0.4, 0.4, n_time) * (t[1] - t[0]))
+    t_d = _lib.dev(t)
+    curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)
+    return t_d, _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy()))
+
+
+@pytest.mark.parametrize("n_time,irregular", [(100, False), (200, True), (500, True), (1500, False)])
+def test_every_row_is_exact_or_a_valid_bound(n_time, irregular):
+    """per row: the full chi^2/2, or a lower bound of it that lies above min + 90 (so that it carries no
+    weight after the reduction's cut at 80 and cannot be the best draw); the minimum itself is always exact"""
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    t_d, f_d = _light_curve(n_time, rng, irregular)
+    n = 30000 if n_time <= 500 else 6000
+    cnt = ctypes.c_ulonglong(0)
+    total = 0
+    try:
+        for fam in synth.FAMILIES:
+            rows = synth.family_rows(rng, fam, n)
+            rows[:, :3] = rows[:, 3:6]                  # ties
+            rows[7 if fam[1] == _lib.MODEL_TP else 8, 5] = np.nan      # a draw with NaN eccentricity
+            rows_d = _lib.dev(rows)
+            flags = _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0
+            L.trx_set_debug_bounded_lnl(0)
+            full = _lib.lnl_batch(fam[1], flags, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_set_debug_bounded_lnl(1)
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            got = _lib.lnl_batch(fam[1], flags, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            total += cnt.value
+            assert np.array_equal(np.isnan(full), np.isnan(got))
+            assert np.array_equal(full == np.inf, got == np.inf)
+            fin = np.isfinite(full)
+            hmin = full[fin].min()
+            exact = np.zeros(n, dtype=bool)
+            exact[fin] = np.abs(got[fin] - full[fin]) <= 1e-11 * np.abs(full[fin])
+            bound = fin & ~exact
+            assert int(bound.sum()) == cnt.value, fam[0]
+            assert np.all(got[bound] <= full[bound] * (1 + 1e-9))
+            assert np.all(got[bound] > hmin + 90.0 - 1e-6)
+            assert np.all(exact[fin & (full <= hmin + 90.0)])
+            assert np.argmin(np.where(fin, got, np.inf)) == np.argmin(np.where(fin, full, np.inf))
+    finally:
+        L.trx_set_debug_bounded_lnl(0)
+    assert total > 0.2 * n * len(synth.FAMILIES)        # the rule does bite on these families
+
+
+def test_evidence_and_best_draw_do_not_depend_on_which_rows_stop():
+    """lnZ and the best draw of trx_lnz_scenario with the bounded rows: equal to the full evaluation's to
+    1e-13 (the probe cells of a row are summed first), and bit for bit the same from run to run although the
+    set of abandoned rows changes with the timing of the waves"""
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    t_d, f_d = _light_curve(150, rng, True)
+    n = 60000
+    try:
+        for fam in synth.FAMILIES[:8]:
+            rows_d = _lib.dev(synth.family_rows(rng, fam, n))
+            lp = _lib.dev(np.where(rng.random(n) < 0.1, -np.inf, -rng.exponential(3.0, n)))
+            flags = _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0
+            out = {}
+            for mode in (0, 1, 1, 1):
+                L.trx_set_debug_bounded_lnl(mode)
+                h, lnz = _lib.lnz_scenario(fam[1], flags, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, lp, n,
+                                           float(np.log(synth.SIGMA)))
+                out.setdefault(mode, []).append((float(lnz.cpu()[0]), int(torch.argmin(h).cpu())))
+            (z0, b0), = out[0]
+            assert all(b == b0 for _, b in out[1])
+            assert all(abs(z - z0) <= 1e-13 * abs(z0) for z, _ in out[1])
+    finally:
+        L.trx_set_debug_bounded_lnl(0)

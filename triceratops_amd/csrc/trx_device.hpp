@@ -459,6 +459,10 @@ __device__ __forceinline__ void kepler_full(double M, double e, double& sE, doub
 // Advance (sinE, cosE) of E - e sinE = M to M + dM for small dM: Newton on
 // g(d) = d - e (sinE (cos d - 1) + cosE sin d) - dM with Taylor kernels and a running
 // reciprocal of g' (no division).  Returns false when |d| is too large for the series.
+// FREEZE: a lane that has settled keeps its numbers while the others go on, so that what a lane returns does
+// not depend on which other lanes share its wave (the bounded evaluation changes that from run to run, and
+// its results must not); without it every lane takes the steps the slowest one needs (2 % faster).
+template <bool FREEZE = false>
 __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, double& cE)
 {
     double rho = rcp_nr1(fma(-e, cE, 1.0));
@@ -467,23 +471,30 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
     // second-order start: one Newton step then suffices (a third-order start, tried in round 3, changes
     // nothing: the lanes of a trip nearly always settle in one step already)
     d = fma(-0.5 * e * sE * rho * d, d, d);
+    // (a lane that has settled keeps its numbers while the others go on: what a lane returns must not
+    // depend on which other lanes share its wave -- the bounded evaluation changes that from run to run)
     double ds = 0.0, dc = 0.0, step = 0.0;
+    bool settled = false;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
-        const double d2 = d * d;
-        const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 362880.0, -1.0 / 5040.0),
-                                                    1.0 / 120.0), -1.0 / 6.0), 1.0);
-        const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 3628800.0, 1.0 / 40320.0),
-                                                     -1.0 / 720.0), 1.0 / 24.0), -0.5);
-        ds = fma(sE, c1, cE * sd);   // sin(E+d) - sin E
-        dc = fma(cE, c1, -sE * sd);  // cos(E+d) - cos E
-        const double g = fma(-e, ds, d) - dM;
-        const double gp = fma(-e, cE + dc, 1.0);
-        rho = rho * fma(-gp, rho, 2.0);          // one Newton step on 1/gp
-        step = g * rho;
-        d -= step;
-        // a step below 1e-9 leaves an error ~ step^2: done after applying it
-        if (__all(fabs(step) < 1e-9)) break;
+        if (!FREEZE || !settled) {                       // (an exec-masked block: settled lanes keep their numbers)
+            const double d2 = d * d;
+            const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 362880.0, -1.0 / 5040.0),
+                                                        1.0 / 120.0), -1.0 / 6.0), 1.0);
+            const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 3628800.0, 1.0 / 40320.0),
+                                                         -1.0 / 720.0), 1.0 / 24.0), -0.5);
+            ds = fma(sE, c1, cE * sd);   // sin(E+d) - sin E
+            dc = fma(cE, c1, -sE * sd);  // cos(E+d) - cos E
+            const double g = fma(-e, ds, d) - dM;
+            const double gp = fma(-e, cE + dc, 1.0);
+            rho = rho * fma(-gp, rho, 2.0);              // Newton on 1/gp -- twice when a lane stops at its own
+            if (FREEZE) rho = rho * fma(-gp, rho, 2.0);  // first small step, which must then be a good one
+            step = g * rho;
+            d -= step;
+            // a step below 1e-9 leaves an error ~ step^2: done after applying it
+            settled = fabs(step) < 1e-9;
+        }
+        if (__all(settled)) break;
     }
     // (ds, dc) were evaluated one step back: first-order correction
     const double s1 = sE + ds, c1 = cE + dc;
@@ -496,6 +507,7 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
 // inferior conjunction to an exposure centre inside the transit window -- a tenth of an orbit at most
 // for the reference's periods -- instead of a full solve per cell (plan_cell), and to the points of the
 // secondary-eclipse scan (rowc_kernel).
+template <bool FREEZE = false>
 __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE, double& cE)
 {
     double rho = rcp_nr1(fma(-e, cE, 1.0));
@@ -503,21 +515,26 @@ __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE
     if (!(fabs(d) < 0.3)) return false;
     d = fma(-0.5 * e * sE * rho * d, d, d);
     double ds = 0.0, dc = 0.0, step = 0.0;
+    bool settled = false;
 #pragma unroll 1
     for (int it = 0; it < 10; ++it) {
-        const double d2 = d * d;
-        const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 6227020800.0,
-                              -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
-        const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 87178291200.0,
-                              1.0 / 479001600.0), -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5);
-        ds = fma(sE, c1, cE * sd);
-        dc = fma(cE, c1, -sE * sd);
-        const double g = fma(-e, ds, d) - dM;
-        const double gp = fma(-e, cE + dc, 1.0);
-        rho = rho * fma(-gp, rho, 2.0);
-        step = g * rho;
-        d -= step;
-        if (__all(fabs(step) < 1e-9)) break;
+        if (!FREEZE || !settled) {
+            const double d2 = d * d;
+            const double sd = d * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, 1.0 / 6227020800.0,
+                                  -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+            const double c1 = d2 * fma(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, fma_k(d2, -1.0 / 87178291200.0,
+                                  1.0 / 479001600.0), -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5);
+            ds = fma(sE, c1, cE * sd);
+            dc = fma(cE, c1, -sE * sd);
+            const double g = fma(-e, ds, d) - dM;
+            const double gp = fma(-e, cE + dc, 1.0);
+            rho = rho * fma(-gp, rho, 2.0);
+            if (FREEZE) rho = rho * fma(-gp, rho, 2.0);
+            step = g * rho;
+            d -= step;
+            settled = fabs(step) < 1e-9;
+        }
+        if (__all(settled)) break;
     }
     if (!(fabs(step) < 1e-7)) return false;       // (a lane that did not settle: full solve)
     const double s1 = sE + ds, c1 = cE + dc;
@@ -657,7 +674,7 @@ struct CellPlan {
     bool st_ok = false;                          // no limb contact within the stencil radius (cells_kernel)
 };
 
-template <bool CHECK_WINDOW = true>
+template <bool CHECK_WINDOW = true, bool FREEZE = false>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
                                               const TierTable& tt, bool use_tiers, double st_radius = 0.0)
 {
@@ -679,7 +696,7 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     // the row's solution there (RowC::sEt, cEt) instead of a full solve; wave-uniform fallback
     p.sE = c.sEt;
     p.cE = c.cEt;
-    const bool stepped = kepler_step_wide(reduce_2pi(phase), c.e, p.sE, p.cE);
+    const bool stepped = kepler_step_wide<FREEZE>(reduce_2pi(phase), c.e, p.sE, p.cE);
     if (!__all(stepped)) {
         double sF, cF;
         kepler_full(p.Mprev, c.e, sF, cF);

@@ -34,15 +34,22 @@ private:
 // The likelihood of the draws that passed a geometry mask, read in place from the draw kernel's
 // [n_param][src_stride] block: row r = draw src_idx[r], r < *n_dev (both left on the device by earlier
 // kernels of the stream; n_upper bounds the count).  twin: the EB_TWIN rows (2 P, a of 2 P).
+// The caller reduces the rows to lnZ (with lnprior per draw, or null) and the best draw only, which
+// allows the bounded evaluation of cells_kernel<PRUNE>: a row that can neither carry weight nor be the
+// best draw reports a lower bound of its chi^2/2 instead of the value.  *bounds_base then points at the row
+// blocks of the launch, behind which its header keeps the largest log-weight (lme_draws reads it; the
+// pointer stays valid for work enqueued on this stream); null when every row was evaluated to the end.
 int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
               const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
-              int twin, double exptime, int nsupersample, double* out_halfchi2, hipStream_t st);
+              int twin, double exptime, int nsupersample, double* out_halfchi2, const double* lnprior,
+              double lnsigma, const double** bounds_base, hipStream_t st);
 
 // First pass of the evidence and of the best-draw search over those chi^2/2 values: per-block
 // (max, sum exp, saw +inf) partials in ws[3 * 2048] and (value, position) argmin partials in
 // amin_pv / amin_pi [2048]; lme_blocks(*n_dev) of them are valid.
 int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
-              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, hipStream_t st);
+              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base,
+              hipStream_t st);
 
 // trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
 // [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)

@@ -92,6 +92,12 @@ struct RowsArgs {
     long src_stride;
     int twin_cols;     // EB_TWIN rows of the draw kernel's block: P = 2 * column 2, a = column 11
     int forced_B;      // trx_set_rows_per_wave
+    // Bounded evaluation (trx_scenario_evidence only; cells_kernel<..., PRUNE>): see cells_body
+    int prune;         // 1: rows that provably carry no weight in the evidence and cannot be its best draw are abandoned
+    int pstride;       // every pstride-th time stamp of a row is a probe cell (evaluated first)
+    double prune_c0;   // -ln(2 pi)/2 - ln sigma: log-weight of a row = prune_c0 - chi^2/2 + lnprior
+    const double* prune_lp;   // lnprior per DRAW (indexed through src_idx), or null
+    int part;          // PRUNE: 1 = the pilot rows [0, min(n, kPilotRows)), 2 = the rows behind them, 0 = all rows
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -129,6 +135,8 @@ __device__ unsigned long long g_phase_cycles[8];
 // rows whose light curve was not evaluated because lnL_EB_p's secondary-eclipse rule excludes them
 // anyway (statistics for benchmarks: trx_skipped_rows)
 __device__ unsigned long long g_skipped_rows;
+// rows abandoned by the bounded evaluation (cells_kernel<PRUNE>): statistics, trx_pruned_rows
+__device__ unsigned long long g_pruned_rows;
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
 __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
@@ -220,7 +228,12 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
 // the disc).  Anything else -- non-uniform stamps, coarse grids, cells near a contact, the first
 // and last kStM cells of a chunk -- takes the Gauss nodes as before.
 constexpr int kStM = 6;
-constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrDoubles = 16;
+constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXmax = 16, kHdrProbe = 17, kHdrDoubles = 18;
+// Bounded evaluation, two launches (see cells_body, PRUNE): the first kPilotRows rows are evaluated to the end
+// -- they give the launch's running bounds their first values, so that the bound bites from the first wave
+// of the main launch on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
+// (header slot kHdrProbe) when few pilot rows lie far above the pilot's best.
+constexpr long kPilotRows = 4096;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
 // Row constants of 64 rows per workgroup, every lane of the first wave on a row of its own, written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
@@ -249,7 +262,15 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             acc += (d * d) / a.s2;
         }
         acc = wave_sum(acc);
-        if ((lane & 63) == 0) a.rowc[n * kRowDoubles + kHdrFlat] = acc;
+        if ((lane & 63) == 0) {
+            double* hdr = a.rowc + n * kRowDoubles;
+            hdr[kHdrFlat] = acc;
+            // running bounds of the launch (cells_kernel<PRUNE>): the smallest chi^2/2 and the largest
+            // log-weight among the rows finished so far
+            hdr[kHdrHmin] = INFINITY;
+            hdr[kHdrXmax] = -INFINITY;
+            hdr[kHdrProbe] = 1.0;
+        }
     }
     if (blk == 0 && (lane >> 6) == 2) {
         // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
@@ -468,15 +489,39 @@ __device__ __forceinline__ int lane_prefix(int cnt, int& total)
 //               are mostly neighbours), chi^2 summed directly per lane and reduced once per row.
 // ST: the launch uses the centre-value stencil (decided on the device by rowc_kernel: the kernel
 // below picks the instantiation, so a launch without it runs exactly the code it ran before)
-template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
+// running bounds of a launch (see PRUNE below): smallest finished chi^2/2, largest finished log-weight
+__device__ __forceinline__ void tighten_bounds(double* hdr, double h, double x)
+{
+    if (h < __hip_atomic_load(&hdr[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_min(&hdr[kHdrHmin], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x > __hip_atomic_load(&hdr[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_max(&hdr[kHdrXmax], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// PRUNE (trx_scenario_evidence; MODE_LNL, no stencil): bounded evaluation.  The evidence is a sum of
+// exp(c0 - chi^2/2 + lnprior) over the rows and the reduction drops every term more than 80 below the
+// largest (lme_partial_kernel: it cannot change an fp64 sum that is >= 1); the best draw is the row with
+// the smallest chi^2.  chi^2 only grows as cells are added, so a row whose chi^2/2 over the cells done so
+// far already (i) exceeds the smallest FINISHED chi^2/2 of the launch and (ii) puts its log-weight 90
+// below the largest finished log-weight can neither be the best draw nor carry weight: it is abandoned
+// and reports the bound it reached (any value >= it gives the same lnZ bits and the same best draw).
+// The two running bounds live behind the launch header (global atomics, min / max: they only tighten, a
+// stale read is merely looser).  To let the bound bite early a row's cells are taken in two phases:
+// every pstride-th time stamp (the probe cells, ~16 per row) plus -- for free -- all its out-of-window
+// cells, then the verdict, then the rest.  On a real detection most prior draws miss the observed depth
+// or duration by far: 95 % of the rows of TOI-465.01's lnZ_TTP stop at the probe
+// (profiles/prune_potential.py).  Which rows stop depends on timing, the results do not.
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE>
 __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_radius)
 {
+    static_assert(!PRUNE || (MODE == MODE_LNL && !ST), "bounded evaluation: likelihood mode, no stencil");
     extern __shared__ double lds[];
     const int Bl = LONG ? 1 : a.B;                                    // rows the LDS layout holds
     RowC* rows = reinterpret_cast<RowC*>(lds);
     double* hacc = lds + (size_t)Bl * kRowDoubles;                    // [Bl] chi^2 corrections per row
     double* hmout = hacc + Bl;                                        // [Bl] diluted model of an unocculted cell: 1, or NaN
-    double* tier_xw = hmout + Bl;
+    double* hrem = hmout + Bl;                                        // [Bl] PRUNE: (f - 1)^2 / s2 over the row's in-window cells not done yet
+    double* tier_xw = hrem + Bl;
     unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
     constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
@@ -527,12 +572,21 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
     if (ST && lane <= 2 * kStM) ss.stw[lane] = hdr[kHdrStW + lane];
 
+    // the rows of this launch: all of them, or (PRUNE) the pilot rows / the rows behind the pilot
+    long row0 = 0, row1 = n;
+    if (PRUNE && a.part) {
+        const long np = n < kPilotRows ? n : kPilotRows;
+        if (a.part == 1) row1 = np; else row0 = np;
+        nbatch = (row1 - row0 + B - 1) / B;
+    }
+    // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes)
+    const bool probing = PRUNE && a.pstride > 1 && a.part != 1 && hdr[kHdrProbe] != 0.0;
     const long per_xcd = (nbatch + 7) / 8;
     for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
         const long batch = (v & 7) * per_xcd + (v >> 3);
         if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
-        const long base = batch * B;
-        const int nb = (int)((n - base < B) ? (n - base) : B);
+        const long base = row0 + batch * B;
+        const int nb = (int)((row1 - base < B) ? (row1 - base) : B);
         TRX_TICK(t_pro);
         // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
         {
@@ -544,6 +598,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         if (lane < nb) {
             const RowC& c = rows[lane];
             hacc[lane] = 0.0;
+            hrem[lane] = 0.0;
             // an unocculted cell: 1 diluted is 1 (or NaN for a degenerate flux ratio)
             double m1 = 1.0;
             if (eblike) m1 = (m1 + c.xeb) / (1.0 + c.xeb);
@@ -577,12 +632,20 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         }
         double lacc = 0.0;                 // LONG: this lane's share of the row's chi^2
         bool nonflat = false;              // LONG: a cell of this lane has a model value other than 1
+        // PRUNE: lnprior of this lane's row (lanes = rows) and the rows abandoned so far
+        double lp_row = 0.0;
+        unsigned long long deadmask = 0;
+        bool long_dead = false;
+        if (PRUNE && a.prune_lp && lane < nb) lp_row = a.prune_lp[a.src_idx ? (long)a.src_idx[base + lane] : base + lane];
+        const int nphase = probing ? 2 : 1;
         TRX_TOCK(0, t_pro);
 
         const int ncell = nb * n_time;
         for (int win0 = 0; win0 < ncell; win0 += kCellsWindow) {
             const int win1 = (win0 + kCellsWindow < ncell) ? (win0 + kCellsWindow) : ncell;
-            // pass 1: window test, 64 cells at a time across row boundaries
+            for (int phase_no = 0; phase_no < nphase; ++phase_no) {
+            // pass 1: window test, 64 cells at a time across row boundaries (PRUNE: phase 0 files the probe
+            // cells, phase 1 the other cells of the rows still alive)
             TRX_TICK(t_p1);
             int nw = 0;
             for (int c0 = win0; c0 < win1; c0 += 64) {
@@ -605,9 +668,20 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     // no occultation anywhere in the exposure: the model is 1, diluted
                     if (MODE == MODE_GRID && (!inw || a.debug_nodes))
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
-                    if (LONG && MODE == MODE_LNL && !inw) {
+                    if (LONG && MODE == MODE_LNL && !inw && phase_no == 0) {
                         const double d = fl[j] - 1.0;
                         lacc += (d * d) / s2;                                   // :486, :537, :586
+                    }
+                    if (PRUNE) {
+                        // what the flat model charges the row for its in-window cells, until they are done
+                        if (!LONG && inw && phase_no == 0) {
+                            const double d = fl[j] - 1.0;
+                            __hip_atomic_fetch_add(&hrem[rr], (d * d) / s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (nphase == 2) {
+                            const bool probe = (j % a.pstride) == (a.pstride >> 1);
+                            inw = inw && (probe == (phase_no == 0));
+                        }
                     }
                 }
                 const unsigned long long mw = __ballot(inw);
@@ -657,7 +731,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 CellPlan pl;
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
-                    pl = plan_cell<false>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0);
+                    pl = plan_cell<false, PRUNE>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
                         kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
@@ -736,7 +810,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                                 const double Mc = c.nmot * (tc - c.t0) + c.Mtr;
                                 const double M = c.nmot * ((tc + a.exptime * frac) - c.t0) + c.Mtr;
                                 bool have = false;
-                                if (STEP && cs.anchored[h]) have = kepler_step(M - Mc, c.e, sE, cE);
+                                if (STEP && cs.anchored[h]) have = kepler_step<PRUNE>(M - Mc, c.e, sE, cE);
                                 if (!have) kepler_full(M, c.e, sE, cE);
                             }
                             const double ce = cE - c.e;
@@ -800,6 +874,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) / s2;
                             if (contrib != 0.0)
                                 __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (PRUNE && nphase == 2 && phase_no == 0) {      // this cell's share of chi^2 is now exact
+                                const double d1 = f - 1.0;
+                                __hip_atomic_fetch_add(&hrem[rr], -(d1 * d1) / s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                     }
                 }
@@ -807,7 +885,45 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             }
             }
             __syncthreads();
+            if (PRUNE && nphase == 2 && phase_no == 0) {
+                // the verdict after the probe cells (and, for free, every out-of-window cell)
+                const double* hdr_b = a.rowc + n * kRowDoubles;
+                const double hmin_run = __hip_atomic_load(&hdr_b[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double xmax_run = __hip_atomic_load(&hdr_b[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (LONG) {
+                    double lb = 0.5 * wave_sum(lacc);
+                    lb -= fma(1e-9, fabs(lb), 1e-9);                       // summation order
+                    const double lp0 = __shfl(lp_row, 0, 64);
+                    long_dead = hmout[0] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp0) < xmax_run - 90.0;
+                    if (long_dead) {
+                        if (lane == 0) {
+                            a.out[base] = lb;
+                            atomicAdd(&g_pruned_rows, 1ull);
+                        }
+                        break;
+                    }
+                } else {
+                    bool dead = false;
+                    if (lane < nb && !((skipmask >> lane) & 1ull)) {
+                        double lb = 0.5 * (flat_sum + hacc[lane] - hrem[lane]);
+                        lb -= fma(1e-9, fabs(lb) + flat_sum, 1e-9);        // cancellation between the three sums
+                        dead = hmout[lane] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp_row) < xmax_run - 90.0;
+#ifdef TRX_PRUNE_NEVER_DEAD
+                        dead = false;
+#endif
+                        if (dead) hrem[lane] = lb;                         // what the row reports
+                    }
+                    const unsigned long long md = __ballot(dead);
+                    deadmask |= md;
+                    skipmask |= md;
+                    if (lane == 0 && md) atomicAdd(&g_pruned_rows, (unsigned long long)__popcll(md));
+                    __syncthreads();
+                }
+            }
+            }
+            if (PRUNE && LONG && long_dead) break;
         }
+        if (PRUNE && LONG && long_dead) { __syncthreads(); continue; }
         if (MODE == MODE_LNL) {
             if (LONG) {
                 // a row whose model is flat over the data takes the launch's flat-model value, so
@@ -816,11 +932,31 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 const double direct = wave_sum(lacc);
                 double h = (hmout[0] == 1.0 || n_time == 0) ? 0.5 * (__any(nonflat) ? direct : flat_sum) : NAN;
                 if (a.model == TRX_MODEL_EB && rows[0].excl != 0.0) h = INFINITY;   // :535-538
-                if (lane == 0) a.out[base] = h;
-            } else if (lane < nb) {
-                double h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
-                if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
-                a.out[base + lane] = h;
+                if (lane == 0) {
+                    a.out[base] = h;
+                    if (PRUNE && (probing || a.part == 1) && h < INFINITY)
+                        tighten_bounds(a.rowc + n * kRowDoubles, h, a.prune_c0 - h + lp_row);
+                }
+            } else {
+                double h = INFINITY;
+                if (lane < nb) {
+                    h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
+                    if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
+                    if (PRUNE && ((deadmask >> lane) & 1ull)) h = hrem[lane];
+                    a.out[base + lane] = h;
+                }
+                if (PRUNE && (probing || a.part == 1)) {
+                    // the batch's best finished row tightens the launch's running bounds (one wave, one update)
+                    const bool fin = lane < nb && !((deadmask >> lane) & 1ull) && h < INFINITY;      // (false for NaN)
+                    double hb = fin ? h : INFINITY, xb = fin ? a.prune_c0 - h + lp_row : -INFINITY;
+                    if (!(xb == xb)) xb = -INFINITY;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        hb = fmin(hb, __shfl_xor(hb, o, 64));
+                        xb = fmax(xb, __shfl_xor(xb, o, 64));
+                    }
+                    if (lane == 0) tighten_bounds(a.rowc + n * kRowDoubles, hb, xb);
+                }
             }
         }
         __syncthreads();
@@ -840,7 +976,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // launches enqueue only the instantiation it predicts.  A stale memo (the address now holds another
 // light curve) is harmless -- the stencil instantiation falls back to the Gauss nodes when the
 // device finds no uniform grid, the other one never uses the stencil.
-template <int MODE, bool STEP, bool FP32, bool LONG, bool ST>
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
 __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
 {
     if (a.n_dev) {
@@ -851,7 +987,12 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             B = batch_rows(nd, a.n_time, a.forced_B);
             B = B < a.B ? B : a.B;
         }
-        if ((long)blockIdx.x >= 8 * (((nd + B - 1) / B + 7) / 8)) return;
+        long rows_here = nd;
+        if (PRUNE && a.part) {
+            const long np = nd < kPilotRows ? nd : kPilotRows;
+            rows_here = a.part == 1 ? np : nd - np;
+        }
+        if ((long)blockIdx.x >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
     }
     double st_radius = 0.0;
     if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
@@ -860,7 +1001,7 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
         if (a.use_stencil == 1 && (st_radius > 0.0) != ST) return;
         if (!ST) st_radius = 0.0;
     }
-    cells_body<MODE, STEP, FP32, LONG, ST>(a, st_radius);
+    cells_body<MODE, STEP, FP32, LONG, ST, PRUNE>(a, st_radius);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -969,15 +1110,23 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                                                           double* __restrict__ ws,
                                                           const long* __restrict__ n_dev,
                                                           const int* __restrict__ src_idx,
-                                                          double* __restrict__ amin_pv, long* __restrict__ amin_pi)
+                                                          double* __restrict__ amin_pv, long* __restrict__ amin_pi,
+                                                          const double* __restrict__ bounds_base)
 {
     typedef double dvec2 __attribute__((ext_vector_type(2)));
     Lme st{-INFINITY, 0.0, 0};
     unsigned nblocks = gridDim.x;
+    // SCEN after a bounded evaluation (cells_kernel<PRUNE>): the launch header holds the largest log-weight M
+    // of the call, and every term below M - 90 is taken as -inf.  Such a term carries no weight either way;
+    // but WHICH rows were abandoned (and report a bound instead of their value) depends on timing, and a term
+    // that is large against a thread's running maximum steers the fold below (queues, the census): filtered,
+    // the fold sees the same numbers every run -- the rows within 90 of M are never abandoned.
+    double floor_x = -INFINITY;
     if (SCEN) {
         n = *n_dev;
         nblocks = (unsigned)lme_blocks(n);
         if (blockIdx.x >= nblocks) return;
+        if (bounds_base) floor_x = bounds_base[n * kRowDoubles + kHdrXmax] - 90.0;
     }
     double amin_v = INFINITY;          // SCEN: this thread's first minimum of h
     long amin_i = -1;
@@ -1051,6 +1200,10 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                     a = c0 - a;
                     if (pri) a += curp[u];
                 }
+                if (SCEN) {
+                    a.x = (a.x < floor_x) ? -INFINITY : a.x;
+                    a.y = (a.y < floor_x) ? -INFINITY : a.y;
+                }
                 x[2 * u] = ok ? a.x : -INFINITY;
                 x[2 * u + 1] = ok ? a.y : -INFINITY;
             }
@@ -1101,6 +1254,7 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                 if (amin_i < 0 || argmin_before(hv, n - 1, amin_v, amin_i)) { amin_v = hv; amin_i = n - 1; }
                 double x = c0 - hv;
                 if (lnprior) x += lnprior[src_idx[n - 1]];
+                if (x < floor_x) x = -INFINITY;
                 lme_fold4(st, x, -INFINITY, -INFINITY, -INFINITY);
             } else {
                 lme_fold4(st, lme_value(logw, h, lnprior, c0, n - 1), -INFINITY, -INFINITY, -INFINITY);
@@ -1211,6 +1365,8 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
+std::atomic<int> g_prune{1};          // bounded evaluation in trx_scenario_evidence (0 = every row evaluated to the end)
+std::atomic<int> g_prune_lnl{0};      // tests: trx_lnl_batch applies it too (as for an evidence without prior)
 std::atomic<int> g_skip_excluded{1};  // rows excluded by the EB secondary rule are not evaluated (likelihood calls)
 std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
 std::atomic<int> g_debug_nodes{0};  // grid mode writes the number of model evaluations per cell instead of the flux
@@ -1353,6 +1509,63 @@ StencilMemo g_stencil_memo;
 // light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
 std::atomic<int> g_cells_below{320};
 
+// what the last launch_cells of this thread did (trx::lnl_draws hands it to the reduction that follows)
+thread_local const double* t_last_rowc = nullptr;
+thread_local bool t_last_pruned = false;
+
+// After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 35 %
+// of the finite ones lie more than 150 above the smallest, the main launch evaluates its rows in one pass
+// (a scenario no draw of which comes near the data -- a faint neighbour that would need a 50 % deep eclipse --
+// has all its rows within a few tens of each other: nothing to abandon, and probing costs ~10 %).
+__global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
+                                                          double* __restrict__ rowc)
+{
+    __shared__ double smin[4];
+    __shared__ int sfar[4], sfin[4];
+    if (n_dev) n = *n_dev;
+    const long np = n < kPilotRows ? n : kPilotRows;
+    double m = INFINITY;
+    for (long i = threadIdx.x; i < np; i += 256) {
+        const double v = h[i];
+        if (v < m) m = v;                               // (false for NaN)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    int far = 0, fin = 0;
+    for (long i = threadIdx.x; i < np; i += 256) {
+        const double v = h[i];
+        fin += (v < INFINITY) ? 1 : 0;
+        far += (v < INFINITY && v > m + 150.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { far += __shfl_xor(far, o, 64); fin += __shfl_xor(fin, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sfar[threadIdx.x >> 6] = far; sfin[threadIdx.x >> 6] = fin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        far = sfar[0] + sfar[1] + sfar[2] + sfar[3];
+        fin = sfin[0] + sfin[1] + sfin[2] + sfin[3];
+        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 35L * fin) ? 1.0 : 0.0;
+    }
+}
+
+// the PRUNE instantiations exist for the likelihood mode only
+template <int MODE>
+void launch_pruned(const RowsArgs& a, hipStream_t st, bool long_rows, bool fp32, unsigned grid, size_t lds)
+{
+    if constexpr (MODE == MODE_LNL) {
+        if (long_rows) {
+            if (fp32) hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, true, true, false, true>), dim3(grid), dim3(64), lds, st, a);
+            else      hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, false, true, false, true>), dim3(grid), dim3(64), lds, st, a);
+        } else {
+            if (fp32) hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, true, false, false, true>), dim3(grid), dim3(64), lds, st, a);
+            else      hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, false, false, false, true>), dim3(grid), dim3(64), lds, st, a);
+        }
+    }
+}
+
 template <int MODE>
 int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
 {
@@ -1379,7 +1592,11 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     };
     const unsigned grid = grid_for(a.nbatch);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
-    a.use_stencil = (long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
+    // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
+    const bool prune = MODE == MODE_LNL && a.prune && g_prune.load(std::memory_order_relaxed) && g_step.load(std::memory_order_relaxed);
+    a.prune = prune ? 1 : 0;
+    a.pstride = prune ? (a.n_time >= 48 ? a.n_time / 16 : 1) : 1;
+    a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
@@ -1396,7 +1613,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
-    size_t head = ((size_t)a.B * (kRowDoubles + 2) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
+    size_t head = ((size_t)a.B * (kRowDoubles + 3) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
                 + (kCellsPairs + cells_window(long_rows)) * sizeof(unsigned short) + sizeof(CellState);
     if (long_rows) head += sizeof(StencilState);
     static_assert((kCellsPairs + kCellsWindowLong) % 4 == 0 && (kCellsPairs + kCellsWindowBatch) % 4 == 0 &&
@@ -1426,7 +1643,21 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
     const unsigned g2 = long_rows ? grid_for(a.n) : grid;
-    if (long_rows) {
+    t_last_rowc = a.rowc;
+    t_last_pruned = prune;
+    if (prune) {
+        // pilot rows (evaluated to the end; first values of the running bounds), verdict on probing, the rest
+        const long np = a.n < kPilotRows ? a.n : kPilotRows;
+        const long pilot_batches = long_rows ? np : (np + a.B - 1) / a.B;
+        RowsArgs ap = a;
+        ap.part = 1;
+        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_batches + 7) / 8)), lds);
+        if (a.n_dev || a.n > kPilotRows) {
+            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc);
+            ap.part = 2;
+            launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+        }
+    } else if (long_rows) {
         if (verdict != 2) {
             if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, false>), dim3(g2), dim3(64), lds, st, a);
             else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true, false>), dim3(g2), dim3(64), lds, st, a);
@@ -1466,7 +1697,8 @@ int launch_lme(const double* logw, const double* h, const double* lnprior, doubl
     const uintptr_t al = (uintptr_t)(h ? h : logw) | (uintptr_t)lnprior;
     const int vec_ok = (al % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(lme_partial_kernel<false>, dim3(blocks), dim3(256), 0, st, logw, h, lnprior, c0, n,
-                       vec_ok, ws, (const long*)nullptr, (const int*)nullptr, (double*)nullptr, (long*)nullptr);
+                       vec_ok, ws, (const long*)nullptr, (const int*)nullptr, (double*)nullptr, (long*)nullptr,
+                       (const double*)nullptr);
     TRX_HIP(hipGetLastError());
     hipLaunchKernelGGL(lme_final_kernel, dim3(1), dim3(64), 0, st, ws, blocks, n_total, out);
     TRX_HIP(hipGetLastError());
@@ -1533,8 +1765,10 @@ int fail_hip(hipError_t e) { return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipG
 
 int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
               const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
-              int twin, double exptime, int nsupersample, double* out_halfchi2, hipStream_t st)
+              int twin, double exptime, int nsupersample, double* out_halfchi2, const double* lnprior,
+              double lnsigma, const double** bounds_base, hipStream_t st)
 {
+    *bounds_base = nullptr;
     if (int rc = check_rows(model, time, n_time, cols, n_upper, nsupersample)) return rc;
     if (model == TRX_MODEL_RAW || !n_dev || !src_idx || !out_halfchi2 || n_upper < 1 || (n_time > 0 && !flux))
         return fail(TRX_ERR_ARG, "lnl_draws: bad argument%s", "", 0);
@@ -1542,17 +1776,23 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
     a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
     a.params = cols; a.n = n_upper; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
     a.n_dev = n_dev; a.src_idx = src_idx; a.src_stride = src_stride; a.twin_cols = twin;
-    return launch_rows<MODE_LNL>(a, st);
+    // the caller keeps only lnZ and the best draw of these rows: bounded evaluation (cells_body, PRUNE)
+    a.prune = 1;
+    a.prune_c0 = -0.5 * log(kTwoPi) - lnsigma;
+    a.prune_lp = lnprior;
+    const int rc = launch_rows<MODE_LNL>(a, st);
+    if (rc == TRX_OK && t_last_pruned) *bounds_base = t_last_rowc;
+    return rc;
 }
 
 int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
-              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, hipStream_t st)
+              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base, hipStream_t st)
 {
     if (!halfchi2 || !n_dev || !src_idx || !ws || !amin_pv || !amin_pi || ((uintptr_t)halfchi2 % 16) != 0)
         return fail(TRX_ERR_ARG, "lme_draws: bad argument%s", "", 0);
     const double c0 = -0.5 * log(kTwoPi) - lnsigma;   // marginal_likelihoods.py:130 etc.
     hipLaunchKernelGGL(lme_partial_kernel<true>, dim3(lme_blocks(n_upper)), dim3(256), 0, st, (const double*)nullptr,
-                       halfchi2, lnprior, c0, n_upper, 1, ws, n_dev, src_idx, amin_pv, amin_pi);
+                       halfchi2, lnprior, c0, n_upper, 1, ws, n_dev, src_idx, amin_pv, amin_pi, bounds_base);
     TRX_HIP(hipGetLastError());
     return TRX_OK;
 }
@@ -1572,6 +1812,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     RowsArgs a{};
     a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
     a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
+    if (g_prune_lnl.load(std::memory_order_relaxed)) { a.prune = 1; a.prune_c0 = 0.0; a.prune_lp = nullptr; }
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1743,6 +1984,32 @@ int trx_skipped_rows(unsigned long long* out, int reset)
     if (reset) {
         const unsigned long long zero = 0;
         TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_skipped_rows), &zero, sizeof(zero)));
+    }
+    return TRX_OK;
+}
+
+/* diagnostics (include/trx.h): 0 = trx_scenario_evidence evaluates every masked draw to the end */
+int trx_set_bounded_evaluation(int on)
+{
+    g_prune = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* tests (include/trx.h): trx_lnl_batch / trx_lnz_scenario evaluate their rows the bounded way, too */
+int trx_set_debug_bounded_lnl(int on)
+{
+    g_prune_lnl = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* statistics (include/trx.h): rows abandoned by the bounded evaluation on the current device since the last reset */
+int trx_pruned_rows(unsigned long long* out, int reset)
+{
+    TRX_HIP(hipDeviceSynchronize());
+    if (out) TRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pruned_rows), sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero = 0;
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pruned_rows), &zero, sizeof(zero)));
     }
     return TRX_OK;
 }

@@ -182,12 +182,13 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
                        A.at<int>(o_cnt), idx[0], idx[1], n_dev);
     for (int b = 0; b < nbr; ++b) {
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
+        const double* bounds = nullptr;
         if (int rc = trx::lnl_draws(model, s->flags, s->time, s->flux, s->n_time, s->sigma, d.cols, N, n_dev + b, idx[b], N,
-                                    b, s->exptime, s->nsupersample, h[b], st))
+                                    b, s->exptime, s->nsupersample, h[b], d.lnprior, s->lnsigma, &bounds, st))
             return rc;
         if (int rc = trx::lme_draws(h[b], d.lnprior, s->lnsigma, N, n_dev + b, idx[b],
                                     A.at<double>(o_ws) + (size_t)b * 3 * kLmeParts, A.at<double>(o_pv) + (size_t)b * kLmeParts,
-                                    A.at<long>(o_pi) + (size_t)b * kLmeParts, st))
+                                    A.at<long>(o_pi) + (size_t)b * kLmeParts, bounds, st))
             return rc;
     }
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)nbr), dim3(64), 0, st, A.at<double>(o_ws), A.at<double>(o_pv),
