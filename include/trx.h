@@ -173,14 +173,17 @@ int trx_set_rows_per_wave(int rows);
  *    exposure centre's solution;
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
  *    for each cell instead of the flux. */
-/*  - trx_set_bounded_evaluation(0): trx_scenario_evidence / trx_scenario_enqueue evaluate every masked draw to
- *    the end.  By default a draw is abandoned once its chi^2 over the cells done so far shows that it can
- *    neither be the best draw (it exceeds the smallest finished chi^2) nor carry weight in the evidence (its
- *    log-weight lies 90 below the largest finished one; the reduction drops everything 80 below the largest):
- *    lnZ and the best draw come out bit for bit the same, most draws of a real detection stop after ~16
- *    probe cells.  trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the device).  The
- *    per-row entry points (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
-int trx_set_bounded_evaluation(int on);
+/*  - trx_set_bounded_evaluation(mode): 0 = trx_scenario_evidence / trx_scenario_enqueue evaluate every masked
+ *    draw to the end; 1 (default) = bounded evaluation for light curves of trx_set_cell_packing_below's
+ *    threshold and more (one row per wave), 2 = for every light curve.  Bounded: a draw is abandoned once its
+ *    chi^2 over the cells done so far shows that it can neither be the best draw (it exceeds the smallest
+ *    finished chi^2) nor carry weight in the evidence (its log-weight lies 90 below the largest finished one;
+ *    the reduction drops everything 80 below the largest).  lnZ agrees to rounding (the ~16 probe cells of a
+ *    row are summed first), the best draw is the same, results repeat bit for bit from run to run; the first
+ *    4096 rows are evaluated to the end (they seed the bounds and decide whether probing pays).
+ *    trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the device).  The per-row entry
+ *    points (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
+int trx_set_bounded_evaluation(int mode);
 /*    trx_set_debug_bounded_lnl(1) (tests): trx_lnl_batch / trx_lnz_scenario treat their rows the same way, as
  *    for an evidence without prior: a row then holds its chi^2/2 or, if abandoned, a lower bound of it that
  *    exceeds the smallest chi^2/2 of the call by more than 90. */

@@ -149,9 +149,10 @@ def test_native_scenario_call_equals_the_torch_operator_path():
     """trx_scenario_enqueue (draws -> compaction -> likelihood -> evidence -> best draw in one library
     call, no host sync) against the chain of torch operators around trx_draw_scenario / trx_lnz_scenario on
     the same Philox keys, on all 18 scenarios of several TOIs, with a contrast curve, in fp64 and in the
-    mixed-precision mode.  With every row evaluated to the end (trx_set_bounded_evaluation(0)): every lnZ,
-    every best-fit column and FPP / NFPP bit for bit.  With the bounded evaluation (the default): the same
-    best draws, lnZ to 1e-12 (the probe cells of a row are summed first: another order of the same terms)."""
+    mixed-precision mode.  With every row evaluated to the end (trx_set_bounded_evaluation(0), and the default
+    for these 200-point light curves): every lnZ, every best-fit column and FPP / NFPP bit for bit.  With the
+    bounded evaluation forced (mode 2): the same best draws, lnZ to 1e-12 (the probe cells of a row are summed
+    first: another order of the same terms)."""
     import triceratops_amd
     from triceratops_amd import fused, sharding
     triceratops_amd.set_sampling("device")
@@ -165,7 +166,7 @@ def test_native_scenario_call_equals_the_torch_operator_path():
             got = {}
             for mode in ("native", "native-unbounded", "torch"):
                 fused.NATIVE = mode != "torch"
-                L.trx_set_bounded_evaluation(0 if mode == "native-unbounded" else 1)
+                L.trx_set_bounded_evaluation(0 if mode == "native-unbounded" else 2)
                 np.random.seed(5)
                 torch.manual_seed(5)
                 _lib.reset_stats()

@@ -1,0 +1,112 @@
+"""set_sampling("device") against set_sampling("numpy"), the reference's own host arithmetic: all ten lnZ_*
+of calc_probs (marginal_likelihoods.py:39-2362), 20 seeds per mode at N = 1e6 on TOI-465.01's light curve
+(with its contrast curve).  The two modes cannot be compared draw for draw (numpy's MT19937 stream against
+Philox counters in the draw kernel), so the comparison is statistical:
+
+ * per branch (q < 0.95 / twin), mean lnZ of the two modes within 3 standard errors of their difference --
+   wherever the estimate is not carried by a single draw (seed-to-seed scatter of lnZ below 2.5: a hopeless
+   fit's evidence is the luckiest draw's, and its mean over 20 runs means nothing);
+ * per lnZ_* call, the share of draws that pass the geometry masks (transit probability, collision,
+   q < 0.95 / >= 0.95, companion cuts; marginal_likelihoods.py:101-123): the binomial scatter at N = 1e6 is
+   ~3e-4 of the share, so a wrong sampler, mask or column on the device side shows at once (two-sample
+   Kolmogorov-Smirnov over the 20 + 20 runs and agreement of the means within 4 standard errors).
+
+The table goes to stdout (pytest -s) and, from profiles/mc_scatter.py, into profiles/r03_mc_scatter.txt."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.stats import ks_2samp
+
+import anchors
+from helpers import GOLD
+
+pytestmark = pytest.mark.gpu
+N = 1_000_000
+SEEDS = range(2000, 2020)
+
+
+def _jobs():
+    from triceratops_amd import marginal_likelihoods as ml
+    stars, t, f, sigma, P = anchors.inputs("toi465_cc")
+    M_s, R_s, Teff, plx = (float(stars[c][0]) for c in ("mass", "rad", "Teff", "plx"))
+    mags = tuple(float(stars[c][0]) for c in ("Tmag", "Jmag", "Hmag", "Kmag"))
+    cc, tri = anchors.CC465, anchors.TRILEGAL
+    base = (t, f, sigma, P, M_s, R_s, Teff)
+    return {
+        "TTP": lambda: ml.lnZ_TTP(*base, 0.0, N, True),
+        "TEB": lambda: ml.lnZ_TEB(*base, 0.0, N, True),
+        "PTP": lambda: ml.lnZ_PTP(*base, 0.0, plx, cc, "TESS", N, True),
+        "PEB": lambda: ml.lnZ_PEB(*base, 0.0, plx, cc, "TESS", N, True),
+        "STP": lambda: ml.lnZ_STP(*base, 0.0, plx, cc, "TESS", N, True),
+        "SEB": lambda: ml.lnZ_SEB(*base, 0.0, plx, cc, "TESS", N, True),
+        "DTP": lambda: ml.lnZ_DTP(*base, 0.0, *mags, tri, cc, "TESS", N, True),
+        "DEB": lambda: ml.lnZ_DEB(*base, 0.0, *mags, tri, cc, "TESS", N, True),
+        "BTP": lambda: ml.lnZ_BTP(*base, *mags, tri, cc, "TESS", N, True),
+        "BEB": lambda: ml.lnZ_BEB(*base, *mags, tri, cc, "TESS", N, True),
+    }
+
+
+def collect(seeds=SEEDS):
+    """{mode: {name: (lnZ [runs][branches], mask share [runs])}}"""
+    import triceratops_amd
+    from triceratops_amd import _lib
+    out = {}
+    jobs = _jobs()
+    prev = triceratops_amd.get_sampling()
+    try:
+        for mode in ("numpy", "device"):
+            triceratops_amd.set_sampling(mode)
+            out[mode] = {}
+            for name, job in jobs.items():
+                lnz, share = [], []
+                for seed in seeds:
+                    np.random.seed(seed)
+                    torch.manual_seed(seed)
+                    _lib.reset_stats()
+                    res = job()
+                    torch.cuda.synchronize()
+                    lnz.append([d["lnZ"] for d in (res if isinstance(res, tuple) else (res,))])
+                    share.append(_lib.STATS["rows"] / N)
+                out[mode][name] = (np.array(lnz), np.array(share))
+    finally:
+        triceratops_amd.set_sampling(prev)
+    return out
+
+
+def table(out):
+    lines = ["%-5s %-6s %10s %8s %10s %8s %7s   %9s %9s %7s %6s" % ("call", "branch", "numpy lnZ", "std", "device lnZ", "std",
+                                                                 "z", "numpy n/N", "device n/N", "z", "KS p")]
+    rows = []
+    for name in out["numpy"]:
+        (za, sa), (zb, sb) = out["numpy"][name], out["device"][name]
+        se = np.sqrt(sa.var(ddof=1) / sa.size + sb.var(ddof=1) / sb.size)
+        zs = (sa.mean() - sb.mean()) / se if se > 0 else 0.0
+        ks = ks_2samp(sa, sb).pvalue
+        for b in range(za.shape[1]):
+            fa, fb = za[:, b][np.isfinite(za[:, b])], zb[:, b][np.isfinite(zb[:, b])]
+            if fa.size < 2 or fb.size < 2:
+                z = float("nan")
+                ma = mb = da = db = float("nan")
+            else:
+                ma, mb, da, db = fa.mean(), fb.mean(), fa.std(ddof=1), fb.std(ddof=1)
+                z = (ma - mb) / np.sqrt(da ** 2 / fa.size + db ** 2 / fb.size)
+            rows.append((name, b, ma, da, mb, db, z, sa.mean(), sb.mean(), zs, ks, fa.size, fb.size))
+            lines.append("%-5s %-6s %10.3f %8.3f %10.3f %8.3f %7.2f   %9.6f %9.6f %7.2f %6.3f"
+                         % (name, "twin" if b else "main", ma, da, mb, db, z, sa.mean(), sb.mean(), zs, ks))
+    return rows, "\n".join(lines)
+
+
+def test_all_ten_scenarios_device_equals_numpy_sampling_statistically():
+    rows, text = table(collect())
+    print("\n" + text)
+    checked = 0
+    for name, b, ma, da, mb, db, z, sa, sb, zs, ks, na, nb in rows:
+        assert na == nb == len(SEEDS) or (na < 2 and nb < 2), (name, b, na, nb)     # the same branches are finite
+        if b == 0:
+            assert abs(zs) < 4.0 and ks > 1e-3, (name, "mask share", sa, sb, zs, ks)
+        if np.isfinite(z) and max(da, db) < 2.5:
+            checked += 1
+            assert abs(z) < 3.0, (name, b, ma, mb, z)
+    assert checked >= 6

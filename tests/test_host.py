@@ -223,3 +223,14 @@ def test_constant_period_semi_major_axis_shortcut_is_bit_identical():
     M_var = rng.uniform(0.5, 2.0, 1000)
     assert np.array_equal(ml._sma(M_var, np.full(1000, 3.3)),
                           ((G * M_var * Msun) / (4 * pi ** 2) * (np.full(1000, 3.3) * 86400) ** 2) ** (1 / 3))
+
+
+def test_default_sampling_mode_is_the_device_path():
+    """a user who drops the package in gets the fast mode; "numpy" is the validation mode (conftest.py selects it)"""
+    import subprocess
+    import sys
+    code = ("import triceratops_amd, triceratops_amd.marginal_likelihoods as ml;"
+            "assert ml.DEFAULT_SAMPLING == 'device' and triceratops_amd.get_sampling() == 'device'")
+    env = {k: v for k, v in __import__("os").environ.items() if k != "TRX_SAMPLING"}
+    assert subprocess.run([sys.executable, "-c", code], cwd=__import__("os").path.dirname(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__))), env=env).returncode == 0

@@ -59,13 +59,20 @@ def _flatten(results):
     return rows
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, seed=4242):
+    import triceratops_amd
+    triceratops_amd.set_sampling("numpy")       # (a fresh process starts in the package default, "device")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    np.random.seed(4242)                      # same global state on every rank, like a user would
+    np.random.seed(seed if seed else 100 + rank)   # same global state on every rank (sharding verifies it)
     units = _fake_units()
-    res = sharding.run_units(units, verbose=0)
+    try:
+        res = sharding.run_units(units, verbose=0)
+    except RuntimeError as exc:
+        q.put((rank, str(exc), None))
+        dist.destroy_process_group()
+        return
     owners = sharding.schedule([sharding._COST.get(u[5], 1.0) for u in units if u[4] is not None], world)
     q.put((rank, _flatten(res), owners))
     dist.barrier()
@@ -110,6 +117,21 @@ def test_world2_gloo_matches_single_process():
     for a, b in zip(res0, single):
         assert (a is None and b is None) or np.array_equal(a, b)
     assert res0[3] is None      # the dropped PEB unit stays empty
+
+
+def test_ranks_seeded_differently_are_refused():
+    """the seed base is drawn on every rank instead of being broadcast; the all_gather carries it and a
+    mismatch raises on every rank"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 0)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(g[1], str) and "seed numpy alike" in g[1] for g in got)
 
 
 def test_single_process_consumes_the_stream_sequentially():
@@ -215,6 +237,8 @@ def test_calc_probs_many_equals_sequential_calls_on_one_stream(monkeypatch):
 
 def _many_worker(rank, world, port, q):
     import pytest as _pytest
+    import triceratops_amd
+    triceratops_amd.set_sampling("numpy")
     from helpers import install_cpu_device_fakes
     from triceratops_amd.triceratops import calc_probs_many
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -234,10 +258,11 @@ def _many_worker(rank, world, port, q):
     mp_.undo()
 
 
-def test_calc_probs_many_world2_gloo_matches_single_process(monkeypatch):
+@pytest.mark.parametrize("world", [2, 4])
+def test_calc_probs_many_gloo_matches_single_process(monkeypatch, world):
     from helpers import install_cpu_device_fakes
     from triceratops_amd.triceratops import calc_probs_many
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_many_worker, args=(r, world, port, q)) for r in range(world)]
@@ -247,11 +272,12 @@ def test_calc_probs_many_world2_gloo_matches_single_process(monkeypatch):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, t0, own0), (_, t1, own1) = got
-    assert own0 == own1 and set(own0) == {0, 1}
-    # the larger job's units weigh more: the two ranks' loads are balanced by weight, not by count
-    for a, b in zip(t0, t1):
-        assert np.array_equal(a, b, equal_nan=True)
+    t0, own0 = got[0][1], got[0][2]
+    assert all(g[2] == own0 for g in got) and set(own0) == set(range(world))
+    # the larger job's units weigh more: the ranks' loads are balanced by weight, not by count
+    for g in got[1:]:
+        for a, b in zip(t0, g[1]):
+            assert np.array_equal(a, b, equal_nan=True)
     install_cpu_device_fakes(monkeypatch)
     jobs = _two_jobs()
     np.random.seed(77)

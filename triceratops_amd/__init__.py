@@ -8,9 +8,10 @@ __version__ = "0.2.0"
 
 
 def set_sampling(mode):
-    """'numpy' (default): priors sampled on the host from numpy's global stream, bit-for-bit the
-    reference's host arithmetic; 'numpy-device': the same stream and draws, everything downstream
-    of the uniforms on the GPU; 'device': the whole scenario on the GPU with torch's generator."""
+    """'device' (default): the whole scenario on the GPU, the draw kernel's own Philox numbers (seeded through
+    torch.manual_seed); 'numpy': priors sampled on the host from numpy's global stream, bit-for-bit the
+    reference's host arithmetic under the same np.random.seed (the validation mode, ~300x slower at N = 1e6);
+    'numpy-device': the same stream and draws, everything downstream of the uniforms on the GPU."""
     from .marginal_likelihoods import set_sampling as _set
     _set(mode)
 
@@ -30,8 +31,11 @@ def set_precision(mode):
 
 def set_threads(n):
     """Host threads (each with its own HIP stream) that evaluate the scenarios of calc_probs /
-    calc_probs_many side by side; effective with set_sampling("device") only.  Implies per-unit
-    seeding: results do not depend on n."""
+    calc_probs_many side by side; effective with set_sampling("device") only (the numpy modes consume one
+    global stream and stay on the calling thread).  With n > 1 every work unit draws from its own Philox key,
+    so results do not depend on n >= 2 (sharding.per_unit_seed = True gives the same numbers with n = 1).
+    One thread already overlaps the calls on sharding.streams HIP streams; more threads only help when
+    the host side of the calls is the bottleneck."""
     from . import sharding
     if int(n) < 1:
         raise ValueError("threads must be >= 1")

@@ -1365,7 +1365,7 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
-std::atomic<int> g_prune{1};          // bounded evaluation in trx_scenario_evidence (0 = every row evaluated to the end)
+std::atomic<int> g_prune{1};          // bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always
 std::atomic<int> g_prune_lnl{0};      // tests: trx_lnl_batch applies it too (as for an evidence without prior)
 std::atomic<int> g_skip_excluded{1};  // rows excluded by the EB secondary rule are not evaluated (likelihood calls)
 std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
@@ -1593,7 +1593,12 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     const unsigned grid = grid_for(a.nbatch);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
-    const bool prune = MODE == MODE_LNL && a.prune && g_prune.load(std::memory_order_relaxed) && g_step.load(std::memory_order_relaxed);
+    // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
+    // 46 -> 39 ms; at 100 binned points the batched variant gains or loses ~3 % (the probe phase, the pilot
+    // launch and the second window pass eat what the abandoned rows save): profiles/r03_bounded_e2e.txt)
+    const int prune_mode = a.prune == 2 ? 2 : g_prune.load(std::memory_order_relaxed);
+    const bool prune = MODE == MODE_LNL && a.prune && g_step.load(std::memory_order_relaxed) &&
+                       (prune_mode == 2 || (prune_mode == 1 && long_rows));
     a.prune = prune ? 1 : 0;
     a.pstride = prune ? (a.n_time >= 48 ? a.n_time / 16 : 1) : 1;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
@@ -1812,7 +1817,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     RowsArgs a{};
     a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
     a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
-    if (g_prune_lnl.load(std::memory_order_relaxed)) { a.prune = 1; a.prune_c0 = 0.0; a.prune_lp = nullptr; }
+    if (g_prune_lnl.load(std::memory_order_relaxed)) { a.prune = 2; a.prune_c0 = 0.0; a.prune_lp = nullptr; }
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1989,9 +1994,10 @@ int trx_skipped_rows(unsigned long long* out, int reset)
 }
 
 /* diagnostics (include/trx.h): 0 = trx_scenario_evidence evaluates every masked draw to the end */
-int trx_set_bounded_evaluation(int on)
+int trx_set_bounded_evaluation(int mode)
 {
-    g_prune = on ? 1 : 0;
+    if (mode < 0 || mode > 2) return fail(TRX_ERR_ARG, "bounded evaluation mode must be 0, 1 or 2%s (got %ld)", "", (long)mode);
+    g_prune = mode;
     return TRX_OK;
 }
 

@@ -691,12 +691,25 @@ def lnZ_NEB_evolved(time, flux, sigma, P_orb, R_s, Teff, Z, N: int = 1000000,
 
 # ---------------------------------------------------------------------------------------
 # where the priors are sampled:
-#   "numpy"         host numpy, the reference's own arithmetic: draw-for-draw and bit-for-bit
+#   "device"        (default) the whole scenario on the GPU: one HIP kernel draws (Philox4x32-10, keyed by
+#                   torch's CPU generator: torch.manual_seed reproduces a run), derives, masks and weighs the
+#                   N draws; statistically equivalent to the reference (tests/test_gpu_equivalence.py,
+#                   tests/test_gpu_notebook_anchors.py), ~300x faster end to end than "numpy" at N = 1e6
+#   "numpy"         host numpy, the reference's own arithmetic on numpy's global stream: draw-for-draw and
+#                   bit-for-bit the reference under the same np.random.seed -- the validation mode
 #   "numpy-device"  numpy's global stream supplies the uniforms in the reference's order, everything
-#                   downstream runs on the GPU (triceratops_amd/device_pipeline.py): the same draws
-#                   as the reference, derived columns equal to rounding, ~6x faster than "numpy"
-#   "device"        torch's device generator: statistically equivalent, fastest
-_sampling = {"mode": "numpy"}
+#                   downstream runs on the GPU: the same draws as the reference, derived columns equal to
+#                   rounding, ~6x faster than "numpy"
+# TRX_SAMPLING in the environment overrides the default.
+import os as _os
+
+DEFAULT_SAMPLING = "device"
+_sampling = {"mode": _os.environ.get("TRX_SAMPLING", DEFAULT_SAMPLING)}
+if _sampling["mode"] not in ("numpy", "numpy-device", "device"):
+    raise ValueError("TRX_SAMPLING must be 'numpy', 'numpy-device' or 'device'")
+if _sampling["mode"] == "numpy-device":
+    from . import device_pipeline as _dp
+    _dp.RNG = _dp.NumpyStreamRng()
 
 
 def set_sampling(mode):

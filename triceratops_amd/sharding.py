@@ -9,12 +9,13 @@ scenario: the best-fit row + lnZ) assembles the result on every rank.  No other 
 on the data path; the message is a few KB, i.e. latency-bound, so a single direct all_gather
 is the right primitive (no ring, no bucketing).
 
-Random numbers: the lnZ_* functions draw from the global numpy stream like the reference.
-  world == 1  the stream is consumed sequentially, unit after unit -- identical to the reference
-              under the same np.random.seed (unless per_unit_seed is set);
-  world  > 1  each unit reseeds the stream from (base, unit index), base being one draw of rank
-              0's stream broadcast to all ranks, so the result does not depend on the partition
-              or on the world size (per_unit_seed=True gives the same numbers on one GPU).
+Random numbers.  world == 1: the generator of the sampling mode is consumed unit after unit (numpy modes:
+identical to the reference under the same np.random.seed), unless per_unit_seed is set.  world > 1: each
+unit draws from its own seed, derived from (base, unit index), so the result does not depend on the
+partition or on the world size (per_unit_seed = True gives the same numbers on one GPU).  base is one draw
+of numpy's global stream, taken on EVERY rank: the ranks must be seeded alike (np.random.seed(s) on all of
+them), which the all_gather verifies at no extra cost -- each rank's base rides in its chunk and a mismatch
+raises.  No seed broadcast: the all_gather is the only collective of a calc_probs.
 """
 import os
 
@@ -94,13 +95,7 @@ def run_units(units, verbose=0):
     owner = {k: 0 for k in live}
     base = None
     if dist:
-        import torch
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        b = torch.zeros(1, dtype=torch.int64, device=dev)
-        if rank == 0:
-            b[0] = int(np.random.randint(0, 2 ** 31 - 1))
-        dist.broadcast(b, src=0)
-        base = int(b[0])
+        base = int(np.random.randint(0, 2 ** 31 - 1))     # the same on every rank (verified in the all_gather)
         own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
                         for k in live], world)
         owner = {k: own[i] for i, k in enumerate(live)}
@@ -169,6 +164,9 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             table[offs[k]:offs[k] + rows[k]] = _record(p.result())
 
     on_device = _fused.threadable()
+    if on_device:
+        import torch
+        on_device = torch.cuda.is_available()          # (without a GPU the thunks fail loudly themselves)
     n_threads = min(threads, len(mine_k)) if (base is not None and on_device) else 1
     if n_threads <= 1 and not (on_device and mine_k):
         for k in mine_k:
@@ -234,14 +232,31 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         resolve()
 
     if dist:
+        # ONE collective: every rank contributes the records of its own units (in unit order, padded to the
+        # largest share) behind one header row that carries its seed base -- 15 doubles per scenario, a few KB
+        # per rank, latency-bound: a direct all_gather, no ring, no bucketing
         import torch
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        mine = torch.as_tensor(table).to(dev).reshape(-1)
+        ncol = len(RECORD_COLS)
+        share = [sum(rows[k] for k in live if owner[k] == r) for r in range(world)]
+        chunk = np.full((1 + max(share + [0]), ncol), np.nan)
+        chunk[0, 0] = float(base)
+        at = 1
+        for k in mine_k:
+            chunk[at:at + rows[k]] = table[offs[k]:offs[k] + rows[k]]
+            at += rows[k]
+        mine = torch.as_tensor(chunk).to(dev).reshape(-1)
         gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, mine)          # the single data-path collective
-        g = gathered.cpu().numpy().reshape((world,) + table.shape)
+        dist.all_gather_into_tensor(gathered, mine)          # the single collective
+        g = gathered.cpu().numpy().reshape((world,) + chunk.shape)
+        if not np.all(g[:, 0, 0] == float(base)):
+            raise RuntimeError("triceratops_amd.sharding: the ranks drew different seed bases %s -- seed numpy "
+                               "alike on every rank (np.random.seed(s)) before calc_probs" % g[:, 0, 0].tolist())
+        at = [1] * world
         for k in live:
-            table[offs[k]:offs[k] + rows[k]] = g[owner[k], offs[k]:offs[k] + rows[k]]
+            r = owner[k]
+            table[offs[k]:offs[k] + rows[k]] = g[r, at[r]:at[r] + rows[k]]
+            at[r] += rows[k]
 
     out = []
     for k, u in enumerate(units):
