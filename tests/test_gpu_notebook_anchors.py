@@ -89,19 +89,35 @@ def test_fpp_without_contrast_curve_against_the_notebooks_20_runs():
 
 @pytest.mark.parametrize("case", ["toi465_nocc", "toi411"])
 def test_device_path_against_runs_of_the_current_reference_code(case):
-    """lnZ of TP / PTP / STP, log FPP and the TP radius: this implementation's runs against the reference's own
-    (reference_runs.npz), Welch's statistic below 3 for each"""
+    """lnZ of TP / PTP / STP, FPP and the TP radius: this implementation's runs against the reference's own
+    (reference_runs.npz; 6 and 4 runs).  The evidences of a run are skewed (a lucky draw lifts lnZ), so the
+    comparison is by rank: Mann-Whitney's two-sided p-value above 0.002 for each quantity."""
+    from scipy.stats import mannwhitneyu
     R = gold("reference_runs.npz")
     lnZ, prob, fpp, rp = runs(case)
     ref_lnZ, ref_fpp, ref_rp = R[case + "_lnZ"], R[case + "_FPP"], R[case + "_Rp"]
     cols = [anchors.SCENARIOS.index(s) for s in ("TP", "PTP", "STP")]
-    stats = {}
+    pv = {}
     for j, name in zip(range(3), ("lnZ TP", "lnZ PTP", "lnZ STP")):
-        a, b = lnZ[:, cols[j]], ref_lnZ[:, j]
-        stats[name] = welch(a.mean(), a.std(ddof=1), a.size, b.mean(), b.std(ddof=1), b.size)
-    a, b = np.log(fpp), np.log(ref_fpp)
-    stats["ln FPP"] = welch(a.mean(), a.std(ddof=1), a.size, b.mean(), b.std(ddof=1), b.size)
-    stats["R_p"] = welch(rp.mean(), rp.std(ddof=1), rp.size, ref_rp.mean(), ref_rp.std(ddof=1), ref_rp.size)
-    print("\n%s vs %d runs of the reference code: %s; FPP ours %.5f (median %.5f), reference %.5f"
-          % (case, ref_fpp.size, {k: round(float(v), 2) for k, v in stats.items()}, fpp.mean(), np.median(fpp), ref_fpp.mean()))
-    assert all(abs(v) < 3.0 for v in stats.values()), stats
+        pv[name] = mannwhitneyu(lnZ[:, cols[j]], ref_lnZ[:, j], alternative="two-sided").pvalue
+    pv["FPP"] = mannwhitneyu(fpp, ref_fpp, alternative="two-sided").pvalue
+    pv["R_p"] = mannwhitneyu(rp, ref_rp, alternative="two-sided").pvalue
+    print("\n%s vs %d runs of the reference code, Mann-Whitney p: %s; FPP ours %.5f (median %.5f), reference %.5f (median %.5f)"
+          % (case, ref_fpp.size, {k: round(float(v), 3) for k, v in pv.items()}, fpp.mean(), np.median(fpp),
+             ref_fpp.mean(), np.median(ref_fpp)))
+    assert all(v > 0.002 for v in pv.values()), pv
+
+
+def test_numpy_mode_replays_a_run_of_the_reference_code_at_full_size():
+    """set_sampling("numpy") consumes numpy's global stream exactly as the reference does, so seed 1000 of
+    reference_runs.npz (TOI-465.01 without contrast curve, N = 1e6, the reference's calc_probs on the CPU with
+    the oracle behind pytransit's seam) must come out again on the GPU: lnZ to the 1e-3 the run was logged
+    with, FPP and the TP radius to the digits logged."""
+    R = gold("reference_runs.npz")
+    assert int(R["toi465_nocc_seed"][0]) == 1000 and int(R["toi465_nocc_N"][0]) == 1_000_000
+    lnZ, prob, fpp, rp = anchors.run("toi465_nocc", 1000, sampling="numpy")
+    cols = [anchors.SCENARIOS.index(s) for s in ("TP", "PTP", "STP")]
+    print("\nnumpy mode, seed 1000: lnZ %s FPP %.5f R_p %.3f; reference run: lnZ %s FPP %.5f R_p %.3f"
+          % (lnZ[cols], fpp, rp, R["toi465_nocc_lnZ"][0], R["toi465_nocc_FPP"][0], R["toi465_nocc_Rp"][0]))
+    assert np.allclose(lnZ[cols], R["toi465_nocc_lnZ"][0], rtol=0, atol=2e-3)
+    assert abs(fpp - R["toi465_nocc_FPP"][0]) < 2e-5 and abs(rp - R["toi465_nocc_Rp"][0]) < 2e-3
