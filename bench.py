@@ -29,12 +29,18 @@ One JSON line on rank 0 (contract in the task statement) with these extra object
                (all_subexposures).  traffic = HBM bytes per launch from rocprofv3 PMC passes
                (FETCH_SIZE / WRITE_SIZE, separate passes) collected by this run in child processes.
   kernels      the two HBM-bound reductions (chi^2 over a materialised grid, log-mean-exp).
-  cpu_baseline the CPU oracle (a port: the reference's pytransit engine is not installable) on a
-               bounded sample of the same rows: all host cores (value), single thread, and the
-               reference-shaped numpy pipeline over a materialised (n, n_time) grid.
+  shapes       the same 18 families on the reference's REAL operating points, each with its own census
+               and fraction: 100 and 200 binned points (batched variant of the kernel) and an irregular
+               2000-point grid (every stamp jittered: no centre-value stencil) -- config.representative
+               names the irregular figure; the headline workload is BASELINE's uniform grid.
+  cpu_baseline the CPU oracle (a port: the reference's pytransit engine is not installable), compiled on
+               this box with -O3 -march=native, on a bounded sample of the same rows: all usable host cores
+               (value; affinity mask and cgroup quota stated), single thread, the same with the GPU kernels'
+               transit-window early-out (like for like with the GPU's algorithm), and the reference-shaped
+               numpy pipeline over a materialised (n, n_time) grid.
   e2e          end-to-end calc_probs() wall-clock (the second half of the BASELINE metric) on
                TOI-465.01 (BASELINE configs[2]: real light curve + contrast curve, 1 + 20 stars,
-               75 scenarios, N = 1e6) in the three sampling modes.
+               75 scenarios, N = 1e6): the default sampling mode (device) first, then the validation modes.
 """
 import argparse
 import csv
@@ -74,8 +80,8 @@ def parse():
     ap.add_argument("--tois", type=int, default=64, help="batch mode: number of synthetic TOIs")
     ap.add_argument("--batch-n", type=int, default=1_000_000, help="batch mode: Monte-Carlo draws per scenario")
     ap.add_argument("--threads", type=int, default=None,
-                    help="host threads (one HIP stream each) evaluating scenarios side by side: batch mode "
-                         "(default 6) and the threaded e2e leg (default 4)")
+                    help="host threads evaluating scenarios side by side (default 1: one thread already deals the "
+                         "calls to sharding.streams HIP streams and waits once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each of the three CPU legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel, census and e2e legs")
@@ -122,6 +128,8 @@ def collect_pmc(args):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None          # this process is itself being profiled: no nested profiler runs
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
              "--no-extras", "--pmc", "off", "--n-samples", str(args.n_samples), "--n-time", str(args.n_time)]
     if args.fp32_model:
@@ -312,6 +320,54 @@ def hbm_kernels(ctx, f_d, n_time):
     return kernels
 
 
+def shapes_leg(ctx, rows_d, fams, reps=2):
+    """The 18 families at the reference's real operating points (the same parameter rows; the timed workload
+    above is BASELINE's uniform 2000-point grid): 100 and 200 binned points, and 2000 irregular stamps."""
+    import torch
+    from triceratops_amd import _lib, synth
+    device, n_rows = ctx["device"], rows_d[0].shape[1]
+    rng = np.random.default_rng(synth.SEED + 77)
+    out = {}
+    h = torch.empty(n_rows, dtype=torch.float64, device=device)
+    for key, n_time, jitter in (("n100", 100, False), ("n200", 200, False), ("n2000_irregular", 2000, True)):
+        t = synth.time_grid(n_time)
+        if jitter:      # every stamp moved by up to +-0.3 of the spacing (a folded light curve is not a linspace)
+            t = np.sort(t + rng.uniform(-0.3, 0.3, n_time) * (t[1] - t[0]))
+        t_d = _lib.dev(t, device)
+        curve, _ = _lib.flux_grid(_lib.MODEL_TP, 0, t_d, _lib.dev(synth.reference_tp_row(), device), synth.EXPTIME,
+                                  synth.NSAMPLES, False)
+        f_d = _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy()), device)
+
+        def one_pass(evs=None):
+            for i, (name, model, is_host, has_comp) in enumerate(fams):
+                flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if ctx["args"].fp32_model else 0)
+                if evs is not None:
+                    evs[i][0].record()
+                _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME, synth.NSAMPLES, out=h)
+                if evs is not None:
+                    evs[i][1].record()
+
+        one_pass()
+        torch.cuda.synchronize(device)
+        ms = []
+        for _ in range(reps):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in fams]
+            one_pass(evs)
+            torch.cuda.synchronize(device)
+            ms.append(np.mean([a.elapsed_time(b) for a, b in evs]))
+        launch_s = float(np.min(ms)) * 1e-3
+        evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d)
+        cells = float(n_time) * n_rows
+        tf = evals_per_cell * (F_ORBIT + F_MA) * cells / launch_s / 1e12
+        out[key] = {"n_time": n_time, "rows_per_family": n_rows, "uniform_grid": not jitter,
+                    "kernel": "cells_kernel<lnl, %s>" % ("batches of rows per wave" if n_time < 320 else
+                                                         "one row per wave, Gauss nodes (irregular stamps: no stencil)"),
+                    "mean_launch_ms": launch_s * 1e3, "evals_per_s": cells / launch_s,
+                    "model_evaluations_per_cell": evals_per_cell, "p_in": p_in,
+                    "achieved_tflops": tf, "frac": tf / FP64_VALU_PEAK_TF}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 def run_grid(ctx):
     import torch
@@ -396,11 +452,12 @@ def run_grid(ctx):
     roof = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "mean_launch_ms": mean_launch_s * 1e3, "cells_per_launch": cells_per_launch,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            # the row constants' round trip between rowc_kernel and cells_kernel (144 B per row written and
+            # the row constants' round trip between rowc_kernel and cells_kernel (160 B per row written and
             # read once): design traffic on top of the algorithmic bytes, counted in `traffic`
-            "scratch_round_trip_bytes_per_launch": 2.0 * 144.0 * n_rows,
+            "scratch_round_trip_bytes_per_launch": 2.0 * 160.0 * n_rows,
             "hbm_GBps_algorithmic": alg_bytes_per_launch / mean_launch_s / 1e9}
     kernels = {}
+    shapes = None
     if ctx["extras"]:
         evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d)
         flop_exec = evals_per_cell * (F_ORBIT + F_MA)
@@ -457,6 +514,7 @@ def run_grid(ctx):
                                    "wave_instructions_per_launch": {k: tr["issued"][k] for k in
                                                                     ("fma_f64", "mul_f64", "add_f64", "trans_f64")}}
         kernels = hbm_kernels(ctx, f_d, n_time)
+        shapes = shapes_leg(ctx, rows_d, fams)
     else:
         # no census in this run: price every cell at ONE model evaluation (a lower bound of the executed work)
         achieved = (F_ORBIT + F_MA) * cells_per_launch / mean_launch_s / 1e12
@@ -491,8 +549,12 @@ def run_grid(ctx):
                    "n_time": n_time, "n_samples": n_rows, "n_scenarios": len(fams),
                    "evals_per_step_per_gpu": evals_per_step_per_gpu,
                    "all_subexposures": bool(args.all_subexposures),
+                   "representative": "shapes.n2000_irregular (2000 irregular stamps: what a folded, unbinned light "
+                                     "curve looks like) and shapes.n100 / n200 (the reference's binned operating "
+                                     "point); `value` is BASELINE configs[1]'s uniform grid, on which the "
+                                     "centre-value stencil applies",
                    "parallelism": "scenario-sharded x%d, one all_gather of lnZ" % world},
-        "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "e2e": e2e,
+        "roofline": roof, "shapes": shapes, "kernels": kernels, "cpu_baseline": cpu, "e2e": e2e,
         "lnZ_checksum": float(np.nansum(lnz_host[np.isfinite(lnz_host)])),
     }
 
@@ -506,7 +568,7 @@ def run_batch(ctx):
     args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
     triceratops_amd.set_sampling("device")
     if args.threads is None:
-        args.threads = 6
+        args.threads = 1          # one host thread deals the calls to sharding.streams HIP streams and waits once
     triceratops_amd.set_threads(args.threads)
     if args.fp32_model:
         triceratops_amd.set_precision("fp32")
@@ -587,7 +649,7 @@ def run_batch(ctx):
         "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
-                               "light curves, calc_probs_many with device-side sampling, %d host threads per rank; "
+                               "light curves, calc_probs_many with device-side sampling, %d host thread(s) per rank, every lnZ_* call enqueued without a host sync on one of 3 streams; "
                                "value counts the (draw, time) cells that pass the geometry mask and are evaluated (the draws that lnL_EB_p's secondary-eclipse rule excludes are not: rows_not_evaluated_per_step)"
                                % (args.tois, args.batch_n, args.n_time, args.threads),
                    "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
@@ -634,7 +696,7 @@ def e2e_calc_probs(threads=3):
                        "synthetic TRILEGAL table; reference notebook (unstated laptop): ~61 s per 15-scenario run",
            "seconds": {}, "FPP": {}}
     for tag, modes in (("blend", ("device", "device-threads", "numpy-device", "numpy")),
-                       ("real", ("device", "device-threads", "numpy-device"))):
+                       ("real", ("device", "numpy-device"))):
         st = pd.DataFrame({c: g["%s_stars_%s" % (tag, c)] for c in cols})
         st["ID"] = st["ID"].astype(np.int64)
         for mode in modes:
@@ -664,20 +726,62 @@ def e2e_calc_probs(threads=3):
                 res["seconds"][key] = best
                 res["FPP"][key] = float(tg.FPP)
             finally:
-                triceratops_amd.set_sampling("numpy")
+                triceratops_amd.set_sampling("device")
                 triceratops_amd.set_threads(1)
     res["threads"] = threads
+    res["default_mode"] = "device (one host thread, calls enqueued on %d streams, one wait)" % __import__(
+        "triceratops_amd.sharding", fromlist=["streams"]).streams
     return res
 
 
+def usable_cores():
+    """(cores this process may use, how that was found): the affinity mask capped by the cgroup CPU quota --
+    omp_get_max_threads() counts the machine's cores, which a container does not own"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return n, {"sched_getaffinity": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count()}
+
+
+def native_oracle():
+    """the oracle compiled on THIS box with -O3 -march=native; falls back to the shipped
+    -O2 build when there is no compiler"""
+    from oracle import oracle as O
+    src = os.path.join(ROOT, "oracle", "trx_oracle.c")
+    out = os.path.join(tempfile.mkdtemp(prefix="trx_oracle_", dir="/tmp"), "libtrx_oracle_native.so")
+    cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+           "-shared", "-o", out, src, "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        O.use_library(out)
+        return "gcc -O3 -march=native -fopenmp, built on this box"
+    except Exception:
+        return "shipped build (gcc -O2 -fopenmp): no compiler on this box"
+
+
 def cpu_baseline(t, flux, rows_h, fams, budget_s):
-    """The CPU oracle on a bounded sample of the same rows: all host cores (OpenMP over rows), one
-    thread, and the reference-shaped numpy pipeline (materialised (n, n_time) grid + the elementwise
-    passes and row sum of likelihoods.py:352-357, 427-438, 486, 534-538) around the oracle's
-    pytransit-shaped evaluate_pv."""
+    """The CPU oracle on a bounded sample of the same rows: all usable host cores (OpenMP over rows), one
+    thread, the same two with the GPU kernels' transit-window early-out, and the reference-shaped numpy pipeline
+    (materialised (n, n_time) grid + the elementwise passes and row sum of likelihoods.py:352-357, 427-438, 486,
+    534-538) around the oracle's pytransit-shaped evaluate_pv."""
     from oracle import oracle as O
     from triceratops_amd import synth
-    cores = O.num_threads()
+    build = native_oracle()
+    cores, how = usable_cores()
+    omp_default = O.num_threads()
 
     def leg(run, n_threads, what):
         O.set_num_threads(n_threads)
@@ -743,14 +847,30 @@ def cpu_baseline(t, flux, rows_h, fams, budget_s):
         return h
 
     try:
-        allc = leg(fused, cores, "fused C restatement, OpenMP over rows on all cores")
+        allc = leg(fused, cores, "fused C restatement, OpenMP over rows on all usable cores")
         one = leg(fused, 1, "fused C restatement, one thread")
+        O.set_window_skip(1)
+        try:
+            win = leg(fused, cores, "fused C restatement + the GPU kernels' transit-window early-out, all usable cores")
+            win1 = leg(fused, 1, "fused C restatement + transit-window early-out, one thread")
+        finally:
+            O.set_window_skip(0)
         grid = leg(numpy_grid, cores, "numpy materialised-grid pipeline of the reference around the oracle's "
-                                      "evaluate_pv, model on all cores, numpy passes on one")
+                                      "evaluate_pv, model on all usable cores, numpy passes on one")
     finally:
-        O.set_num_threads(cores)
+        O.set_num_threads(omp_default)
     allc["single_thread"] = one
+    allc["window_early_out"] = win
+    allc["window_early_out_single_thread"] = win1
     allc["numpy_grid"] = grid
+    allc["build"] = build
+    allc["cores_detail"] = dict(how, omp_get_max_threads=omp_default, used=cores,
+                                scaling_all_over_one=allc["value"] / one["value"])
+    allc["note"] = ("a port (the reference's pytransit engine cannot be installed): every sub-exposure of every point "
+                    "with a full Kepler solve, like the reference; window_early_out adds the one shortcut of the GPU "
+                    "kernels that a CPU implementation would take as well.  cores = affinity mask capped by the cgroup "
+                    "quota; round 2 ran omp_get_max_threads() = every core of the machine inside a smaller quota, "
+                    "hence its 13x 'scaling' on 128 threads")
     return allc
 
 

@@ -17,6 +17,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtrx_oracle.so")
 
+
+def use_library(path):
+    """load another build of trx_oracle.c from now on (bench.py's cpu_baseline compiles one with
+    -O3 -march=native on the box it runs on)"""
+    global _SO, _lib
+    _SO, _lib = path, None
+
 MODEL_TP, MODEL_EB, MODEL_EB_TWIN = 0, 1, 2
 FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K = 1, 2
 N_PARAM = {MODEL_TP: 10, MODEL_EB: 11, MODEL_EB_TWIN: 11}
@@ -62,6 +69,8 @@ def lib():
         L.trxo_normalize_probabilities.argtypes = [_dp, ctypes.c_int, _dp]
         L.trxo_num_threads.restype = ctypes.c_int
         L.trxo_set_num_threads.argtypes = [ctypes.c_int]
+        L.trxo_set_window_skip.argtypes = [ctypes.c_int]
+        L.trxo_set_window_skip.restype = None
         _lib = L
     return _lib
 
@@ -155,6 +164,12 @@ def normalize_probabilities(lnZ):
 
 def num_threads():
     return lib().trxo_num_threads()
+
+
+def set_window_skip(on):
+    """bench.py's cpu_baseline only: exposures outside the transit window return 1 without an orbit solve (the
+    GPU kernels' early-out); the plain restatement (default) evaluates every point like the reference"""
+    lib().trxo_set_window_skip(int(bool(on)))
 
 
 def set_num_threads(n):

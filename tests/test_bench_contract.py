@@ -53,7 +53,19 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "evals/s" and c["sample"]
     assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
     assert c["numpy_grid"]["value"] > 0
+    # the honest CPU leg: usable cores (affinity mask capped by the cgroup quota), built on this box, and the
+    # same restatement with the GPU kernels' transit-window early-out
+    assert c["cores"] == c["cores_detail"]["used"] <= c["cores_detail"]["sched_getaffinity"]
+    assert "march=native" in c["build"] or "shipped" in c["build"]
+    assert c["window_early_out"]["value"] > c["value"] and c["window_early_out_single_thread"]["cores"] == 1
     assert d["value"] > 50 * c["value"]
+    # the reference's real operating points ride in the same line, each with its own census and fraction
+    assert "representative" in d["config"]
+    for key, n_time in (("n100", 100), ("n200", 200), ("n2000_irregular", 2000)):
+        sh = d["shapes"][key]
+        assert sh["n_time"] == n_time and sh["evals_per_s"] > 0 and 0 < sh["frac"] < 1
+        assert 1.0 < sh["model_evaluations_per_cell"] < 20.0
+    assert d["shapes"]["n2000_irregular"]["uniform_grid"] is False
     r = d["roofline"]
     # executed work is priced below the plain 20-sub-exposure equivalent, and the run with the
     # shortcut off (timed in the same process) is slower than the default one
