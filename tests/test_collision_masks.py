@@ -28,7 +28,7 @@ def _branches(path, radius_eb, P_orb, N=64):
         return ml._binary_branches(g["time"], g["flux"], float(g["sigma"][0]), N, True, 0.00139, 20,
                                    *cols, *tail)
     import torch
-    from triceratops_amd import device_pipeline as dp
+    import torch_pipeline as dp
     ctx = dp._ctx(g["time"], g["flux"], float(g["sigma"][0]), N, 0.00139, 20)
     return dp._binary_branches(ctx, *(torch.as_tensor(c) for c in cols), *tail)
 

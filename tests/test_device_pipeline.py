@@ -1,4 +1,5 @@
-"""Device-resident scenario pipeline (triceratops_amd/device_pipeline.py).
+"""The torch expression of the device-resident scenario pipeline (tests/torch_pipeline.py: round 1's device
+path, now the cross-check of the fused draw kernel).
 
 Its samplers, relations and priors are deterministic functions of the uniforms, so they are
 checked value for value against the host path (itself bit-identical to the reference).  The whole
@@ -15,7 +16,8 @@ import pytest
 import torch
 
 from helpers import GOLD, gold, install_cpu_device_fakes
-from triceratops_amd import device_pipeline as dp
+import torch_pipeline as dp
+from triceratops_amd import device_pipeline as prod
 from triceratops_amd import funcs, priors
 
 CPU = torch.device("cpu")
@@ -93,7 +95,7 @@ def test_device_pipeline_reproduces_reference_when_fed_the_numpy_stream(case, mo
     install_cpu_device_fakes(monkeypatch)
     from triceratops_amd import _lib
     monkeypatch.setattr(_lib, "compute_device", lambda: CPU)
-    monkeypatch.setattr(dp, "RNG", NumpyStreamRng())
+    monkeypatch.setattr(prod, "RNG", NumpyStreamRng())
     name, variant = case.split("_")
     P = [2.5, 4.0] if variant == "range" else 3.3
     cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
@@ -125,21 +127,19 @@ def test_sampling_switch(monkeypatch):
     from triceratops_amd import marginal_likelihoods as ml
     from triceratops_amd import fused
     calls = []
-    monkeypatch.setattr(dp, "lnZ_TTP", lambda *a, **k: calls.append(a) or {"lnZ": 0.0})
     monkeypatch.setattr(fused, "lnZ_TTP", lambda *a, **k: calls.append(a) or {"lnZ": 0.0})
-    assert dp.FUSED is True                  # the fused per-draw kernel is the default device path
     triceratops_amd.set_sampling("device")
     try:
+        assert isinstance(prod.RNG, prod.TorchRng)
         assert ml.lnZ_TTP(1, 2, 3)["lnZ"] == 0.0 and calls
     finally:
         triceratops_amd.set_sampling("numpy")
-    with pytest.raises(ValueError):
-        triceratops_amd.set_sampling("cuda")
-    # numpy-device: the numpy stream feeds the device pipeline; per-draw-loop calls stay on the host
+    n0 = len(calls)
     triceratops_amd.set_sampling("numpy-device")
     try:
-        assert isinstance(dp.RNG, dp.NumpyStreamRng)
-        n0 = len(calls)
+        assert isinstance(prod.RNG, prod.NumpyStreamRng)
         assert ml.lnZ_TTP(1, 2, 3, 4, 5, 6, 7, 8, 100, True)["lnZ"] == 0.0 and len(calls) == n0 + 1
     finally:
         triceratops_amd.set_sampling("numpy")
+    with pytest.raises(ValueError):
+        triceratops_amd.set_sampling("gpu")

@@ -1,5 +1,5 @@
 """The fused per-draw kernel (trx_draw_scenario, triceratops_amd/fused.py) against the elementwise
-torch expression of the same chain (device_pipeline.py, itself pinned to the reference's goldens):
+torch expression of the same chain (tests/torch_pipeline.py, itself pinned to the reference's goldens):
 the same staged random numbers through both must give the same masks, columns, priors and
 therefore lnZ and best-fit tables -- for all ten scenarios, with and without a contrast curve,
 fixed period and period range, vector-path and per-draw-loop semantics, MOLUSC table."""
@@ -35,19 +35,19 @@ def _call(ml, name, P, N, parallel, cc, filt, star=(0.82, 0.8, 5100.0), molusc=N
 
 
 def _both(name, mode, seed, **kw):
+    """the product's fused kernel (through the lnZ_* dispatch) and the torch expression of the same chain
+    (tests/torch_pipeline.py) on the same random-number source"""
+    import torch_pipeline
     import triceratops_amd
-    from triceratops_amd import device_pipeline as dp
     from triceratops_amd import marginal_likelihoods as ml
     out = {}
     triceratops_amd.set_sampling(mode)
     try:
         for fused in (True, False):
-            dp.FUSED = fused
             np.random.seed(seed)
             torch.manual_seed(seed)
-            out[fused] = _call(ml, name, **kw)
+            out[fused] = _call(ml if fused else torch_pipeline, name, **kw)
     finally:
-        dp.FUSED = True
         triceratops_amd.set_sampling("numpy")
     return out[True], out[False]
 
@@ -105,18 +105,16 @@ def test_fused_kernel_equals_torch_pipeline_on_the_device_generator(name):
 def test_missing_limb_darkening_cell_raises_like_the_reference():
     """SEB draws companions up to 13000 K but the Claret grid stops at 10000 K: a hot target makes
     the reference's `.item()` on the empty match raise ValueError; so do both device paths"""
+    import torch_pipeline
     import triceratops_amd
-    from triceratops_amd import device_pipeline as dp
     from triceratops_amd import marginal_likelihoods as ml
     triceratops_amd.set_sampling("device")
     try:
-        for fused in (True, False):
-            dp.FUSED = fused
+        for mod in (ml, torch_pipeline):
             torch.manual_seed(3)
             with pytest.raises(ValueError):
-                _call(ml, "SEB", 3.3, 20000, True, None, "TESS", star=(4.0, 2.9, 14000.0))
+                _call(mod, "SEB", 3.3, 20000, True, None, "TESS", star=(4.0, 2.9, 14000.0))
     finally:
-        dp.FUSED = True
         triceratops_amd.set_sampling("numpy")
 
 

@@ -700,7 +700,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             // With the centre-value stencil the chunks of the first sweep overlap by 2 kStM cells: a
             // chunk finalises its lanes [lo, hi) and only lends the centre values of the kStM lanes on
             // either side, so the cells at a chunk's edges find their neighbours in the next one.
-            const bool halo = ST && sweep == 0;
+            // (a launch sent here by a stale memo -- the address now holds a light curve without a uniform grid --
+            // finds radius 0 and walks the list exactly like the instantiation without the stencil: same chunks,
+            // same summation order)
+            const bool halo = ST && sweep == 0 && st_radius > 0.0;
             int carry_rel = 0;
             for (int w0 = 0, step = 64; w0 < count; w0 += step) {
                 TRX_TICK(t_plan);

@@ -124,27 +124,3 @@ def trilegal_results(trilegal_fname: str, Tmag: float):
     keep = Tmags >= Tmag
     return (Tmags[keep], cols["Masses"][keep], cols["loggs"][keep], cols["Teffs"][keep],
             cols["Zs"][keep], cols["Jmags"][keep], cols["Hmags"][keep], cols["Kmags"][keep])
-
-
-def color_Teff_relations(V, Ks):
-    """Effective temperature [K] from the V - Ks colour: a quadratic in the colour below 5.05 mag,
-    a cubic plus 205.26 K above (funcs.py:143-161).  Like the reference, a colour of exactly
-    5.05 falls in neither branch and raises UnboundLocalError."""
-    c = V - Ks
-    if c < 5.05:
-        Teff = 5040 / (0.54042 + 0.23676 * c - 0.00796 * c ** 2)
-    elif c > 5.05:
-        Teff = 5040 / (-0.4809 + 0.8009 * c - 0.1039 * c ** 2 + 0.0056 * c ** 3) + 205.26
-    return Teff
-
-
-def Gauss2D(x, y, mu_x, mu_y, sigma, A):
-    """Circular Gaussian of area A centred on (mu_x, mu_y): a float for scalar x, y, else the
-    (len(y), len(x)) grid over the two axes (funcs.py:180-200).  calc_depths integrates this
-    profile over pixels in closed form (ndtr differences) and does not call it."""
-    norm = A / (2 * np.pi * sigma ** 2)
-    if np.ndim(x) == 0 and np.ndim(y) == 0:
-        return float(norm * np.exp(-((float(x) - mu_x) ** 2 + (float(y) - mu_y) ** 2) / (2 * sigma ** 2)))
-    gx = np.exp(-(np.asarray(x, dtype=float) - mu_x) ** 2 / (2 * sigma ** 2))
-    gy = np.exp(-(np.asarray(y, dtype=float) - mu_y) ** 2 / (2 * sigma ** 2))
-    return norm * np.outer(gy, gx)

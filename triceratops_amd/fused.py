@@ -1,6 +1,6 @@
 """The ten lnZ_* of calc_probs on the fused per-draw kernel (trx_draw_scenario, include/trx.h).
 
-device_pipeline.py expresses a scenario as ~350 elementwise torch launches (samplers, splines,
+tests/torch_pipeline.py (round 1's device path) expresses a scenario as ~350 elementwise torch launches (samplers, splines,
 priors, masks); here the whole draw -> derive -> mask -> prior chain of a scenario is ONE HIP
 kernel over the N draws, fed with staged random numbers in the reference's draw order (the RNG
 classes of device_pipeline: torch's device generator, or numpy's global stream), followed by the
@@ -203,7 +203,7 @@ def _fn():
 # ---------------------------------------------------------------------------------------
 # host constants
 def _law(edges, powers, amps_int, amps_inv):
-    """constants of device_pipeline._invert, same Python-float arithmetic"""
+    """constants of tests/torch_pipeline._invert, same Python-float arithmetic"""
     law = PowerLaw()
     ints = []
     for j, p in enumerate(powers):
@@ -235,7 +235,7 @@ def _rp_laws():
 
 
 def _q_law(M_s, p_hi, F_twin):
-    """device_pipeline._mass_ratio (priors.py:168-383)"""
+    """tests/torch_pipeline._mass_ratio (priors.py:168-383)"""
     if M_s <= 0.1:
         law = PowerLaw()
         law.ones = 1
@@ -283,7 +283,7 @@ def _spline_table(device, band):
 
 
 def _flux0(M_s, band):
-    """flux_relation(M_s) as device_pipeline._flux_share forms it"""
+    """flux_relation(M_s) as tests/torch_pipeline._flux_share forms it"""
     return float(10 ** funcs._flux_spl[band](np.array([M_s]))[0])
 
 
@@ -324,7 +324,7 @@ def _companion_lut(mission, Z, teff_cap, device):
 
 
 def _bound_constants(a, M_s, plx):
-    """constants of device_pipeline._bound_rate (priors.py:601-660)"""
+    """constants of tests/torch_pipeline._bound_rate (priors.py:601-660)"""
     if np.isnan(plx):
         plx = 0.1
     M_ref = M_s if M_s >= 1.0 else 1.0
@@ -592,7 +592,7 @@ class _Scenario:
         return pend.result()
 
     def _best(self, h, idx, n):
-        """indices of the N_BEST best draws (see device_pipeline._evidence for the tie rules)"""
+        """indices of the N_BEST best draws (see tests/torch_pipeline._evidence for the tie rules)"""
         dev, N = self.dev, self.N
         if not isinstance(dp.RNG, dp.NumpyStreamRng):
             rows = TABLE_ROWS

@@ -729,13 +729,9 @@ def _dispatch(fn):
     def wrapper(*args, **kwargs):
         mode = _sampling["mode"]
         if mode != "numpy":
-            # one fused HIP kernel per scenario (fused.py); device_pipeline.FUSED = False selects the
-            # elementwise torch expression of the same chain (kept as the cross-check of the kernel)
-            from . import device_pipeline
-            if device_pipeline.FUSED:
-                from . import fused
-                return getattr(fused, fn.__name__)(*args, **kwargs)
-            return getattr(device_pipeline, fn.__name__)(*args, **kwargs)
+            # one fused HIP kernel per scenario (fused.py)
+            from . import fused
+            return getattr(fused, fn.__name__)(*args, **kwargs)
         return fn(*args, **kwargs)
     return wrapper
 

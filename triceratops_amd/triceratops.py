@@ -6,12 +6,12 @@ Mirrors the compute half of triceratops/triceratops.py `class target`:
 with the same argument lists and the same result attributes (.probs .lnZ .FPP .NFPP
 .FPP_degenerate .star_num .u1 .u2 .fluxratio_EB .fluxratio_comp).
 
-and the caller-side helpers around it:
-  add_star / remove_star / update_star (triceratops.py:265-335)   edits of the .stars table
-  fit_curves, plot_fits (triceratops.py:1487-1638)   best-fit model light curve per scenario
+and the data half of plot_fits:
+  fit_curves (triceratops.py:1502-1597)   best-fit model light curve per scenario
 
-Out of scope (SURVEY.md section 2 rows 12, 14): the catalogue / cut-out / TRILEGAL web queries of
-__init__ and plot_field.  A `target` here is built from a ready star table (and, for
+Out of scope (SURVEY.md section 2 rows 10, 12, 14): the catalogue / cut-out / TRILEGAL web queries of
+__init__, plot_field, the matplotlib figure of plot_fits and the star-table edits (plain pandas: edit
+`target.stars` directly).  A `target` here is built from a ready star table (and, for
 calc_depths, pixel coordinates); the TRILEGAL population is a local csv (`trilegal_fname`).
 
 With torch.distributed initialised (one process per GPU, RCCL) calc_probs shards the
@@ -21,7 +21,7 @@ results; see triceratops_amd/sharding.py.
 import warnings
 
 import numpy as np
-from pandas import DataFrame, concat
+from pandas import DataFrame
 from scipy.special import ndtr
 
 from . import _lib
@@ -71,34 +71,6 @@ class target:
         self.trilegal_url = None
         self.stars = stars.reset_index(drop=True)
         self.pix_coords = pix_coords
-
-    # -----------------------------------------------------------------------------------
-    def add_star(self, ID: int, Tmag: float, bound: bool):
-        """Append a star found by follow-up (e.g. an unresolved companion) to .stars.  A bound
-        star inherits the target's parallax; every other column is NaN.  Its pixel position in
-        each sector is the target's."""
-        row = {"ID": str(ID), "Tmag": Tmag}
-        if bound:
-            row["plx"] = self.stars["plx"].values[0]
-        self.stars = concat([self.stars, DataFrame([row])]).reset_index(drop=True)
-        if self.pix_coords is not None:
-            self.pix_coords = [np.vstack([np.asarray(c), np.asarray(c)[:1]])
-                               for c in self.pix_coords]
-        return
-
-    def remove_star(self, drop_stars):
-        """Drop stars (scalar ID or sequence of IDs) that were ruled out as NTP/NEB hosts.  Like
-        the reference this keeps the surviving rows' index labels and does not touch pix_coords."""
-        ids = [drop_stars] if np.isscalar(drop_stars) else list(drop_stars)
-        gone = self.stars["ID"].astype(str).isin([str(s) for s in ids])
-        self.stars = self.stars[~gone]
-        return
-
-    def update_star(self, ID: int, param: str, value: float):
-        """Set column `param` of star `ID` to `value`."""
-        hit = self.stars["ID"].astype(str) == str(ID)
-        self.stars.loc[hit, [param]] = value
-        return
 
     # -----------------------------------------------------------------------------------
     def calc_depths(self, tdepth: float, all_ap_pixels=None):
@@ -334,35 +306,6 @@ class target:
             curves.append({"ID": df["ID"].values[k], "scenario": df["scenario"].values[k],
                            "flux": flux, "flux_err": flux_err, "model": models[k]})
         return model_time, curves
-
-    def plot_fits(self, time, flux_0, flux_err_0: float, save: bool = False, fname: str = None):
-        """One panel per scenario (rows of three: TP, EB, EBx2P of a star) with the renormalised
-        data and the best-fit model of fit_curves.  save=False shows the figure; save=True writes
-        `fname`.pdf, or TIC<target>_fits.pdf without a name (as the reference)."""
-        import matplotlib.pyplot as plt
-        from matplotlib import ticker
-        model_time, curves = self.fit_curves(time, flux_0, flux_err_0)
-        n_rows = len(curves) // 3
-        f, ax = plt.subplots(n_rows, 3, figsize=(12, n_rows * 4), sharex=True, squeeze=False)
-        for k, c in enumerate(curves[:3 * n_rows]):
-            p = ax[k // 3, k % 3]
-            p.yaxis.set_major_formatter(ticker.ScalarFormatter(useOffset=False))
-            p.errorbar(time, c["flux"], c["flux_err"], fmt=".", color="blue", alpha=0.25, zorder=0,
-                       rasterized=True)
-            p.plot(model_time, c["model"], "k-", lw=3, zorder=2)
-            p.set_ylabel("normalized flux", fontsize=12)
-            p.annotate(str(c["ID"]), xy=(0.05, 0.92), xycoords="axes fraction", fontsize=12)
-            p.annotate(str(c["scenario"]), xy=(0.05, 0.05), xycoords="axes fraction", fontsize=12)
-        for j in range(3):
-            ax[n_rows - 1, j].set_xlabel("days from transit center", fontsize=12)
-        plt.tight_layout()
-        if save is False:
-            plt.show()
-        elif fname is None:
-            plt.savefig("TIC" + str(self.stars.ID.values[0]) + "_fits.pdf")
-        else:
-            plt.savefig(fname + ".pdf")
-        return f
 
 
 def calc_probs_many(jobs, verbose: int = 0):
