@@ -304,7 +304,7 @@ def _evidence(model, is_host, time_d, flux_d, sigma, cols, mask, lnprior, N, exp
     # more than N_BEST finite, distinct values is the top-k's, but few surviving draws, or the
     # equal chi^2 of draws whose model is flat over the data window, come out in whatever order
     # the reference's (-lnL).argsort() gives the ties -- so that very call is made on the host.
-    if not isinstance(RNG, NumpyStreamRng):
+    if not isinstance(_prod.RNG, NumpyStreamRng):
         k = min(N_BEST, n)
         best = idx[torch.topk(h, k, largest=False, sorted=True).indices] if k else idx
         if k < N_BEST:
