@@ -13,7 +13,9 @@ python profiles/short_curves.py 100000 > $O/${T}_short_curves.txt 2>&1
 python profiles/cells_batch_sweep.py 100000 50 100 200 > $O/${T}_cells_batch_sweep.txt 2>&1
 python profiles/cells_batch_sweep.py 30000 100 >> $O/${T}_cells_batch_sweep.txt 2>&1
 python profiles/cells_batch_sweep.py 300000 100 >> $O/${T}_cells_batch_sweep.txt 2>&1
-python profiles/e2e_threads.py > $O/${T}_e2e_threads.txt 2>&1
+python profiles/e2e_streams.py > $O/${T}_e2e_streams.txt 2>&1
+python profiles/bounded_e2e.py > $O/${T}_bounded_e2e.txt 2>&1
+python profiles/prune_potential.py > $O/${T}_prune_potential.txt 2>&1
 python profiles/stencil_check.py 2000 3000 > $O/${T}_stencil.txt 2>&1
 bash profiles/stats_e2e.sh ${T}e2e blend > $O/${T}_e2e_kernel_stats.txt 2>&1
 bash profiles/pmc_cells.sh ${T}2000 2000 100000 rows > /dev/null 2>&1

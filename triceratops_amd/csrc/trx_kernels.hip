@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -412,9 +413,44 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
     // output of simulate_EB_transit_p; lnL_EB_twin_p (:542-587) uses neither
     if (!a.need_sec) return;
     if (lane < 64) { secmin[lane] = INFINITY; secnan[lane] = 0; }
+    // Likelihood calls only need the verdict "depth >= 1.5 sigma", and the scan's minimum can only be deeper
+    // than any one of its points: the point at the secondary conjunction (the 13th of the 25) alone settles 97 %
+    // of the draws of a typical lnZ_*EB call, the other 24 points are evaluated for the rest (and for every row
+    // when the depth itself is asked for: trx_flux_grid's out_secdepth).
+    __shared__ unsigned char undecided[64];
+    __shared__ int n_undecided;
+    const bool quick = a.out_sec == nullptr;
+#ifdef TRX_SEC_FULL_SCAN
+    const bool use_quick = false;
+#else
+    const bool use_quick = quick;
+#endif
+    if (lane == 0) n_undecided = 0;
     __syncthreads();
-    for (int it = lane; it < nb * kSecPoints; it += 256) {
-        const int r = it / kSecPoints, j = it - r * kSecPoints;
+    bool open = false;                                      // this lane's row still needs the scan
+    if (lane < 64) {
+        open = lane < nb;
+        if (open && use_quick) {
+            const RowC sc = srows[lane];
+            const Limb L{sc.cle, sc.cld, sc.ced};
+            const double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, 12.0), -0.05);       // linspace(-0.05, 0.05, 25)[12]
+            const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
+            const double m = (f + ysec) / (1.0 + ysec);
+            const double depth = 1.0 - (m + fdil) / (1.0 + fdil);
+            if (!(depth < 1.5 * a.sigma)) {                 // deep enough already (or NaN: np.min would propagate it)
+                dst[kRowDoubles - 1] = 1.0;                 // RowC::excl, :535
+                open = false;
+            }
+        }
+        const unsigned long long mo = __ballot(open);
+        if (open) undecided[lanes_below(mo)] = (unsigned char)lane;
+        if (lane == 0) n_undecided = __popcll(mo);
+    }
+    __syncthreads();
+    const int nu = n_undecided;
+    for (int it = lane; it < nu * kSecPoints; it += 256) {
+        const int ri = it / kSecPoints, j = it - ri * kSecPoints;
+        const int r = undecided[ri];
         const RowC sc = srows[r];
         const Limb L{sc.cle, sc.cld, sc.ced};
         // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
@@ -425,7 +461,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
         else __hip_atomic_fetch_min(&secmin[r], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    if (lane < nb) {
+    if (open) {
         double m = secnan[lane] ? NAN : secmin[lane];                   // np.min propagates NaN
         m = (m + ysec) / (1.0 + ysec);
         const double secdepth = 1.0 - (m + fdil) / (1.0 + fdil);
@@ -1368,7 +1404,14 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
-std::atomic<int> g_prune{1};          // bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always
+// bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always (TRX_BOUNDED in
+// the environment sets the initial value: A/B runs of whole programs)
+static int initial_prune_mode()
+{
+    const char* e = getenv("TRX_BOUNDED");
+    return (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : 1;
+}
+std::atomic<int> g_prune{initial_prune_mode()};
 std::atomic<int> g_prune_lnl{0};      // tests: trx_lnl_batch applies it too (as for an evidence without prior)
 std::atomic<int> g_skip_excluded{1};  // rows excluded by the EB secondary rule are not evaluated (likelihood calls)
 std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
