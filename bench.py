@@ -340,7 +340,8 @@ def shapes_leg(ctx, rows_d, fams, reps=2):
 
         def one_pass(evs=None):
             for i, (name, model, is_host, has_comp) in enumerate(fams):
-                flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if ctx["args"].fp32_model else 0)
+                flags = ((_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if ctx["args"].fp32_model else 0)
+                         | _lib.FLAG_EVALUATE_EXCLUDED)
                 if evs is not None:
                     evs[i][0].record()
                 _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME, synth.NSAMPLES, out=h)
@@ -373,9 +374,10 @@ def run_grid(ctx):
     import torch
     import torch.distributed as dist
     from triceratops_amd import _lib, synth
-    # every row this mode counts is evaluated: the likelihood calls do not skip the rows that lnL_EB_p's
-    # secondary-eclipse rule excludes anyway (the default, which the e2e leg below runs with)
-    _lib.lib().trx_set_skip_excluded(0)
+    # every row this mode counts is evaluated: its likelihood calls carry TRX_FLAG_EVALUATE_EXCLUDED, i.e. they
+    # do not skip the rows that lnL_EB_p's secondary-eclipse rule excludes anyway (a per-call flag: the
+    # process-wide default -- skip them -- stays in force for the e2e leg below)
+    EVAL_ALL = _lib.FLAG_EVALUATE_EXCLUDED
     args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
     if args.all_subexposures:
         _lib.lib().trx_set_supersample_tiers(0)
@@ -414,7 +416,7 @@ def run_grid(ctx):
     def step(evs=None, collective=True):
         lnz = []
         for i, (name, model, is_host, has_comp) in enumerate(fams):
-            flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0)
+            flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0) | EVAL_ALL
             if evs is not None:
                 evs[i][0].record()
             _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME,
@@ -534,7 +536,6 @@ def run_grid(ctx):
         cpu = cpu_baseline(t, flux, rows_h, fams, args.cpu_seconds)
     e2e = None
     if ctx["extras"] and not args.no_e2e and world == 1:
-        _lib.lib().trx_set_skip_excluded(1)          # the product's default
         e2e = e2e_calc_probs(args.threads or 4)
 
     return {

@@ -61,6 +61,10 @@ extern "C" {
                                         differences, fp32 Mandel-Agol arithmetic, fp64 chi^2 and
                                         log-mean-exp accumulation; ~1e-7 absolute in flux */
 
+#define TRX_FLAG_EVALUATE_EXCLUDED   8 /* trx_lnl_batch / trx_lnz_scenario: evaluate the light curve of a draw that
+                                        lnL_EB_p's secondary-eclipse rule excludes anyway (+inf either way): per-call
+                                        form of trx_set_skip_excluded(0), for benchmarks that count every row */
+
 /* parameter-block rows, SoA [n_param][n] contiguous fp64 (reference argument order):
  *   TP  (10): R_p[R_earth] P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio
  *   EB  (11): R_EB[R_sun] EB_fluxratio P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio

@@ -684,6 +684,11 @@ def test_rows_excluded_by_the_secondary_rule_are_skipped_not_changed():
             L.trx_set_skip_excluded(1)
         assert np.array_equal(res[1], res[0])
         assert res["n0"] == 0 and res["n1"] == int(np.isinf(res[1]).sum()) > 1000
+        # the per-call form of the switch (bench.py: every row it counts is evaluated)
+        _lib.check(L.trx_skipped_rows(None, 1))
+        flagged = _lib.lnl_batch(1, _lib.FLAG_EVALUATE_EXCLUDED, t_d, f_d, synth.SIGMA, r_d, synth.EXPTIME, 20).cpu().numpy()
+        _lib.check(L.trx_skipped_rows(ctypes.byref(n), 1))
+        assert n.value == 0 and np.array_equal(flagged, res[1])
         # twin rows and grids are never skipped
         _lib.check(L.trx_skipped_rows(None, 1))
         _lib.lnl_batch(2, 0, t_d, f_d, synth.SIGMA, _lib.dev(synth.eb_rows(rng, 500, True)), synth.EXPTIME, 20)

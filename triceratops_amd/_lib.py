@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRX_LIB") or os.path.join(_HERE, "libtrx.so")   # TRX_LIB: A/B builds
 
 MODEL_TP, MODEL_EB, MODEL_EB_TWIN, MODEL_RAW = 0, 1, 2, 3
-FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, FLAG_FP32_MODEL = 1, 2, 4
+FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, FLAG_FP32_MODEL, FLAG_EVALUATE_EXCLUDED = 1, 2, 4, 8
 N_PARAM = {MODEL_TP: 10, MODEL_EB: 11, MODEL_EB_TWIN: 11, MODEL_RAW: 9}
 ERR_NTOTAL = 4
 

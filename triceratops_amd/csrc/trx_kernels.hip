@@ -1660,7 +1660,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         if (a.memo) verdict = *static_cast<volatile int*>(a.memo);
         if (verdict == 1 || verdict == 2) a.use_stencil = 2;
     }
-    a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed);
+    a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
