@@ -741,6 +741,27 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     return p;
 }
 
+// A cell already known to need all S sub-exposures (the contact cells' second sweep): only the exposure
+// centre's solution, none of the criteria.
+template <bool FREEZE = false>
+__device__ __forceinline__ CellPlan plan_all_subexposures(const RowC& c, double t, int S)
+{
+    CellPlan p;
+    p.n = S;
+    const double phase = c.nmot * (t - c.t0);
+    p.Mprev = phase + c.Mtr;
+    p.sE = c.sEt;
+    p.cE = c.cEt;
+    const bool stepped = kepler_step_wide<FREEZE>(reduce_2pi(phase), c.e, p.sE, p.cE);
+    if (!__all(stepped)) {
+        double sF, cF;
+        kepler_full(p.Mprev, c.e, sF, cF);
+        if (!stepped) { p.sE = sF; p.cE = cF; }
+    }
+    p.anchored = true;
+    return p;
+}
+
 // Node s (1-based) of the plan: advances the orbit; returns z^2 (NaN propagates) and Y (< 0 on
 // the far side of the orbit).  frac = node offset / exptime.
 __device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, double exptime,

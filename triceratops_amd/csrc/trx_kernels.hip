@@ -770,6 +770,12 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 CellPlan pl;
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
+#ifndef TRX_PLAN_FULL_SOLVE
+                    // (one row per wave only: in the batched variant the second code path costs more -- measured
+                    // -2 % at 100-200 points -- than the criteria it skips; +1-3 % here)
+                    if (LONG && sweep == 1) pl = plan_all_subexposures<PRUNE>(c, t, a.S);      // filed as such by the first sweep
+                    else
+#endif
                     pl = plan_cell<false, PRUNE>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
