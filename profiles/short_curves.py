@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from triceratops_amd import _lib, synth
 
+JITTER = "--jitter" in sys.argv          # irregular stamps (+-0.3 of the spacing): no centre-value stencil
+if JITTER:
+    sys.argv.remove("--jitter")
 n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 L = _lib.lib()
 L.trx_set_skip_excluded(0)      # throughput of the model: every row counted is evaluated
@@ -15,6 +18,8 @@ print("# %s, %d rows per family, 18 families; evals/s = n_time x rows x 18 / tim
 for n_time in ([int(x) for x in sys.argv[2:]] or (50, 100, 150, 200, 250, 300, 400, 500, 1000, 2000)):
     rng = np.random.default_rng(synth.SEED)
     t = synth.time_grid(n_time)
+    if JITTER:
+        t = np.sort(t + rng.uniform(-0.3, 0.3, n_time) * (t[1] - t[0]))
     t_d = _lib.dev(t)
     curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)
     f_d = _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy()))

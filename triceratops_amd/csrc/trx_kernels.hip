@@ -829,8 +829,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
                     const int extra = (ST && s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
+                    // (first sweep: at most 9 nodes + the centre per cell -- four ballots; contact cells: up to S)
                     int total;
-                    const int off = lane_prefix<10>(cnt + extra, total);
+                    const int off = (sweep == 0 && a.use_tiers) ? lane_prefix<4>(cnt + extra, total)
+                                                                : lane_prefix<10>(cnt + extra, total);
                     for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
                     if (extra) pdesc[off + cnt] = (unsigned short)(lane | (kCentreNode << 6));
                     __syncthreads();
