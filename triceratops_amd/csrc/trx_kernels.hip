@@ -492,9 +492,7 @@ struct CellState {
     double sE[64], cE[64];                  // eccentric anomaly at the exposure centre
     double t[64];                           // exposure centre
     double facc[64];                        // the cell's sum over its nodes
-    signed char tier[64];                   // node set (-1 = all S sub-exposures)
-    unsigned char row[64], anchored[64];
-    unsigned char pad[64];
+    unsigned meta[64];                      // row | (tier + 1) << 8 | anchored << 16 (tier -1 = all S sub-exposures): one read per pair
 };
 // centre-value stencil (LONG only): the chunk's centre fluxes and the launch's weights
 struct StencilState {
@@ -814,9 +812,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
                 cs.t[lane] = t;
                 cs.facc[lane] = 0.0;
-                cs.tier[lane] = (signed char)tier;
-                cs.row[lane] = (unsigned char)rr;
-                cs.anchored[lane] = pl.anchored ? 1 : 0;
+                cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u);
                 TRX_TOCK(2, t_plan);
                 TRX_TICK(t_a);
                 // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
@@ -847,18 +843,18 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             const int h = d & 63;
                             const bool at_centre = ST && (d >> 6) == kCentreNode;
                             const int s = at_centre ? 0 : s0 + (d >> 6);
-                            const RowC& c = LONG ? cu : rows[cs.row[h]];
-                            const int ht = (int)cs.tier[h];
-                            const double tc = cs.t[h];
+                            const unsigned meta = cs.meta[h];
+                            const RowC& c = LONG ? cu : rows[meta & 0xffu];
+                            const int ht = (int)((meta >> 8) & 0xffu) - 1;
                             double sE = cs.sE[h], cE = cs.cE[h];
                             if (!at_centre) {
                                 const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
                                                              : tier_xw[ht * kTierMaxNodes + s];
-                                const double Mc = c.nmot * (tc - c.t0) + c.Mtr;
-                                const double M = c.nmot * ((tc + a.exptime * frac) - c.t0) + c.Mtr;
+                                // mean-anomaly offset of the node from the exposure centre
+                                const double dM = c.nmot * (a.exptime * frac);
                                 bool have = false;
-                                if (STEP && cs.anchored[h]) have = kepler_step<PRUNE>(M - Mc, c.e, sE, cE);
-                                if (!have) kepler_full(M, c.e, sE, cE);
+                                if (STEP && (meta & 0x10000u)) have = kepler_step<PRUNE>(dM, c.e, sE, cE);
+                                if (!have) kepler_full(c.nmot * ((cs.t[h] + a.exptime * frac) - c.t0) + c.Mtr, c.e, sE, cE);
                             }
                             const double ce = cE - c.e;
                             const double X = fma(c.ax, ce, c.bx * sE);
