@@ -550,7 +550,8 @@ struct RowC {
     double ax, ay, bx, by, cosi;
     double wlo, whi;          // mean-anomaly window (relative to conjunction), margins included
     double cle, cld, ced;     // limb-darkening weights
-    double xeb, fdil;         // dilution: m = (m + xeb)/(1 + xeb) [EB]; m = (m + fdil)/(1 + fdil)
+    double rdil;              // dilution: 1 - m_out = (1 - m) * rdil, rdil = 1 / ((1 + xeb)(1 + fdil)) for the reference's
+                              // m = (m + xeb)/(1 + xeb) [EB], m = (m + fdil)/(1 + fdil); NaN when a flux ratio is not finite
     double sEt, cEt;          // sin, cos of the eccentric anomaly at inferior conjunction (where M = Mtr)
     double excl;              // 1.0 when the EB secondary rule excludes the draw (+inf), else 0
 };

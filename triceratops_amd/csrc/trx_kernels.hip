@@ -344,7 +344,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
         if (a.model == TRX_MODEL_RAW) {
             u1 = p[7 * ps]; u2 = p[8 * ps];
             orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
-            c.xeb = 0.0; c.fdil = 0.0;
+            c.rdil = 1.0;
         } else {
             double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
             if (a.model == TRX_MODEL_TP) {
@@ -369,9 +369,9 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             const double inc_r = inc * (kPi / 180.0);                   // :344, :410
             const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
             orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+            double xeb = 0.0;
             if (!eblike) {
-                c.xeb = 0.0;
-                c.fdil = is_host ? (1.0 / fcomp) : fcomp;               // :352-357
+                fdil = is_host ? (1.0 / fcomp) : fcomp;                 // :352-357
             } else {
                 if (a.need_sec) {
                     RowC& sc = srows[lane];
@@ -379,23 +379,27 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
                     orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
                     const Limb L = limb_weights(u1, u2);
                     sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
-                    sc.xeb = 0.0; sc.fdil = 0.0; sc.excl = 0.0;
+                    sc.rdil = 1.0; sc.excl = 0.0;
                 }
                 if (is_host) {                                          // :427-432
-                    c.xeb = feb / fcomp;
+                    xeb = feb / fcomp;
                     ysec = fcomp / feb;
-                    c.fdil = 1.0 / (fcomp + feb);
+                    fdil = 1.0 / (fcomp + feb);
                 } else {                                                // :433-438
-                    c.xeb = feb / 1.0;
+                    xeb = feb / 1.0;
                     ysec = 1.0 / feb;
-                    c.fdil = fcomp / (1.0 + feb);
+                    fdil = fcomp / (1.0 + feb);
                 }
             }
+            // the two dilution stages as one factor on the flux DEFICIT: (m + x)/(1 + x) = 1 - (1 - m)/(1 + x), so
+            // an unocculted point stays exactly 1 and a cell costs one fma instead of two divisions; a flux ratio
+            // that is not finite makes the reference's quotient NaN (inf / inf), hence NaN here
+            c.rdil = 1.0 / ((1.0 + xeb) * (1.0 + fdil));
+            if (!(fabs(xeb) < INFINITY) || !(fabs(fdil) < INFINITY)) c.rdil = NAN;
         }
         const Limb L = limb_weights(u1, u2);
         c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
         c.excl = 0.0;
-        fdil = c.fdil;
         // through LDS to memory: 64 x 18 doubles leave the block as one contiguous 9 KB run (a lane
         // writing its own 144-byte block made every store instruction touch 64 cache lines)
         const double* src = reinterpret_cast<const double*>(&c);
@@ -635,8 +639,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             hrem[lane] = 0.0;
             // an unocculted cell: 1 diluted is 1 (or NaN for a degenerate flux ratio)
             double m1 = 1.0;
-            if (eblike) m1 = (m1 + c.xeb) / (1.0 + c.xeb);
-            if (a.model != TRX_MODEL_RAW) m1 = (m1 + c.fdil) / (1.0 + c.fdil);
+            m1 = fma(-(1.0 - m1), c.rdil, 1.0);
             hmout[lane] = m1;
         }
         __syncthreads();
@@ -896,10 +899,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 #pragma unroll
                         for (int i = -kStM; i <= kStM; ++i) fsum = fma(ss.stw[i + kStM], 1.0 - ss.fc[lane + i], fsum);
                     }
-                    double m = (pl.n == 0) ? 1.0 : ((tier < 0) ? fsum / a.dS : 1.0 - fsum);
+                    // the cell's flux deficit: nothing, 1 - mean of the S sub-exposures, or the Gauss rule's weighted sum
+                    const double deficit = (pl.n == 0) ? 0.0 : ((tier < 0) ? 1.0 - fsum / a.dS : fsum);
                     const RowC& cd = rows[rr];
-                    if (eblike) m = (m + cd.xeb) / (1.0 + cd.xeb);
-                    if (a.model != TRX_MODEL_RAW) m = (m + cd.fdil) / (1.0 + cd.fdil);
+                    const double m = fma(-deficit, cd.rdil, 1.0);    // dilution(s), :352-357, :427-438
                     if (MODE == MODE_GRID) {
                         a.out[(size_t)base * n_time + cell] = m;
                     } else {
