@@ -102,7 +102,7 @@ struct RowsArgs {
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
-    double s2, dS, rS;
+    double s2, rs2, dS, rS;      // sigma^2, 1 / sigma^2, S, 1 / S
 };
 
 // a wave-uniform double moved to a scalar register pair
@@ -260,7 +260,8 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
         double acc = 0.0;
         for (int j = lane & 63; j < a.n_time; j += 64) {
             const double d = a.flux[j] - 1.0;
-            acc += (d * d) / a.s2;
+            acc = fma(d * d, a.rs2, acc);            // (every chi^2 term of the path is (f - m)^2 x (1 / sigma^2): the
+                                                     // same operation everywhere, so that flat rows tie exactly)
         }
         acc = wave_sum(acc);
         if ((lane & 63) == 0) {
@@ -572,14 +573,14 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const double* fl = LONG ? a.flux : (tl + a.n_time);               // [n_time] (MODE_LNL)
     if (a.use_tiers && threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {
-            tier_xw[i] = a.tiers.x[i];
-            tier_xw[kTiers * kTierMaxNodes + i] = a.tiers.w[i];
+        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {       // (node offset, weight) pairs: one 16-byte read per pair
+            tier_xw[2 * i] = a.tiers.x[i];
+            tier_xw[2 * i + 1] = a.tiers.w[i];
         }
     }
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
-    const double s2 = a.s2;
+    const double rs2 = a.rs2;
     const int n_time = a.n_time;
     const float inv_nt = 1.0f / (float)n_time;
     // the row count: known to the host, or left on the device by an earlier kernel of the stream (the
@@ -707,13 +708,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
                     if (LONG && MODE == MODE_LNL && !inw && phase_no == 0) {
                         const double d = fl[j] - 1.0;
-                        lacc += (d * d) / s2;                                   // :486, :537, :586
+                        lacc = fma(d * d, rs2, lacc);                           // :486, :537, :586
                     }
                     if (PRUNE) {
                         // what the flat model charges the row for its in-window cells, until they are done
                         if (!LONG && inw && phase_no == 0) {
                             const double d = fl[j] - 1.0;
-                            __hip_atomic_fetch_add(&hrem[rr], (d * d) / s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&hrem[rr], (d * d) * rs2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (nphase == 2) {
                             const bool probe = (j % a.pstride) == (a.pstride >> 1);
@@ -852,7 +853,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             double sE = cs.sE[h], cE = cs.cE[h];
                             if (!at_centre) {
                                 const double frac = (ht < 0) ? fma((double)(s + 1) - 0.5, a.rS, -0.5)
-                                                             : tier_xw[ht * kTierMaxNodes + s];
+                                                             : tier_xw[2 * (ht * kTierMaxNodes + s)];
                                 // mean-anomaly offset of the node from the exposure centre
                                 const double dM = c.nmot * (a.exptime * frac);
                                 bool have = false;
@@ -875,7 +876,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             if (at_centre) {
                                 ss.fc[h] = f;
                             } else {
-                                const double term = (ht < 0) ? f : tier_xw[(kTiers + ht) * kTierMaxNodes + s] * (1.0 - f);
+                                const double term = (ht < 0) ? f : tier_xw[2 * (ht * kTierMaxNodes + s) + 1] * (1.0 - f);
                                 if (ht < 0 || term != 0.0)
                                     __hip_atomic_fetch_add(&cs.facc[h], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
@@ -909,7 +910,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         if (LONG) {
                             // the row's own lanes sum (f - m)^2 / sigma^2 directly    :486, :537, :586
                             const double d = fobs - m;
-                            lacc += (d * d) / s2;
+                            lacc = fma(d * d, rs2, lacc);
                             nonflat = nonflat || (m != 1.0);
                         } else {
                             // (f - m)^2 - (f - 1)^2, exactly 0 for m = 1: one LDS atomic per cell with a
@@ -917,12 +918,12 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             // serialises them in a fixed order, so results repeat bit for bit from run
                             // to run; a six-step shuffle reduction per chunk costs ten times the latency
                             const double f = fl[j];
-                            const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) / s2;
+                            const double contrib = ((1.0 - m) * ((f - m) + (f - 1.0))) * rs2;
                             if (contrib != 0.0)
                                 __hip_atomic_fetch_add(&hacc[rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (PRUNE && nphase == 2 && phase_no == 0) {      // this cell's share of chi^2 is now exact
                                 const double d1 = f - 1.0;
-                                __hip_atomic_fetch_add(&hrem[rr], -(d1 * d1) / s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(&hrem[rr], -(d1 * d1) * rs2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
                     }
@@ -1628,6 +1629,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.forced_B = g_rows_per_wave.load(std::memory_order_relaxed);
     a.B = long_rows ? 1 : batch_rows(a.n_dev ? -1 : a.n, a.n_time, a.forced_B);
     a.s2 = a.sigma * a.sigma;
+    a.rs2 = 1.0 / a.s2;
     a.dS = (double)a.S;
     a.rS = 1.0 / a.dS;
     a.nbatch = (a.n + a.B - 1) / a.B;
