@@ -571,9 +571,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // "rest" work
     const double* tl = LONG ? a.time : (lds + a.tl_off);              // [n_time]
     const double* fl = LONG ? a.flux : (tl + a.n_time);               // [n_time] (MODE_LNL)
-    if (a.use_tiers && threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) {       // (node offset, weight) pairs: one 16-byte read per pair
+    // the node tables into LDS as (node offset, weight) pairs (one 16-byte read per pair), an entry per lane: a
+    // loop on one lane was 420 wave instructions per workgroup -- 3 % of a batch at 100 points
+    if (a.use_tiers) {
+        for (int i = threadIdx.x; i < kTiers * kTierMaxNodes; i += 64) {
             tier_xw[2 * i] = a.tiers.x[i];
             tier_xw[2 * i + 1] = a.tiers.w[i];
         }
