@@ -723,19 +723,33 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     const double kd = fmin(c.k, 1.0);
     const double hx = 0.5 * fabs(exptime) * fma(0.5 * kd, kd, 1.0);
     const double om = fabs(nr) * rho;                                // bound on the angular rate
+    // the smallest admissible node count wins.  The test is monotone in the radius and the radii fall with the
+    // tier index, so with all seven tiers usable (S >= 20) three tests find it by bisection instead of seven
+    auto admissible = [&](double radius) -> bool {
+        const double tau = radius * hx;
+        return G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
+    };
+    static_assert(kTiers == 7, "bisection over seven tiers");
+    if (tt.n[kTiers - 1] > 0) {
+        const bool ok3 = admissible(tt.radius[3]);
+        const bool ok1 = admissible(ok3 ? tt.radius[1] : tt.radius[5]);
+        const bool ok2 = admissible(ok3 ? (ok1 ? tt.radius[0] : tt.radius[2]) : (ok1 ? tt.radius[4] : tt.radius[6]));
+        const int q = (ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)) + (ok2 ? 0 : 1);      // first admissible tier, 7 = none
+        if (q < kTiers) {
+            p.tier = q;
+            p.n = (q < 4) ? ((q < 2) ? (q == 0 ? tt.n[0] : tt.n[1]) : (q == 2 ? tt.n[2] : tt.n[3]))
+                          : ((q < 6) ? (q == 4 ? tt.n[4] : tt.n[5]) : tt.n[6]);
+        }
+    } else {
 #pragma unroll
-    for (int q = kTiers - 1; q >= 0; --q) {
-        // scanned from the largest node count down: the smallest admissible one wins
-        const double tau = tt.radius[q] * hx;
-        const bool ok = tt.n[q] > 0 && G >= 1.25 * fma(g2 * tau, tau, g1 * tau) &&
-                        om * tau <= 0.15 && Y > fabs(Yp) * tau;
-        if (ok) { p.tier = q; p.n = tt.n[q]; }
+        for (int q = kTiers - 1; q >= 0; --q) {
+            // scanned from the largest node count down
+            const bool ok = tt.n[q] > 0 && admissible(tt.radius[q]);
+            if (ok) { p.tier = q; p.n = tt.n[q]; }
+        }
     }
     // the same test at the radius the centre-value stencil of a dense uniform time grid needs
-    if (st_radius > 0.0) {
-        const double tau = st_radius * hx;
-        p.st_ok = G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
-    }
+    if (st_radius > 0.0) p.st_ok = admissible(st_radius);
     // whole exposure off the disc: every sub-exposure is exactly 1
     const double tau1 = 1.5 * hx;
     if (z2 > opp2 && G >= 1.25 * fma(g2 * tau1, tau1, g1 * tau1) && om * tau1 <= 0.15) p.n = 0;
