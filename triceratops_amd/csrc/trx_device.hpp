@@ -164,6 +164,41 @@ __device__ __forceinline__ double atan_pos(double x)
     return hi - ((t * (s1 + s2) - lo) - t);
 }
 
+// The same function with the argument reduction's constants taken from a 5 x 6 table (in LDS: cells_kernel) by
+// range index instead of four nested selects per constant: t = (alpha x + beta) / (gamma x + delta), then
+// hi, lo.  The same operations on the same numbers as atan_pos -- bit for bit -- in ~25 instructions less.
+constexpr int kAtanRanges = 5, kAtanCols = 6;
+__device__ __forceinline__ void atan_table_fill(double* tab, int i)
+{
+    // (alpha, beta, gamma, delta, hi, lo) of range i: x < 0.4375, < 0.6875, < 1.1875, < 2.4375, the rest
+    const double al[5] = {1.0, 2.0, 1.0, 1.0, 0.0}, be[5] = {0.0, -1.0, -1.0, -1.5, -1.0};
+    const double ga[5] = {0.0, 1.0, 1.0, 1.5, 1.0}, de[5] = {1.0, 2.0, 1.0, 1.0, 0.0};
+    const double hi[5] = {0.0, 4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+                          1.57079632679489655800e+00};
+    const double lo[5] = {0.0, 2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
+                          6.12323399573676603587e-17};
+    tab[6 * i + 0] = al[i]; tab[6 * i + 1] = be[i]; tab[6 * i + 2] = ga[i];
+    tab[6 * i + 3] = de[i]; tab[6 * i + 4] = hi[i]; tab[6 * i + 5] = lo[i];
+}
+
+__device__ __forceinline__ double atan_pos_tab(double x, const double* tab)
+{
+    const int i = (x >= 0.4375 ? 1 : 0) + (x >= 0.6875 ? 1 : 0) + (x >= 1.1875 ? 1 : 0) + (x >= 2.4375 ? 1 : 0);
+    const double* r = tab + kAtanCols * i;       // (NaN: range 0, as in atan_pos where every comparison is false... see below)
+    const double num = fma(r[0], x, r[1]);
+    const double den = fma(r[2], x, r[3]);
+    const double t = (den > 1.7e308) ? 0.0 : num * rcp_fast(den);
+    const double z = t * t, w = z * z;
+    const double s1 = z * fma_k(w, fma_k(w, fma_k(w, fma_k(w, fma_k(w, 1.62858201153657823623e-02,
+                      4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                      9.09088713343650656196e-02), 1.42857142725034663711e-01),
+                      3.33333333333329318027e-01);
+    const double s2 = w * fma_k(w, fma_k(w, fma_k(w, fma_k(w, -3.65315727442169155270e-02,
+                      -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                      -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    return r[4] - ((t * (s1 + s2) - r[5]) - t);
+}
+
 // ---------------------------------------------------------------------------------------
 // cel(kc,1,a1,b1) + cel(kc,p2,g2,g2) (Bulirsch 1969): the kc/em recurrence is shared and the
 // two p-sequences use one reciprocal per iteration.  Returns the sum of the two integrals.
@@ -226,7 +261,7 @@ __device__ __forceinline__ Limb limb_weights(double u1, double u2)
 // Mandel & Agol (2002) quadratic-law flux for 0 <= z < 1+p, p > 0 (callers handle the
 // unocculted side).  Case analysis and factored contact-triangle form: DESIGN.md section 4.
 // Both regions (disk inside the limb / crossing it) feed ONE cel_pair call.
-__device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
+__device__ __forceinline__ double ma_flux(double z, double p, const Limb& L, const double* atab = nullptr)
 {
     if (p >= 1.0 && z <= p - 1.0) return 0.0;
     const double z2 = z * z, p2 = p * p;
@@ -271,8 +306,9 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L)
         // tangents are sqrt(f2 f3 / (f1 f4)) = area4/(f1 f4) and sqrt(f1 f2 / (f3 f4)) = area4/(f3 f4)
         const double f14 = f1 * f4, f34 = f3 * f4;
         const double area4 = sqrt_fast(f14 * (f2 * f3));
-        const double kap0 = 2.0 * atan_pos((f14 > 0.0) ? area4 * rcp_fast(f14) : INFINITY);
-        const double kap1 = 2.0 * atan_pos(area4 * rcp_fast(f34));
+        const double x0 = (f14 > 0.0) ? area4 * rcp_fast(f14) : INFINITY, x1 = area4 * rcp_fast(f34);
+        const double kap0 = 2.0 * (atab ? atan_pos_tab(x0, atab) : atan_pos(x0));
+        const double kap1 = 2.0 * (atab ? atan_pos_tab(x1, atab) : atan_pos(x1));
         le = (p2 * kap0 + kap1 - 0.5 * area4) * (1.0 / kPi);
         ed = (kap1 + 2.0 * eta2 * kap0 - 0.25 * (1.0 + 5.0 * p2 + z2) * area4) * (1.0 / kTwoPi);
         const double fzp = 4.0 * z * p;
@@ -800,9 +836,9 @@ __device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, 
 }
 
 template <bool FP32>
-__device__ __forceinline__ double disc_flux(double z, double k, const Limb& L)
+__device__ __forceinline__ double disc_flux(double z, double k, const Limb& L, const double* atab = nullptr)
 {
-    return FP32 ? ma_flux_f32(z, k, L) : ma_flux(z, k, L);
+    return FP32 ? ma_flux_f32(z, k, L) : ma_flux(z, k, L, atab);
 }
 
 // Mean model flux of one exposure (centre t) evaluated by one lane: the body of pytransit's

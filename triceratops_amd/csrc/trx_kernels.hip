@@ -561,7 +561,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     double* hmout = hacc + Bl;                                        // [Bl] diluted model of an unocculted cell: 1, or NaN
     double* hrem = hmout + Bl;                                        // [Bl] PRUNE: (f - 1)^2 / s2 over the row's in-window cells not done yet
     double* tier_xw = hrem + Bl;
-    unsigned short* pdesc = reinterpret_cast<unsigned short*>(tier_xw + 2 * kTiers * kTierMaxNodes);   // [kCellsPairs] pair -> cell lane | node << 6
+    double* atab = tier_xw + 2 * kTiers * kTierMaxNodes;             // atan_pos_tab's range constants
+    unsigned short* pdesc = reinterpret_cast<unsigned short*>(atab + kAtanRanges * kAtanCols);   // [kCellsPairs] pair -> cell lane | node << 6
     constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
@@ -579,6 +580,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             tier_xw[2 * i + 1] = a.tiers.w[i];
         }
     }
+    if (threadIdx.x < kAtanRanges) atan_table_fill(atab, threadIdx.x);
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const double rs2 = a.rs2;
@@ -870,7 +872,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             double f = 1.0;
                             if (Y >= 0.0 && z2 < opp * opp) {
                                 const Limb L{c.cle, c.cld, c.ced};
-                                f = disc_flux<FP32>(sqrt_fast(z2), c.k, L);
+                                f = disc_flux<FP32>(sqrt_fast(z2), c.k, L, atab);
                             } else if (z2 != z2) {
                                 f = z2;
                             }
@@ -1674,7 +1676,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
-    size_t head = ((size_t)a.B * (kRowDoubles + 3) + 2 * kTiers * kTierMaxNodes) * sizeof(double)
+    size_t head = ((size_t)a.B * (kRowDoubles + 3) + 2 * kTiers * kTierMaxNodes + kAtanRanges * kAtanCols) * sizeof(double)
                 + (kCellsPairs + cells_window(long_rows)) * sizeof(unsigned short) + sizeof(CellState);
     if (long_rows) head += sizeof(StencilState);
     static_assert((kCellsPairs + kCellsWindowLong) % 4 == 0 && (kCellsPairs + kCellsWindowBatch) % 4 == 0 &&
