@@ -234,3 +234,47 @@ def test_default_sampling_mode_is_the_device_path():
     env = {k: v for k, v in __import__("os").environ.items() if k != "TRX_SAMPLING"}
     assert subprocess.run([sys.executable, "-c", code], cwd=__import__("os").path.dirname(__import__("os").path.dirname(
         __import__("os").path.abspath(__file__))), env=env).returncode == 0
+
+
+def test_field_star_limb_darkening_lookup_equals_the_dense_comparison():
+    """_LdcTable.field_stars looks a star up in its (Teff, logg) cell; the reference compares every star with
+    every table row (marginal_likelihoods.py:1913-1924).  Same rows, ties, NaNs and failures."""
+    from triceratops_amd import marginal_likelihoods as ml
+
+    def dense(tab, Teffs, loggs, Zs):
+        t = tab.Teffs[np.argmin(np.abs(tab.Teffs[None, :] - Teffs[:, None]), axis=1)]
+        g = tab.loggs[np.argmin(np.abs(tab.loggs[None, :] - loggs[:, None]), axis=1)]
+        cell = (tab.Teffs[None, :] == t[:, None]) & (tab.loggs[None, :] == g[:, None])
+        dz = np.where(cell, np.abs(tab.Zs[None, :] - Zs[:, None]), np.inf)
+        z = tab.Zs[np.argmin(dz, axis=1)]
+        row = cell & (tab.Zs[None, :] == z[:, None])
+        if not np.all(row.sum(axis=1) == 1):
+            raise ValueError("size")
+        idx = np.argmax(row, axis=1)
+        return tab.u1s[idx], tab.u2s[idx]
+
+    rng = np.random.default_rng(5)
+    for mission in ("TESS", "Kepler"):
+        tab = ml._ldc(mission)
+        # stars on cells the grid has (any Teff/logg pair of an existing row, jittered), mid-points (ties), NaN Z
+        j = rng.integers(0, tab.Teffs.size, 3000)
+        Teffs = tab.Teffs[j] + rng.uniform(-100, 100, j.size)
+        loggs = tab.loggs[j] + rng.uniform(-0.2, 0.2, j.size)
+        Zs = rng.uniform(-6, 2, j.size)
+        Teffs[:200] = tab.Teffs[j[:200]] + 125.0          # exactly between two nodes where the grid steps by 250 K
+        loggs[100:300] = tab.loggs[j[100:300]] + 0.25
+        Zs[300:320] = np.nan
+        Zs[320:400] = np.round(Zs[320:400] * 2) / 2 + 0.25   # between two metallicities
+        ok = np.ones(j.size, dtype=bool)
+        for i in range(j.size):
+            try:
+                dense(tab, Teffs[i:i + 1], loggs[i:i + 1], Zs[i:i + 1])
+            except ValueError:
+                ok[i] = False
+        assert ok.sum() > 2000
+        a = dense(tab, Teffs[ok], loggs[ok], Zs[ok])
+        b = tab.field_stars(Teffs[ok], loggs[ok], Zs[ok])
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+        for i in np.flatnonzero(~ok)[:20]:
+            with pytest.raises(ValueError):
+                tab.field_stars(Teffs[i:i + 1], loggs[i:i + 1], Zs[i:i + 1])

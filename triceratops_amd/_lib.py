@@ -162,13 +162,56 @@ def compute_device():
 
 # ---------------------------------------------------------------------------------------
 # device helpers
+_upload_streams = {}
+
+
 def dev(x, device=None):
-    """float64 contiguous device tensor from array-like / tensor."""
+    """float64 contiguous device tensor from array-like / tensor.
+
+    Host arrays go up on a stream of their own: a copy from pageable memory returns when it has completed,
+    so on the caller's stream it would wait for every kernel enqueued there before it -- a lnZ_* call
+    enqueued behind another one's likelihood kernel would stall the host for that kernel's duration.  The
+    data is in place when this returns, whichever stream reads it next."""
     if isinstance(x, torch.Tensor):
-        t = x.to(device=device or "cuda", dtype=torch.float64)
-    else:
-        t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).to(device or "cuda")
-    return t.contiguous()
+        return x.to(device=device or "cuda", dtype=torch.float64).contiguous()
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    d = torch.device(device or "cuda")
+    if d.type != "cuda" or not torch.cuda.is_available():
+        return torch.as_tensor(a).to(d).contiguous()
+    if d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    with upload_stream(d):
+        t = torch.as_tensor(a).to(d)
+    t.record_stream(torch.cuda.current_stream(d))      # the allocator must not hand the block out early
+    return t
+
+
+class upload_stream:
+    """`with upload_stream(device):` -- torch work inside runs on the device's upload stream and has completed
+    at exit: for small tables that several lnZ_* calls on different streams read afterwards"""
+
+    def __init__(self, device):
+        d = torch.device(device)
+        self.stream = self.ctx = None
+        if d.type != "cuda":                 # (the torch expression of the tests on CPU tensors)
+            return
+        if d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        self.stream = _upload_streams.get(d.index)
+        if self.stream is None:
+            self.stream = _upload_streams[d.index] = torch.cuda.Stream(d)
+        self.ctx = torch.cuda.stream(self.stream)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self.stream
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.stream.synchronize()
+        return False
 
 
 def _stream(t):

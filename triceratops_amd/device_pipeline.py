@@ -66,20 +66,36 @@ class _Field:
     """TRILEGAL population on the device (built from the host reader, a few thousand stars)"""
 
     def __init__(self, ctx, trilegal_fname, Tmag, Jmag, Hmag, Kmag, mission, need_ldc):
-        h = ml._Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
-        d = ctx["device"]
+        h = self._host = ml._Field(trilegal_fname, Tmag, Jmag, Hmag, Kmag)
+        d = self._device = ctx["device"]
+        self._mission = mission
         self.N_comp = h.N_comp
-        self.masses, self.loggs, self.Teffs = (_lib.dev(v, d) for v in (h.masses, h.loggs, h.Teffs))
-        self.fluxratios = _lib.dev(h.fluxratios, d)
-        self.delta = {k: _lib.dev(v, d) for k, v in (("T", h.dT), ("J", h.dJ), ("H", h.dH), ("K", h.dK))}
-        self.radii = _lib.dev(h.radii(), d)
+        # the nine columns in one upload (a few thousand stars): rows of one block
+        block = _lib.dev(np.stack([h.masses, h.loggs, h.Teffs, h.fluxratios, h.dT, h.dJ, h.dH, h.dK, h.radii()]), d)
+        self.masses, self.loggs, self.Teffs, self.fluxratios = block[0], block[1], block[2], block[3]
+        self.delta = {"T": block[4], "J": block[5], "H": block[6], "K": block[7]}
+        self.radii = block[8]
+        self._band_fr = {}
+        self.u1 = self.u2 = None
         if need_ldc:
-            u1, u2 = ml._ldc(mission).field_stars(h.Teffs, h.loggs, h.Zs)
-            self.u1, self.u2 = _lib.dev(u1, d), _lib.dev(u2, d)
+            self.need_ldc()
+
+    def need_ldc(self):
+        """per-star limb-darkening coefficients (the B scenarios; the D scenarios never ask)"""
+        if self.u1 is None:
+            h = self._host
+            u1, u2 = ml._ldc(self._mission).field_stars(h.Teffs, h.loggs, h.Zs)
+            both = _lib.dev(np.stack([u1, u2]), self._device)
+            self.u1, self.u2 = both[0], both[1]
 
     def band_delta(self, filt):
         return self.delta.get(filt, self.delta["T"])
 
     def band_fluxratio(self, filt):
-        dm = self.band_delta(filt)
-        return 10 ** (dm / 2.5) / (1 + 10 ** (dm / 2.5))
+        key = filt if filt in self.delta else "T"
+        fr = self._band_fr.get(key)
+        if fr is None:
+            dm = self.delta[key]
+            with _lib.upload_stream(self._device):       # kept: calls on other streams read it later
+                fr = self._band_fr[key] = 10 ** (dm / 2.5) / (1 + 10 ** (dm / 2.5))
+        return fr

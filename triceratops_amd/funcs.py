@@ -8,6 +8,8 @@ color_Teff_relations (143-161) and Gauss2D (180-200) have no caller on the path 
 for API parity only.  The web / FITS I/O (funcs.py:241-333, 405-474) is out of scope (SURVEY.md
 section 2 rows 9-10).
 """
+import os
+
 import numpy as np
 from pandas import read_csv
 from scipy.interpolate import InterpolatedUnivariateSpline
@@ -97,6 +99,24 @@ def trilegal_results(trilegal_fname: str, Tmag: float):
     (funcs.py:335-403): (Tmags, Masses, loggs, Teffs, Zs, Jmags, Hmags, Kmags).
     The last two rows of the file are TRILEGAL's trailer and are dropped (:353); without a
     TESS column the T magnitudes come from the 2MASS relations of Stassun et al. 2018."""
+    Tmags, cols = _trilegal_table(trilegal_fname)
+    keep = Tmags >= Tmag
+    return (Tmags[keep], cols["Masses"][keep], cols["loggs"][keep], cols["Teffs"][keep],
+            cols["Zs"][keep], cols["Jmags"][keep], cols["Hmags"][keep], cols["Kmags"][keep])
+
+
+_trilegal_cache = {}
+
+
+def _trilegal_table(trilegal_fname):
+    """(Tmags, columns) of the whole file.  The ~10 field-star calls of a calc_probs read the same file:
+    the parsed table is kept per (path, mtime, size) -- a rewritten file is read again; the boolean
+    selections above return fresh arrays, so callers never see each other's."""
+    st = os.stat(trilegal_fname)
+    key = (os.path.abspath(trilegal_fname), st.st_mtime_ns, st.st_size)
+    hit = _trilegal_cache.get(key)
+    if hit is not None:
+        return hit
     df = read_csv(trilegal_fname)[:-2]
     cols = {
         "Masses": df["Mact"].values,
@@ -121,6 +141,7 @@ def trilegal_results(trilegal_fname: str, Tmag: float):
                       - 545.64 * c[red] + 147.811)
         Tmags[c < -0.1] = J[c < -0.1] + 0.5
         Tmags[c > 1.0] = J[c > 1.0] + 1.75
-    keep = Tmags >= Tmag
-    return (Tmags[keep], cols["Masses"][keep], cols["loggs"][keep], cols["Teffs"][keep],
-            cols["Zs"][keep], cols["Jmags"][keep], cols["Hmags"][keep], cols["Kmags"][keep])
+    if len(_trilegal_cache) >= 4:
+        _trilegal_cache.clear()
+    _trilegal_cache[key] = (Tmags, cols)
+    return Tmags, cols

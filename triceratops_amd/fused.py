@@ -304,7 +304,7 @@ def _contrast_curve(cc_file, device):
 
 
 _lut_cache = {}
-_field_cache = {}      # TRILEGAL populations on the device, by (file, target magnitudes, mission, ldc, device)
+_field_cache = {}      # TRILEGAL populations on the device, by (file, target magnitudes, mission, device)
 
 
 def _companion_lut(mission, Z, teff_cap, device):
@@ -478,12 +478,15 @@ class _Scenario:
     def field(self, trilegal_fname, mags, need_ldc, cc_file, filt, M_s, hi_offset):
         """TRILEGAL population + the index draw; hi_offset = -1 for the D scenarios (sic)"""
         a = self.a
-        key = (trilegal_fname, tuple(float(m) for m in mags), self.mission, bool(need_ldc), self.dev.index)
+        # the D and B calls of one star share the population (the last few stars' are kept)
+        key = (trilegal_fname, tuple(float(m) for m in mags), self.mission, self.dev.index)
         f = _field_cache.get(key)
         if f is None:
-            if len(_field_cache) > 64:
+            if len(_field_cache) >= 8:
                 _field_cache.clear()
-            f = _field_cache[key] = dp._Field({"device": self.dev}, trilegal_fname, *mags, self.mission, need_ldc)
+            f = _field_cache[key] = dp._Field({"device": self.dev}, trilegal_fname, *mags, self.mission, False)
+        if need_ldc:
+            f.need_ldc()
         self.keep.append(f)
         a.comp = COMP_FIELD
         a.f_mass, a.f_radius, a.f_teff, a.f_logg = (f.masses.data_ptr(), f.radii.data_ptr(),

@@ -87,17 +87,52 @@ class _LdcTable:
 
     def field_stars(self, Teffs, loggs, Zs):
         """per-background-star coefficients: nearest Teff and logg, then the nearest Z among the
-        rows of that (Teff, logg) (marginal_likelihoods.py:1913-1924)."""
-        t = self.Teffs[np.argmin(np.abs(self.Teffs[None, :] - Teffs[:, None]), axis=1)]
-        g = self.loggs[np.argmin(np.abs(self.loggs[None, :] - loggs[:, None]), axis=1)]
-        cell = (self.Teffs[None, :] == t[:, None]) & (self.loggs[None, :] == g[:, None])
-        dz = np.where(cell, np.abs(self.Zs[None, :] - Zs[:, None]), np.inf)
-        z = self.Zs[np.argmin(dz, axis=1)]
-        row = cell & (self.Zs[None, :] == z[:, None])
-        if not np.all(row.sum(axis=1) == 1):
+        rows of that (Teff, logg) (marginal_likelihoods.py:1913-1924).
+
+        The reference compares every star with every table row; here the grid is indexed once --
+        distinct Teff / logg nodes in their order of first appearance (np.argmin's tie rule picks the
+        first row, i.e. the node that appears first) and, per (Teff, logg) cell, its rows in table
+        order -- and a star looks at its cell's few rows only.  Same selections, same errors."""
+        ix = self._index()
+        it = np.argmin(np.abs(ix["uT"][None, :] - Teffs[:, None]), axis=1)
+        ig = np.argmin(np.abs(ix["uG"][None, :] - loggs[:, None]), axis=1)
+        c = ix["cell"][it, ig]
+        if np.any(c < 0):                       # no row at that (Teff, logg): the reference's .item() fails
             raise ValueError("can only convert an array of size 1 to a Python scalar")
-        idx = np.argmax(row, axis=1)
+        dz = np.abs(ix["Z"][c] - Zs[:, None])   # (stars, rows of the cell; padding = inf)
+        slot = np.argmin(dz, axis=1)
+        if not np.all(ix["same"][c, slot] == 1):
+            raise ValueError("can only convert an array of size 1 to a Python scalar")
+        idx = ix["row"][c, slot]
         return self.u1s[idx], self.u2s[idx]
+
+    def _index(self):
+        ix = getattr(self, "_ix", None)
+        if ix is not None:
+            return ix
+
+        def nodes(v):
+            _, first = np.unique(v, return_index=True)
+            u = v[np.sort(first)]
+            return u, {x: i for i, x in enumerate(u.tolist())}
+
+        uT, posT = nodes(self.Teffs)
+        uG, posG = nodes(self.loggs)
+        members = {}
+        for j, (t, g) in enumerate(zip(self.Teffs.tolist(), self.loggs.tolist())):
+            members.setdefault((posT[t], posG[g]), []).append(j)
+        width = max(len(m) for m in members.values())
+        cell = np.full((uT.size, uG.size), -1, dtype=np.int64)
+        Z = np.full((len(members), width), np.inf)
+        row = np.zeros((len(members), width), dtype=np.int64)
+        same = np.zeros((len(members), width), dtype=np.int64)
+        for c, ((a, b), m) in enumerate(members.items()):
+            cell[a, b] = c
+            z = self.Zs[m]
+            Z[c, :len(m)], row[c, :len(m)] = z, m
+            same[c, :len(m)] = (z[None, :] == z[:, None]).sum(axis=1)      # rows of the cell at this Z
+        self._ix = {"uT": uT, "uG": uG, "cell": cell, "Z": Z, "row": row, "same": same}
+        return self._ix
 
 
 _tables = {}
