@@ -168,18 +168,13 @@ __device__ __forceinline__ double atan_pos(double x)
 // range index instead of four nested selects per constant: t = (alpha x + beta) / (gamma x + delta), then
 // hi, lo.  The same operations on the same numbers as atan_pos -- bit for bit -- in ~25 instructions less.
 constexpr int kAtanRanges = 5, kAtanCols = 6;
-__device__ __forceinline__ void atan_table_fill(double* tab, int i)
-{
-    // (alpha, beta, gamma, delta, hi, lo) of range i: x < 0.4375, < 0.6875, < 1.1875, < 2.4375, the rest
-    const double al[5] = {1.0, 2.0, 1.0, 1.0, 0.0}, be[5] = {0.0, -1.0, -1.0, -1.5, -1.0};
-    const double ga[5] = {0.0, 1.0, 1.0, 1.5, 1.0}, de[5] = {1.0, 2.0, 1.0, 1.0, 0.0};
-    const double hi[5] = {0.0, 4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
-                          1.57079632679489655800e+00};
-    const double lo[5] = {0.0, 2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
-                          6.12323399573676603587e-17};
-    tab[6 * i + 0] = al[i]; tab[6 * i + 1] = be[i]; tab[6 * i + 2] = ga[i];
-    tab[6 * i + 3] = de[i]; tab[6 * i + 4] = hi[i]; tab[6 * i + 5] = lo[i];
-}
+// (alpha, beta, gamma, delta, hi, lo) of the ranges x < 0.4375, < 0.6875, < 1.1875, < 2.4375 and the rest
+__device__ const double kAtanTable[kAtanRanges * kAtanCols] = {
+    1.0,  0.0, 0.0, 1.0, 0.0,                        0.0,
+    2.0, -1.0, 1.0, 2.0, 4.63647609000806093515e-01, 2.26987774529616870924e-17,
+    1.0, -1.0, 1.0, 1.0, 7.85398163397448278999e-01, 3.06161699786838301793e-17,
+    1.0, -1.5, 1.5, 1.0, 9.82793723247329054082e-01, 1.39033110312309984516e-17,
+    0.0, -1.0, 1.0, 0.0, 1.57079632679489655800e+00, 6.12323399573676603587e-17};
 
 __device__ __forceinline__ double atan_pos_tab(double x, const double* tab)
 {

@@ -580,7 +580,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             tier_xw[2 * i + 1] = a.tiers.w[i];
         }
     }
-    if (threadIdx.x < kAtanRanges) atan_table_fill(atab, threadIdx.x);
+    if (threadIdx.x < kAtanRanges * kAtanCols) atab[threadIdx.x] = kAtanTable[threadIdx.x];
     const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const double rs2 = a.rs2;
