@@ -63,25 +63,33 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, long i
 __device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
 
 // Gamma(alpha, 1) by Marsaglia & Tsang (2000); alpha < 1 through Gamma(alpha + 1) U^(1/alpha).
-// Each attempt takes two counter blocks (a Box-Muller normal + the acceptance uniform).
+// One counter block per attempt: 53 bits for the radius of the Box-Muller normal, 32 for its angle, 32 for
+// the acceptance uniform.  The variate is a random DRAW, not a model quantity: its arithmetic runs in fp32 on
+// the hardware's log / cos / sqrt / exp (relative error ~1e-7, a shift of the sampled distribution far below
+// what 1e6 draws resolve; the fp64 libm versions were a third of a planet scenario's draw kernel).  The
+// normal's argument 1 - u0 keeps its fp64 exponent, so the tails reach 8.5 sigma.
 __device__ __forceinline__ double philox_gamma(unsigned long long seed, long i, unsigned slot, double alpha)
 {
-    const double a1 = (alpha < 1.0) ? alpha + 1.0 : alpha;
-    const double d = a1 - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    double g = d;
+    const float a1 = (float)((alpha < 1.0) ? alpha + 1.0 : alpha);
+    const float d = a1 - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    float g = d;
     for (unsigned att = 0; att < 64u; ++att) {
-        double u0, u1, u2, u3;
-        philox_uniform2(seed, i, slot, 2u * att + 1u, u0, u1);
-        philox_uniform2(seed, i, slot, 2u * att + 2u, u2, u3);
-        const double x = sqrt(-2.0 * log(1.0 - u0)) * cos(2.0 * kPi * u1);
-        const double t = 1.0 + c * x;
-        if (t <= 0.0) continue;
-        const double v = t * t * t, x2 = x * x;
-        const double lu = log(1.0 - u2);              // log of a uniform in (0, 1]
-        if (lu < 0.5 * x2 + d * (1.0 - v + log(v))) { g = d * v; break; }
+        const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), slot, att + 1u},
+                                   (unsigned)seed, (unsigned)(seed >> 32));
+        const double u0 = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) * (1.0 / 9007199254740992.0);
+        const float u1 = (float)r.z * (1.0f / 4294967296.0f);
+        const float u2 = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);       // in (0, 1)
+        const float x = sqrtf(-2.0f * __logf((float)(1.0 - u0))) * __cosf(6.2831853071795865f * u1);
+        const float t = 1.0f + c * x;
+        if (t <= 0.0f) continue;
+        const float v = t * t * t, x2 = x * x;
+        if (__logf(u2) < 0.5f * x2 + d * (1.0f - v + __logf(v))) { g = d * v; break; }
     }
-    if (alpha < 1.0) g *= pow_pos(1.0 - philox_uniform(seed, i, slot), 1.0 / alpha);   // sub-draw 0: the boost uniform
-    return g;
+    if (alpha < 1.0) {                      // sub-draw 0: the boost uniform
+        const float ub = (float)(1.0 - philox_uniform(seed, i, slot));
+        g *= __expf(__logf(ub) * (float)(1.0 / alpha));
+    }
+    return (double)g;
 }
 
 // ---- tables staged in LDS ------------------------------------------------------------------
@@ -212,220 +220,278 @@ __device__ __forceinline__ bool transits(double Ptra, double inc, bool parallel)
     return parallel ? hit : (hit && ok);
 }
 
-// blk_cnt != null (trx_scenario_evidence): workgroup b takes the `per` consecutive draws from b * per and
-// leaves the number of its draws that passed the mask(s) in blk_cnt[b] (and blk_cnt[gridDim.x + b] for the
-// twin branch) -- the first half of the ordered compaction (compact_kernel, trx_scenario.hip).  A draw's
-// numbers depend on its index only, so the mapping of draws to threads changes no result.
+// One draw: its random inputs, the scenario's parameters, the geometry mask(s), the prior.
+//   PHASE 0  everything (trx_draw_scenario: the torch-operator chain reads whole columns)
+//   PHASE 1  the mask(s) only -- what does not feed them (flux ratios, the prior) is not computed and no
+//            column is written: 90-95 % of the draws fail the geometry and are never looked at again
+//   PHASE 2  the columns and the prior of a draw that passed (fill_kernel, after the compaction): the same
+//            code on the same counter-based random numbers, hence the same values
+template <int PHASE>
+__device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T, const long i, const bool parallel,
+                                         bool& hit, bool& hit_twin)
+{
+    const long N = a.N;
+    hit = hit_twin = false;
+    // a random input: the staged array, or the kernel's own Philox stream.  One counter block yields two
+    // 53-bit uniforms, and the eight inputs fall into three blocks whose halves no scenario needs both of
+    // more than once: (R_p | q, inc), (ecc, argp), (q_comp | field index, P)
+    double gu[3][2];
+    bool gdone[3] = {false, false, false};
+    auto rnd = [&](const double* staged, unsigned slot) -> double {
+        if (staged) return staged[i];
+        const int g = (slot == 2u || slot == 4u || slot == 3u) ? 0 : ((slot == 5u || slot == 6u) ? 1 : 2);
+        const int h = (slot == 3u || slot == 6u || slot == 0u) ? 1 : 0;
+        if (!gdone[g]) {
+            philox_uniform2(a.seed, i, 16u + (unsigned)g, 0u, gu[g][0], gu[g][1]);
+            gdone[g] = true;
+        }
+        return gu[g][h];
+    };
+    double dP = 0.0, dQc = 0.0, dRp = 0.0, dQ = 0.0, dEcc = 0.0, dIdx = 0.0, dBeta = 0.0;
+    double P = a.P_lo;
+    if (a.uP || a.range_P) { dP = rnd(a.uP, 0u); P = a.P_lo + (a.P_hi - a.P_lo) * dP; }
+    // ---- unresolved companion (bound) or field star ----------------------------------
+    double frc = 0.0, qc = 1.0, mc = 0.0;
+    long k = 0;
+    if (a.comp == TRX_COMP_BOUND) {
+        if (a.qc_in) qc = a.qc_in[i];
+        else { dQc = rnd(a.uQc, 1u); qc = plaw_inv(a.law_qc, dQc); }
+        mc = qc * a.M_s;
+        const double f = flux_rel(T, TRX_SPL_F_TESS, mc);
+        frc = f / (f + a.f0_tess);
+    } else if (a.comp == TRX_COMP_FIELD) {
+        if (a.idx) k = a.idx[i];
+        else {
+            dIdx = rnd(nullptr, 7u);
+            k = (long)(dIdx * (double)a.n_field_draw);
+            k = k < a.n_field_draw ? k : a.n_field_draw - 1;
+        }
+        frc = a.f_fr[k];
+    }
+    // ---- host star ---------------------------------------------------------------------
+    double Mh = a.M_s, Rh = a.R_s, Th = a.Teff, u1 = a.u1, u2 = a.u2;
+    bool extra = true;
+    if (a.host == TRX_HOST_COMPANION) {
+        Mh = mc;
+        stellar_relations(T, mc, a.R_s, a.Teff, Rh, Th);
+        const double rm = Rh * kRsun;
+        const double logg = log10(kG * (mc * kMsun) / (rm * rm));
+        // rounded (Teff / 250 K, logg / 0.5 dex) lattice at the nearest Z
+        // (marginal_likelihoods.py:945-972; Teff cap 10000 K for STP, 13000 K for SEB :1181)
+        double ig = rint(logg / 0.5) * 0.5;
+        ig = fmin(fmax(ig, 3.5), 5.0);
+        double it = rint(Th / 250.0) * 250.0;
+        it = fmin(fmax(it, 3500.0), a.teff_cap);
+        double code = rint((it - 3500.0) / 250.0) * 4.0 + rint((ig - 3.5) / 0.5);
+        if (code != code) code = 0.0;
+        int ci = (int)code;
+        ci = ci < 0 ? 0 : (ci >= a.n_lut ? a.n_lut - 1 : ci);
+        u1 = T.lut[0][ci];
+        u2 = T.lut[1][ci];
+        if (PHASE != 2 && u1 != u1) atomicOr(a.flag, 1);     // a cell the Claret grid lacks: the reference raises
+    } else if (a.host == TRX_HOST_FIELD) {
+        Mh = a.f_mass[k];
+        Rh = a.f_radius[k];
+        Th = a.f_teff[k];
+        u1 = a.f_u1[k];
+        u2 = a.f_u2[k];
+        extra = (a.f_logg[k] >= 3.5) && (Th <= 10000.0);      // marginal_likelihoods.py:1950, 2212
+    }
+    if (a.comp == TRX_COMP_BOUND) extra = extra && (qc != 0.0);
+
+    const double dInc = rnd(a.uInc, 3u), dW = rnd(a.uW, 6u);
+    const double inc = acos(1.0 - dInc) * 180.0 / kPi;                  // priors.py:119-132
+    const double w = dW * 360.0;                                        // :157-166
+    const double sinw = sin(w * kPi / 180.0);
+    double ecc, lnprior = 0.0, dm = 0.0;
+    bool dm_set = false;
+    double* col = a.cols + i;
+    if (a.planet) {
+        if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
+        else {
+            const double gx = philox_gamma(a.seed, i, 8u, 0.867), gy = philox_gamma(a.seed, i, 9u, 3.030);
+            ecc = gx / (gx + gy);
+        }
+        dBeta = ecc;
+        dRp = rnd(a.uRp, 2u);
+        double rp;
+        if (a.flat) rp = dRp * 19.5 + 0.5;
+        else rp = (Mh > 0.45) ? plaw_inv(a.law_rp_hi, dRp) : plaw_inv(a.law_rp_lo, dRp);
+        const double sm = sma(Mh, P);
+        const double size = rp * kRearth + Rh * kRsun;
+        const double Ptra = size / sm * ((1.0 + ecc * sinw) / (1.0 - ecc * ecc));
+        const bool coll = size > sm * (1.0 - ecc);
+        const bool m0 = transits(Ptra, inc, parallel) && !coll && extra;
+        hit = m0;
+        if (PHASE != 2) a.mask[i] = m0 ? 1 : 0;
+        if (PHASE != 1) {
+            col[0 * N] = rp; col[1 * N] = P; col[2 * N] = inc; col[3 * N] = sm; col[4 * N] = Rh;
+            col[5 * N] = u1; col[6 * N] = u2; col[7 * N] = ecc; col[8 * N] = w; col[9 * N] = frc;
+            col[10 * N] = Mh;
+        }
+        // ---- prior: flux term of the companion / field star ---------------------------
+        if (a.prior == TRX_PRIOR_BOUND_TP) {
+            double fr = ratio(frc);
+            if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); fr = ratio(f / (f + a.f0_band)); }
+            dm = 2.5 * log10(fr);
+            dm_set = true;
+            lnprior = bound_rate(a, T, fabs(dm), false);
+        }
+    } else {
+        dEcc = rnd(a.uEcc, 5u);
+        ecc = pow_pos(dEcc, a.ecc_pow);                                 // priors.py:146-155
+        dQ = rnd(a.uQ, 4u);
+        const double q = plaw_inv(a.law_q, dQ);
+        const double m = q * Mh;
+        double r, tdummy;
+        stellar_relations(T, m, Rh, Th, r, tdummy);
+        const double fm = flux_rel(T, TRX_SPL_F_TESS, m);
+        double fr = fm / (fm + a.f0_tess);
+        double fh_band_share = 0.0;
+        if (a.host == TRX_HOST_FIELD) {
+            // the background star sits at another distance: rescale the pair's flux share
+            const double fh = flux_rel(T, TRX_SPL_F_TESS, Mh);
+            fr = fr * (frc / (fh / (fh + a.f0_tess)));                  // marginal_likelihoods.py:2147-2159
+            if (a.use_cc) { const double fb = flux_rel(T, TRX_SPL_F_BAND, Mh); fh_band_share = fb / (fb + a.f0_band); }
+        }
+        const double mt = Mh + m;
+        const double sm = sma(mt, P), sm2 = sma(mt, 2.0 * P);
+        const double e_corr = (1.0 + ecc * sinw) / (1.0 - ecc * ecc);
+        const double size = r * kRsun + Rh * kRsun;
+        const double Ptra = size / sm * e_corr, Ptra2 = size / sm2 * e_corr;
+        const bool coll = size > sm * (1.0 - ecc);
+        const bool coll2 = (2.0 * Rh * kRsun) > sm2 * (1.0 - ecc);
+        bool m1 = transits(Ptra, inc, parallel) && !coll && (q < 0.95) && extra;
+        bool m2 = transits(Ptra2, inc, parallel) && !coll2 && (q >= 0.95) && extra;
+        if (!parallel) m2 = m2 && (Ptra <= 1.0);      // the loop `continue`s before the twin test
+        hit = m1;
+        hit_twin = m2;
+        if (PHASE != 2) {
+            a.mask[i] = m1 ? 1 : 0;
+            a.mask_twin[i] = m2 ? 1 : 0;
+        }
+        if (PHASE != 1) {
+            col[0 * N] = r; col[1 * N] = fr; col[2 * N] = P; col[3 * N] = inc; col[4 * N] = sm;
+            col[5 * N] = Rh; col[6 * N] = u1; col[7 * N] = u2; col[8 * N] = ecc; col[9 * N] = w;
+            col[10 * N] = frc; col[11 * N] = sm2; col[12 * N] = m; col[13 * N] = Mh;
+        }
+        if (a.prior == TRX_PRIOR_BOUND_EB) {
+            double term = ratio(frc);
+            if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); term = ratio(f / (f + a.f0_band)); }
+            if (a.host == TRX_HOST_COMPANION) {
+                // lnZ_SEB: the companion AND its EB count (marginal_likelihoods.py:1202-1205)
+                double fe = fr;
+                if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, m); fe = f / (f + a.f0_band); }
+                term = term + ratio(fe);
+            }
+            dm = 2.5 * log10(term);
+            dm_set = true;
+            lnprior = bound_rate(a, T, fabs(dm), true);
+        } else if (a.prior == TRX_PRIOR_FIELD && a.host == TRX_HOST_FIELD) {
+            // lnZ_BEB: background star + its EB (marginal_likelihoods.py:2161-2208)
+            double term;
+            if (a.use_cc) {
+                const double frc_cc = a.f_frband[k];
+                const double fmb = flux_rel(T, TRX_SPL_F_BAND, m);
+                const double fr_cc = (fmb / (fmb + a.f0_band)) * (frc_cc / fh_band_share);
+                term = ratio(frc_cc) + ratio(fr_cc);
+            } else {
+                term = ratio(frc) + ratio(fr);
+            }
+            dm = 2.5 * log10(term);
+            dm_set = true;
+        }
+    }
+    if (a.prior == TRX_PRIOR_FIELD) {
+        if (!dm_set) {
+            // D scenarios and lnZ_BTP: the field star alone
+            dm = a.use_cc ? a.f_delta[k] : 2.5 * log10(ratio(frc));
+        }
+        if (a.use_cc) {
+            const double s = interp(T.cc_con, T.cc_sep, a.n_cc, fabs(dm));
+            lnprior = log(a.bg_amp * (s * s));
+        } else {
+            lnprior = a.bg_const;
+        }
+    }
+    if (a.prior == TRX_PRIOR_BOUND_TP || a.prior == TRX_PRIOR_BOUND_EB || a.prior == TRX_PRIOR_FIELD) {
+        lnprior = (lnprior > 0.0) ? 0.0 : lnprior;     // clamp_max: NaN stays NaN
+        if (dm > 0.0) lnprior = -INFINITY;
+    }
+    if (PHASE != 1 && a.lnprior) a.lnprior[i] = lnprior;
+    if (PHASE != 1 && a.dump) {
+        double* dd = a.dump + i;
+        dd[0 * N] = dP; dd[1 * N] = dQc; dd[2 * N] = dRp; dd[3 * N] = dInc; dd[4 * N] = dQ;
+        dd[5 * N] = dEcc; dd[6 * N] = dW; dd[7 * N] = (double)k; dd[8 * N] = dBeta;
+    }
+}
+
+__device__ __forceinline__ void stage_tables(const trx_draw_args& a, Tables& T)
+{
+    double* dst = reinterpret_cast<double*>(&T);
+    const int nspl = TRX_DRAW_N_SPLINES * TRX_DRAW_SPLINE_DOUBLES;
+    for (int i = threadIdx.x; i < nspl; i += blockDim.x) dst[i] = a.splines[i];
+    for (int i = threadIdx.x; i < a.n_cc; i += blockDim.x) { T.cc_sep[i] = a.cc_seps[i]; T.cc_con[i] = a.cc_cons[i]; }
+    for (int i = threadIdx.x; i < a.n_lut; i += blockDim.x) { T.lut[0][i] = a.lut[i]; T.lut[1][i] = a.lut[a.n_lut + i]; }
+    __syncthreads();
+}
+
+// blk_cnt == null (trx_draw_scenario): every draw in full, grid-stride.
+// blk_cnt != null (trx_scenario_evidence): workgroup b takes the `per` consecutive draws from b * per, writes
+// their mask(s) only and leaves the number of its draws that passed in blk_cnt[b] (and blk_cnt[gridDim.x + b]
+// for the twin branch) -- the first half of the ordered compaction (compact_kernel, trx_scenario.hip); the
+// columns of the draws that passed follow in fill_kernel.  A draw's numbers depend on its index only, so the
+// mapping of draws to threads changes no result.
 __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restrict__ blk_cnt, long per)
 {
     __shared__ Tables T;
     __shared__ int wave_cnt[2][4];
-    {
-        double* dst = reinterpret_cast<double*>(&T);
-        const int nspl = TRX_DRAW_N_SPLINES * TRX_DRAW_SPLINE_DOUBLES;
-        for (int i = threadIdx.x; i < nspl; i += blockDim.x) dst[i] = a.splines[i];
-        for (int i = threadIdx.x; i < a.n_cc; i += blockDim.x) { T.cc_sep[i] = a.cc_seps[i]; T.cc_con[i] = a.cc_cons[i]; }
-        for (int i = threadIdx.x; i < a.n_lut; i += blockDim.x) { T.lut[0][i] = a.lut[i]; T.lut[1][i] = a.lut[a.n_lut + i]; }
-    }
-    __syncthreads();
+    stage_tables(a, T);
     const long N = a.N;
     const bool parallel = a.parallel != 0;
     int hits = 0, hits_twin = 0;
-    long i_first = (long)blockIdx.x * blockDim.x + threadIdx.x, i_end = N, i_step = (long)gridDim.x * blockDim.x;
-    if (blk_cnt) {
-        i_first = (long)blockIdx.x * per + threadIdx.x;
-        i_end = ((long)(blockIdx.x + 1) * per < N) ? (long)(blockIdx.x + 1) * per : N;
-        i_step = blockDim.x;
+    if (!blk_cnt) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+            bool h0, h1;
+            draw_one<0>(a, T, i, parallel, h0, h1);
+        }
+        return;
     }
-    for (long i = i_first; i < i_end; i += i_step) {
-        // a random input: the staged array, or the kernel's own Philox stream
-        auto rnd = [&](const double* staged, unsigned slot) -> double {
-            return staged ? staged[i] : philox_uniform(a.seed, i, slot);
-        };
-        double dP = 0.0, dQc = 0.0, dRp = 0.0, dQ = 0.0, dEcc = 0.0, dIdx = 0.0, dBeta = 0.0;
-        double P = a.P_lo;
-        if (a.uP || a.range_P) { dP = rnd(a.uP, 0u); P = a.P_lo + (a.P_hi - a.P_lo) * dP; }
-        // ---- unresolved companion (bound) or field star ----------------------------------
-        double frc = 0.0, qc = 1.0, mc = 0.0;
-        long k = 0;
-        if (a.comp == TRX_COMP_BOUND) {
-            if (a.qc_in) qc = a.qc_in[i];
-            else { dQc = rnd(a.uQc, 1u); qc = plaw_inv(a.law_qc, dQc); }
-            mc = qc * a.M_s;
-            const double f = flux_rel(T, TRX_SPL_F_TESS, mc);
-            frc = f / (f + a.f0_tess);
-        } else if (a.comp == TRX_COMP_FIELD) {
-            if (a.idx) k = a.idx[i];
-            else {
-                dIdx = philox_uniform(a.seed, i, 7u);
-                k = (long)(dIdx * (double)a.n_field_draw);
-                k = k < a.n_field_draw ? k : a.n_field_draw - 1;
-            }
-            frc = a.f_fr[k];
-        }
-        // ---- host star ---------------------------------------------------------------------
-        double Mh = a.M_s, Rh = a.R_s, Th = a.Teff, u1 = a.u1, u2 = a.u2;
-        bool extra = true;
-        if (a.host == TRX_HOST_COMPANION) {
-            Mh = mc;
-            stellar_relations(T, mc, a.R_s, a.Teff, Rh, Th);
-            const double rm = Rh * kRsun;
-            const double logg = log10(kG * (mc * kMsun) / (rm * rm));
-            // rounded (Teff / 250 K, logg / 0.5 dex) lattice at the nearest Z
-            // (marginal_likelihoods.py:945-972; Teff cap 10000 K for STP, 13000 K for SEB :1181)
-            double ig = rint(logg / 0.5) * 0.5;
-            ig = fmin(fmax(ig, 3.5), 5.0);
-            double it = rint(Th / 250.0) * 250.0;
-            it = fmin(fmax(it, 3500.0), a.teff_cap);
-            double code = rint((it - 3500.0) / 250.0) * 4.0 + rint((ig - 3.5) / 0.5);
-            if (code != code) code = 0.0;
-            int ci = (int)code;
-            ci = ci < 0 ? 0 : (ci >= a.n_lut ? a.n_lut - 1 : ci);
-            u1 = T.lut[0][ci];
-            u2 = T.lut[1][ci];
-            if (u1 != u1) atomicOr(a.flag, 1);     // a cell the Claret grid lacks: the reference raises
-        } else if (a.host == TRX_HOST_FIELD) {
-            Mh = a.f_mass[k];
-            Rh = a.f_radius[k];
-            Th = a.f_teff[k];
-            u1 = a.f_u1[k];
-            u2 = a.f_u2[k];
-            extra = (a.f_logg[k] >= 3.5) && (Th <= 10000.0);      // marginal_likelihoods.py:1950, 2212
-        }
-        if (a.comp == TRX_COMP_BOUND) extra = extra && (qc != 0.0);
-
-        const double dInc = rnd(a.uInc, 3u), dW = rnd(a.uW, 6u);
-        const double inc = acos(1.0 - dInc) * 180.0 / kPi;                  // priors.py:119-132
-        const double w = dW * 360.0;                                        // :157-166
-        const double sinw = sin(w * kPi / 180.0);
-        double ecc, lnprior = 0.0, dm = 0.0;
-        bool dm_set = false;
-        double* col = a.cols + i;
-        if (a.planet) {
-            if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
-            else {
-                const double gx = philox_gamma(a.seed, i, 8u, 0.867), gy = philox_gamma(a.seed, i, 9u, 3.030);
-                ecc = gx / (gx + gy);
-            }
-            dBeta = ecc;
-            dRp = rnd(a.uRp, 2u);
-            double rp;
-            if (a.flat) rp = dRp * 19.5 + 0.5;
-            else rp = (Mh > 0.45) ? plaw_inv(a.law_rp_hi, dRp) : plaw_inv(a.law_rp_lo, dRp);
-            const double sm = sma(Mh, P);
-            const double size = rp * kRearth + Rh * kRsun;
-            const double Ptra = size / sm * ((1.0 + ecc * sinw) / (1.0 - ecc * ecc));
-            const bool coll = size > sm * (1.0 - ecc);
-            const bool m0 = transits(Ptra, inc, parallel) && !coll && extra;
-            a.mask[i] = m0 ? 1 : 0;
-            hits += m0 ? 1 : 0;
-            col[0 * N] = rp; col[1 * N] = P; col[2 * N] = inc; col[3 * N] = sm; col[4 * N] = Rh;
-            col[5 * N] = u1; col[6 * N] = u2; col[7 * N] = ecc; col[8 * N] = w; col[9 * N] = frc;
-            col[10 * N] = Mh;
-            // ---- prior: flux term of the companion / field star ---------------------------
-            if (a.prior == TRX_PRIOR_BOUND_TP) {
-                double fr = ratio(frc);
-                if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); fr = ratio(f / (f + a.f0_band)); }
-                dm = 2.5 * log10(fr);
-                dm_set = true;
-                lnprior = bound_rate(a, T, fabs(dm), false);
-            }
-        } else {
-            dEcc = rnd(a.uEcc, 5u);
-            ecc = pow_pos(dEcc, a.ecc_pow);                                 // priors.py:146-155
-            dQ = rnd(a.uQ, 4u);
-            const double q = plaw_inv(a.law_q, dQ);
-            const double m = q * Mh;
-            double r, tdummy;
-            stellar_relations(T, m, Rh, Th, r, tdummy);
-            const double fm = flux_rel(T, TRX_SPL_F_TESS, m);
-            double fr = fm / (fm + a.f0_tess);
-            double fh_band_share = 0.0;
-            if (a.host == TRX_HOST_FIELD) {
-                // the background star sits at another distance: rescale the pair's flux share
-                const double fh = flux_rel(T, TRX_SPL_F_TESS, Mh);
-                fr = fr * (frc / (fh / (fh + a.f0_tess)));                  // marginal_likelihoods.py:2147-2159
-                if (a.use_cc) { const double fb = flux_rel(T, TRX_SPL_F_BAND, Mh); fh_band_share = fb / (fb + a.f0_band); }
-            }
-            const double mt = Mh + m;
-            const double sm = sma(mt, P), sm2 = sma(mt, 2.0 * P);
-            const double e_corr = (1.0 + ecc * sinw) / (1.0 - ecc * ecc);
-            const double size = r * kRsun + Rh * kRsun;
-            const double Ptra = size / sm * e_corr, Ptra2 = size / sm2 * e_corr;
-            const bool coll = size > sm * (1.0 - ecc);
-            const bool coll2 = (2.0 * Rh * kRsun) > sm2 * (1.0 - ecc);
-            bool m1 = transits(Ptra, inc, parallel) && !coll && (q < 0.95) && extra;
-            bool m2 = transits(Ptra2, inc, parallel) && !coll2 && (q >= 0.95) && extra;
-            if (!parallel) m2 = m2 && (Ptra <= 1.0);      // the loop `continue`s before the twin test
-            a.mask[i] = m1 ? 1 : 0;
-            a.mask_twin[i] = m2 ? 1 : 0;
-            hits += m1 ? 1 : 0;
-            hits_twin += m2 ? 1 : 0;
-            col[0 * N] = r; col[1 * N] = fr; col[2 * N] = P; col[3 * N] = inc; col[4 * N] = sm;
-            col[5 * N] = Rh; col[6 * N] = u1; col[7 * N] = u2; col[8 * N] = ecc; col[9 * N] = w;
-            col[10 * N] = frc; col[11 * N] = sm2; col[12 * N] = m; col[13 * N] = Mh;
-            if (a.prior == TRX_PRIOR_BOUND_EB) {
-                double term = ratio(frc);
-                if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); term = ratio(f / (f + a.f0_band)); }
-                if (a.host == TRX_HOST_COMPANION) {
-                    // lnZ_SEB: the companion AND its EB count (marginal_likelihoods.py:1202-1205)
-                    double fe = fr;
-                    if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, m); fe = f / (f + a.f0_band); }
-                    term = term + ratio(fe);
-                }
-                dm = 2.5 * log10(term);
-                dm_set = true;
-                lnprior = bound_rate(a, T, fabs(dm), true);
-            } else if (a.prior == TRX_PRIOR_FIELD && a.host == TRX_HOST_FIELD) {
-                // lnZ_BEB: background star + its EB (marginal_likelihoods.py:2161-2208)
-                double term;
-                if (a.use_cc) {
-                    const double frc_cc = a.f_frband[k];
-                    const double fmb = flux_rel(T, TRX_SPL_F_BAND, m);
-                    const double fr_cc = (fmb / (fmb + a.f0_band)) * (frc_cc / fh_band_share);
-                    term = ratio(frc_cc) + ratio(fr_cc);
-                } else {
-                    term = ratio(frc) + ratio(fr);
-                }
-                dm = 2.5 * log10(term);
-                dm_set = true;
-            }
-        }
-        if (a.prior == TRX_PRIOR_FIELD) {
-            if (!dm_set) {
-                // D scenarios and lnZ_BTP: the field star alone
-                dm = a.use_cc ? a.f_delta[k] : 2.5 * log10(ratio(frc));
-            }
-            if (a.use_cc) {
-                const double s = interp(T.cc_con, T.cc_sep, a.n_cc, fabs(dm));
-                lnprior = log(a.bg_amp * (s * s));
-            } else {
-                lnprior = a.bg_const;
-            }
-        }
-        if (a.prior == TRX_PRIOR_BOUND_TP || a.prior == TRX_PRIOR_BOUND_EB || a.prior == TRX_PRIOR_FIELD) {
-            lnprior = (lnprior > 0.0) ? 0.0 : lnprior;     // clamp_max: NaN stays NaN
-            if (dm > 0.0) lnprior = -INFINITY;
-        }
-        if (a.lnprior) a.lnprior[i] = lnprior;
-        if (a.dump) {
-            double* dd = a.dump + i;
-            dd[0 * N] = dP; dd[1 * N] = dQc; dd[2 * N] = dRp; dd[3 * N] = dInc; dd[4 * N] = dQ;
-            dd[5 * N] = dEcc; dd[6 * N] = dW; dd[7 * N] = (double)k; dd[8 * N] = dBeta;
-        }
+    const long i_end = ((long)(blockIdx.x + 1) * per < N) ? (long)(blockIdx.x + 1) * per : N;
+    for (long i = (long)blockIdx.x * per + threadIdx.x; i < i_end; i += blockDim.x) {
+        bool h0, h1;
+        draw_one<1>(a, T, i, parallel, h0, h1);
+        hits += h0 ? 1 : 0;
+        hits_twin += h1 ? 1 : 0;
     }
-    if (blk_cnt) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            hits += __shfl_xor(hits, o, 64);
-            hits_twin += __shfl_xor(hits_twin, o, 64);
-        }
-        if ((threadIdx.x & 63) == 0) { wave_cnt[0][threadIdx.x >> 6] = hits; wave_cnt[1][threadIdx.x >> 6] = hits_twin; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            blk_cnt[blockIdx.x] = wave_cnt[0][0] + wave_cnt[0][1] + wave_cnt[0][2] + wave_cnt[0][3];
-            blk_cnt[gridDim.x + blockIdx.x] = wave_cnt[1][0] + wave_cnt[1][1] + wave_cnt[1][2] + wave_cnt[1][3];
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        hits += __shfl_xor(hits, o, 64);
+        hits_twin += __shfl_xor(hits_twin, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { wave_cnt[0][threadIdx.x >> 6] = hits; wave_cnt[1][threadIdx.x >> 6] = hits_twin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_cnt[blockIdx.x] = wave_cnt[0][0] + wave_cnt[0][1] + wave_cnt[0][2] + wave_cnt[0][3];
+        blk_cnt[gridDim.x + blockIdx.x] = wave_cnt[1][0] + wave_cnt[1][1] + wave_cnt[1][2] + wave_cnt[1][3];
+    }
+}
+
+// The columns and the prior of the draws that passed a mask: idx0 / idx1 are the ordered lists of compact_kernel
+// (n_dev[0], n_dev[1] entries; a draw passes at most one of the two masks of a binary scenario), grid-stride
+// over both.  Draw 0 is always filled: it stands in for the best draw of a branch no draw passed.
+__global__ __launch_bounds__(256) void fill_kernel(trx_draw_args a, const int* __restrict__ idx0,
+                                                   const int* __restrict__ idx1, const long* __restrict__ n_dev)
+{
+    __shared__ Tables T;
+    const long n0 = n_dev[0], n1 = idx1 ? n_dev[1] : 0, total = n0 + n1 + 1;
+    if ((long)blockIdx.x * blockDim.x >= total) return;
+    stage_tables(a, T);
+    const bool parallel = a.parallel != 0;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x) {
+        const long i = (j < n0) ? (long)idx0[j] : ((j < n0 + n1) ? (long)idx1[j - n0] : 0L);
+        bool h0, h1;
+        draw_one<2>(a, T, i, parallel, h0, h1);
     }
 }
 
@@ -476,5 +542,17 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
     hipLaunchKernelGGL(draw_kernel, dim3((unsigned)groups), dim3(256), 0, st, a, blk_cnt, per);
     *per_out = per;
     *groups_out = groups;
+    return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
+}
+
+// The columns (and the prior) of the draws on the compacted lists: see fill_kernel.  The lists' lengths are on
+// the device, so the grid is sized for a sixth of the draws -- more than the geometry lets through at the
+// reference's priors -- and strides over whatever there is.
+int trx::fill_draws(const trx_draw_args& a, const int* idx0, const int* idx1, const long* n_dev, hipStream_t st)
+{
+    if (a.N < 1 || !idx0 || !n_dev) return TRX_ERR_ARG;
+    long blocks = (a.N / 6 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx0, idx1, n_dev);
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }

@@ -53,8 +53,10 @@ int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, lon
 
 // trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
 // [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)
-constexpr int kDrawMaxGroups = 4096;
+constexpr int kDrawMaxGroups = 2048;
 int draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* groups_out, hipStream_t st);
+// the columns and the prior of the draws that passed a mask (lists of compact_kernel), enqueued behind it
+int fill_draws(const trx_draw_args& a, const int* idx0, const int* idx1, const long* n_dev, hipStream_t st);
 
 // fail() of trx_kernels.hip for the other translation units (thread-local message of trx_last_error)
 int fail_hip(hipError_t e);

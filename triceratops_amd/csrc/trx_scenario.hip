@@ -4,18 +4,21 @@
 // Round 2's version strung the call together from 12 (planet) or 23 (binary) launches and synchronised
 // the stream twice: the number of draws that pass the geometry mask sized the likelihood launch, so the
 // host had to read it.  Here the count never leaves the device:
-//   draw_kernel         the per-draw half of the scenario (trx_draw.hip); workgroup b takes draws
-//                       [b per, (b + 1) per) and also leaves its mask counts
+//   draw_kernel         the geometry mask(s) of every draw (trx_draw.hip: what does not feed a mask is not
+//                       computed, no column is written); workgroup b takes draws [b per, (b + 1) per) and
+//                       leaves its mask counts
 //   compact_kernel      ordered compaction of the mask(s): a workgroup sums the counts of the workgroups
 //                       before it and appends the indices of its own masked draws, ascending (the order
 //                       numpy's / torch's nonzero gives) -> idx[branch][], n[branch]
+//   fill_kernel         the parameter columns and the prior of the listed draws only (the 5-10 % that passed),
+//                       recomputed from the same counter-based random numbers
 //   rowc_kernel         } the likelihood of the masked draws, read IN PLACE from the draw kernel's columns
 //   cells_kernel        } through idx (no gathered parameter block); the row count is read from n[branch]
 //                         on the device and the grids are sized for a guess (trx_kernels.hip)
 //   lme_partial_kernel  first pass of the log-mean-exp and of the search for the smallest chi^2, one pass
 //   final_kernel        the evidence, the best draw (first of equals, NaN first: numpy's / torch's
 //                       argmin), its columns, the masked count and the limb-darkening flag -> one record
-// 6 launches for a planet scenario, 9 for a binary one (two branches), one 264-byte copy to the host,
+// 7 launches for a planet scenario, 10 for a binary one (two branches), one 264-byte copy to the host,
 // NO sync: a caller can enqueue every lnZ_* call of a calc_probs on a few streams and wait once
 // (trx_scenario_enqueue); trx_scenario_evidence is the same followed by one hipStreamSynchronize.
 // Every buffer lives in the stream's scratch (trx_internal.hpp).  Results are bit for bit those of the
@@ -180,6 +183,7 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
     if (int rc = trx::draw_counted(d, A.at<int>(o_cnt), &per, &groups, st)) return rc;
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)groups, (unsigned)nbr), dim3(256), 0, st, d.mask, d.mask_twin, N, per,
                        A.at<int>(o_cnt), idx[0], idx[1], n_dev);
+    if (int rc = trx::fill_draws(d, idx[0], idx[1], n_dev, st)) return rc;
     for (int b = 0; b < nbr; ++b) {
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
         const double* bounds = nullptr;
