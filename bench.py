@@ -650,9 +650,9 @@ def run_batch(ctx):
         "vs_baseline": None, "dtype": "f32 model / f64 orbit+accumulators" if args.fp32_model else "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
-                               "light curves, calc_probs_many with device-side sampling, %d host thread(s) per rank, every lnZ_* call enqueued without a host sync on one of 3 streams; "
+                               "light curves, calc_probs_many with device-side sampling, %d host thread(s) per rank, every lnZ_* call enqueued without a host sync on one of %d streams; "
                                "value counts the (draw, time) cells that pass the geometry mask and are evaluated (the draws that lnL_EB_p's secondary-eclipse rule excludes are not: rows_not_evaluated_per_step)"
-                               % (args.tois, args.batch_n, args.n_time, args.threads),
+                               % (args.tois, args.batch_n, args.n_time, args.threads, __import__("triceratops_amd.sharding", fromlist=["streams"]).streams),
                    "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
                    "evaluated_cells_per_step": float(cells[0]) / args.steps,
                    "evaluated_rows_per_step": (float(cells[1]) - float(cells[2])) / args.steps,

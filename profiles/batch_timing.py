@@ -15,10 +15,10 @@ tri, cc = os.path.join(GOLD, "trilegal_synth.csv"), os.path.join(GOLD, "contrast
 jobs = synth.toi_jobs(tois, n_time=200, N=N, seed=synth.SEED, trilegal_fname=tri, contrast_curve_file=cc)
 small = synth.toi_jobs(2, n_time=200, N=20000, seed=synth.SEED, trilegal_fname=tri, contrast_curve_file=cc)
 triceratops_amd.calc_probs_many(small)
-for streams in (1, 2, 3, 4, 6):
+for streams in (1, 2, 3, 4, 6, 8, 12):
     sharding.streams = streams
     best = None
-    for rep in range(3):
+    for rep in range(5):
         np.random.seed(5 + rep)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

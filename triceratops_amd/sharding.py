@@ -34,7 +34,10 @@ threads = 1
 # is enqueued without any host synchronisation (trx_scenario_enqueue), so the thread enqueues every
 # unit, the streams overlap the small kernels of one call with the large ones of another, and the
 # results are read after one wait.  The library keeps ~0.3 GB of scratch per stream at N = 1e6.
-streams = int(os.environ.get("TRX_STREAMS", "3"))
+# Six: a call is a chain of dependent launches, most of them small, so a stream keeps the chip busy only
+# while its likelihood kernel runs; measured on 64 TOIs x 18 scenarios (profiles/batch_timing.py): 0.54 s a
+# step on one stream, 0.49 on three, 0.43 on six, no gain beyond.
+streams = int(os.environ.get("TRX_STREAMS", "6"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
 timing = {"enqueue_s": 0.0, "wait_s": 0.0}
 
@@ -181,8 +184,14 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         try:
             import time
             t0 = time.perf_counter()
-            for j, k in enumerate(mine_k):
-                with torch.cuda.stream(pool[j % len(pool)]):
+            # each call goes to the stream with the least work queued so far (by the schedule's cost weights):
+            # dealt round-robin, the planet calls and the dearer binary calls of a star's twelve end up on
+            # different streams whenever their number divides twelve, and the step waits for the slowest
+            load = [0.0] * len(pool)
+            for k in mine_k:
+                j = min(range(len(pool)), key=lambda i: (load[i], i))
+                load[j] += _COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
+                with torch.cuda.stream(pool[j]):
                     one(k)
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
