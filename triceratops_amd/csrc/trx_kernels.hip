@@ -80,7 +80,8 @@ struct RowsArgs {
                        // that does not apply returns; 2: only the instantiation the memo predicts is enqueued
     int skip_excl;     // cells_kernel<lnl>: rows the EB secondary rule excludes (+inf whatever the model) are not evaluated
     int* memo;         // rowc_kernel: where to leave the verdict for later launches on this light curve (or null)
-    int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS
+    int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS (shared by the workgroup's waves)
+    int wave_off, wave_doubles;   // cells_kernel: offset of the first wave's own LDS block and the size of one (in doubles)
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     // Rows counted on the device (trx_scenario_evidence: the draws that passed the geometry mask): when
     // n_dev is set the kernels read the row count from it and `n` is only its upper bound (grid, scratch);
@@ -180,6 +181,16 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 //   * LONG: the row constants ride in scalar registers, time stamps and fluxes are read from global
 //     memory, and the lanes sum (f-m)^2/sigma^2 directly (a perfect fit gives exactly 0); a row
 //     with a flat model takes the launch's flat-model value, so those rows tie exactly as well.
+// Waves per workgroup of the batched variant (rows of short light curves, several per wave).  Every wave works
+// through its own batches; what the waves of a workgroup share is read-only LDS -- the staged light curve, the
+// node tables -- so four of them hold one copy instead of four and five waves per SIMD fit the CU's 160 KB
+// where four did (the variant needs < 102 VGPRs).  One row per wave (LONG): the light curve stays in global
+// memory, nothing to share, one wave per workgroup.
+#ifndef TRX_BATCH_WAVES
+#define TRX_BATCH_WAVES 4
+#endif
+constexpr int kBatchWaves = TRX_BATCH_WAVES;
+__host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows ? 1 : kBatchWaves; }
 #ifndef TRX_CELLS_WAVES_PER_EU
 #define TRX_CELLS_WAVES_PER_EU 4
 #endif
@@ -537,6 +548,18 @@ __device__ __forceinline__ void tighten_bounds(double* hdr, double h, double x)
         __hip_atomic_fetch_max(&hdr[kHdrXmax], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The lanes of a wave exchange data through LDS (pair tables, cell state, row accumulators).  LDS operations of
+// one wave are issued and performed in order, so all the hand-over needs is that the compiler keeps them in
+// program order and re-reads memory afterwards: a fence at wavefront scope, no instruction.  (A workgroup
+// barrier would also do for one wave per workgroup, but the waves of the batched variant run independent
+// loops of different lengths.)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // PRUNE (trx_scenario_evidence; MODE_LNL, no stencil): bounded evaluation.  The evidence is a sum of
 // exp(c0 - chi^2/2 + lnprior) over the rows and the reduction drops every term more than 80 below the
 // largest (lme_partial_kernel: it cannot change an fp64 sum that is >= 1); the best draw is the row with
@@ -554,15 +577,20 @@ template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE>
 __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_radius)
 {
     static_assert(!PRUNE || (MODE == MODE_LNL && !ST), "bounded evaluation: likelihood mode, no stencil");
-    extern __shared__ double lds[];
+    extern __shared__ double lds_all[];
+    constexpr int W = cells_waves(LONG);
+    const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
+    // shared by the workgroup's waves: node tables, atan constants, (short curves) the light curve
+    double* tier_xw = lds_all;
+    double* atab = tier_xw + 2 * kTiers * kTierMaxNodes;             // atan_pos_tab's range constants
+    // this wave's own: row blocks, accumulators, pair table, in-window list, cell state
+    double* lds = lds_all + a.wave_off + (size_t)wave * a.wave_doubles;
     const int Bl = LONG ? 1 : a.B;                                    // rows the LDS layout holds
     RowC* rows = reinterpret_cast<RowC*>(lds);
     double* hacc = lds + (size_t)Bl * kRowDoubles;                    // [Bl] chi^2 corrections per row
     double* hmout = hacc + Bl;                                        // [Bl] diluted model of an unocculted cell: 1, or NaN
     double* hrem = hmout + Bl;                                        // [Bl] PRUNE: (f - 1)^2 / s2 over the row's in-window cells not done yet
-    double* tier_xw = hrem + Bl;
-    double* atab = tier_xw + 2 * kTiers * kTierMaxNodes;             // atan_pos_tab's range constants
-    unsigned short* pdesc = reinterpret_cast<unsigned short*>(atab + kAtanRanges * kAtanCols);   // [kCellsPairs] pair -> cell lane | node << 6
+    unsigned short* pdesc = reinterpret_cast<unsigned short*>(hrem + Bl);   // [kCellsPairs] pair -> cell lane | node << 6
     constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
@@ -570,18 +598,18 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // short curves: the light curve itself in LDS -- every chunk reads time stamps and fluxes of
     // arbitrary cells, and a global load right before its use costs more than the chunk's other
     // "rest" work
-    const double* tl = LONG ? a.time : (lds + a.tl_off);              // [n_time]
+    const double* tl = LONG ? a.time : (lds_all + a.tl_off);          // [n_time]
     const double* fl = LONG ? a.flux : (tl + a.n_time);               // [n_time] (MODE_LNL)
     // the node tables into LDS as (node offset, weight) pairs (one 16-byte read per pair), an entry per lane: a
     // loop on one lane was 420 wave instructions per workgroup -- 3 % of a batch at 100 points
     if (a.use_tiers) {
-        for (int i = threadIdx.x; i < kTiers * kTierMaxNodes; i += 64) {
+        for (int i = threadIdx.x; i < kTiers * kTierMaxNodes; i += 64 * W) {
             tier_xw[2 * i] = a.tiers.x[i];
             tier_xw[2 * i + 1] = a.tiers.w[i];
         }
     }
     if (threadIdx.x < kAtanRanges * kAtanCols) atab[threadIdx.x] = kAtanTable[threadIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const double rs2 = a.rs2;
     const int n_time = a.n_time;
@@ -603,12 +631,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     TRX_TICK(t_all);
 #endif
     if (!LONG) {
-        double* tw = lds + a.tl_off;
-        for (int j = lane; j < n_time; j += 64) {
+        double* tw = lds_all + a.tl_off;
+        for (int j = threadIdx.x; j < n_time; j += 64 * W) {
             tw[j] = a.time[j];
             if (MODE == MODE_LNL) tw[n_time + j] = a.flux[j];
         }
     }
+    if (W > 1) __syncthreads();       // the only workgroup barrier: from here on every wave is on its own
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
     const double* hdr = a.rowc + n * kRowDoubles;
     const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
@@ -624,7 +653,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes)
     const bool probing = PRUNE && a.pstride > 1 && a.part != 1 && hdr[kHdrProbe] != 0.0;
     const long per_xcd = (nbatch + 7) / 8;
-    for (long v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
+    // workgroups go round the 8 XCDs (blockIdx & 7) and an XCD's waves take consecutive batches of its share
+    // of the rows, whose blocks then stay in that XCD's L2
+    const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
+    for (long v = v0; v < 8 * per_xcd; v += (long)gridDim.x * W) {
         const long batch = (v & 7) * per_xcd + (v >> 3);
         if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
         const long base = row0 + batch * B;
@@ -636,7 +668,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             double* dst = reinterpret_cast<double*>(rows);
             for (int i = lane; i < nb * kRowDoubles; i += 64) dst[i] = src[i];
         }
-        __syncthreads();
+        wave_sync();
         if (lane < nb) {
             const RowC& c = rows[lane];
             hacc[lane] = 0.0;
@@ -646,7 +678,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             m1 = fma(-(1.0 - m1), c.rdil, 1.0);
             hmout[lane] = m1;
         }
-        __syncthreads();
+        wave_sync();
         // lnL_EB_p returns +inf for a draw whose secondary eclipse is deeper than 1.5 sigma, whatever its
         // light curve looks like (likelihoods.py:535-538): such rows are not evaluated at all
         unsigned long long skipmask = 0;
@@ -655,7 +687,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             if (lane == 0 && skipmask) atomicAdd(&g_skipped_rows, (unsigned long long)__popcll(skipmask));
             if (LONG && skipmask) {                  // the wave's only row: done
                 if (lane == 0) a.out[base] = INFINITY;
-                __syncthreads();
+                wave_sync();
                 continue;
             }
         }
@@ -729,7 +761,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (inw) winlist[nw + lanes_below(mw)] = (unsigned short)(cell - win0);
                 nw += __popcll(mw);
             }
-            __syncthreads();
+            wave_sync();
             TRX_TOCK(1, t_p1);
             // pass 2: the in-window cells, 64 at a time.  A cell next to a limb contact evaluates
             // all S sub-exposures, the others 3-9 nodes: the first sweep only files those cells
@@ -838,7 +870,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                                                                 : lane_prefix<10>(cnt + extra, total);
                     for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
                     if (extra) pdesc[off + cnt] = (unsigned short)(lane | (kCentreNode << 6));
-                    __syncthreads();
+                    wave_sync();
                     // one pair per lane: the orbit stepped from the cell's centre solution (|dM| <=
                     // half an exposure), the Mandel-Agol flux, and the node's term added to the
                     // cell's sum in LDS (ds_add_f64; a cell's pairs sit in consecutive lanes and the
@@ -885,7 +917,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             }
                         }
                     }
-                    __syncthreads();
+                    wave_sync();
                 }
                 TRX_TOCK(3, t_a);
                 TRX_TICK(t_rest);
@@ -934,7 +966,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 TRX_TOCK(5, t_rest);
             }
             }
-            __syncthreads();
+            wave_sync();
             if (PRUNE && nphase == 2 && phase_no == 0) {
                 // the verdict after the probe cells (and, for free, every out-of-window cell)
                 const double* hdr_b = a.rowc + n * kRowDoubles;
@@ -967,13 +999,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     deadmask |= md;
                     skipmask |= md;
                     if (lane == 0 && md) atomicAdd(&g_pruned_rows, (unsigned long long)__popcll(md));
-                    __syncthreads();
+                    wave_sync();
                 }
             }
             }
             if (PRUNE && LONG && long_dead) break;
         }
-        if (PRUNE && LONG && long_dead) { __syncthreads(); continue; }
+        if (PRUNE && LONG && long_dead) { wave_sync(); continue; }
         if (MODE == MODE_LNL) {
             if (LONG) {
                 // a row whose model is flat over the data takes the launch's flat-model value, so
@@ -1009,7 +1041,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 #ifdef TRX_PHASE_TIMERS
     TRX_TOCK(7, t_all);
@@ -1027,7 +1059,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // light curve) is harmless -- the stencil instantiation falls back to the Gauss nodes when the
 // device finds no uniform grid, the other one never uses the stencil.
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
-__global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+__global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
 {
     if (a.n_dev) {
         // the grid was sized for an upper bound of the row count: the blocks beyond the batches leave at once
@@ -1042,7 +1074,8 @@ __global__ __launch_bounds__(64, TRX_CELLS_WAVES_PER_EU) void cells_kernel(RowsA
             const long np = nd < kPilotRows ? nd : kPilotRows;
             rows_here = a.part == 1 ? np : nd - np;
         }
-        if ((long)blockIdx.x >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
+        // (the first batch index of this workgroup's first wave, see cells_body)
+        if ((long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * cells_waves(LONG)) >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
     }
     double st_radius = 0.0;
     if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
@@ -1617,8 +1650,8 @@ void launch_pruned(const RowsArgs& a, hipStream_t st, bool long_rows, bool fp32,
             if (fp32) hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, true, true, false, true>), dim3(grid), dim3(64), lds, st, a);
             else      hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, false, true, false, true>), dim3(grid), dim3(64), lds, st, a);
         } else {
-            if (fp32) hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, true, false, false, true>), dim3(grid), dim3(64), lds, st, a);
-            else      hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, false, false, false, true>), dim3(grid), dim3(64), lds, st, a);
+            if (fp32) hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, true, false, false, true>), dim3(grid), dim3(64 * kBatchWaves), lds, st, a);
+            else      hipLaunchKernelGGL((cells_kernel<MODE_LNL, true, false, false, false, true>), dim3(grid), dim3(64 * kBatchWaves), lds, st, a);
         }
     }
 }
@@ -1640,15 +1673,17 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
     // keeps 2-11 % of them, so the grid takes a quarter of the bound -- blocks
     // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
-    auto grid_for = [&](long batches) -> unsigned {
+    // (a workgroup is cells_waves() waves, each with its own batches; a multiple of 8 workgroups: one per XCD)
+    auto grid_for = [&](long batches, bool long_variant) -> unsigned {
         if (a.n_dev) {
             batches = (batches + 3) / 4;
             batches = batches < 4096 ? 4096 : batches;
         }
-        const long want = 8 * ((batches + 7) / 8);
+        const long groups = (batches + cells_waves(long_variant) - 1) / cells_waves(long_variant);
+        const long want = 8 * ((groups + 7) / 8);
         return (unsigned)(want < max_grid ? want : max_grid);
     };
-    const unsigned grid = grid_for(a.nbatch);
+    const unsigned grid = grid_for(a.nbatch, long_rows);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
     // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
@@ -1675,21 +1710,28 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
-    // rows, accumulators, node tables | pair table | in-window list | cell state | the staged light curve
-    size_t head = ((size_t)a.B * (kRowDoubles + 3) + 2 * kTiers * kTierMaxNodes + kAtanRanges * kAtanCols) * sizeof(double)
-                + (kCellsPairs + cells_window(long_rows)) * sizeof(unsigned short) + sizeof(CellState);
-    if (long_rows) head += sizeof(StencilState);
+    // LDS: [node tables | atan constants | the staged light curve (short curves)] shared by the workgroup's waves,
+    // then per wave [rows, accumulators | pair table | in-window list | cell state (| stencil state)]
     static_assert((kCellsPairs + kCellsWindowLong) % 4 == 0 && (kCellsPairs + kCellsWindowBatch) % 4 == 0 &&
-                  sizeof(CellState) % 8 == 0, "8-byte alignment of the LDS arrays");
-    a.tl_off = (int)(head / sizeof(double));
-    size_t lds = head + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
+                  sizeof(CellState) % 8 == 0 && sizeof(StencilState) % 8 == 0, "8-byte alignment of the LDS arrays");
+    const size_t tables = (size_t)(2 * kTiers * kTierMaxNodes + kAtanRanges * kAtanCols) * sizeof(double);
+    auto wave_bytes = [&](bool long_variant) -> size_t {
+        return (size_t)a.B * (kRowDoubles + 3) * sizeof(double)
+             + (kCellsPairs + cells_window(long_variant)) * sizeof(unsigned short) + sizeof(CellState)
+             + (long_variant ? sizeof(StencilState) : 0);
+    };
+    a.tl_off = (int)(tables / sizeof(double));
+    size_t shared = tables + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
+    size_t lds = shared + cells_waves(long_rows) * wave_bytes(long_rows);
     if (lds > 64 * 1024) {             // a long curve forced through the batched variant by a test knob
         long_rows = true;
-        head += sizeof(StencilState) + (kCellsWindowLong - kCellsWindowBatch) * sizeof(unsigned short);
-        lds = head;
         a.B = 1;
         a.nbatch = a.n;
+        shared = tables;
+        lds = shared + wave_bytes(true);
     }
+    a.wave_off = (int)(shared / sizeof(double));
+    a.wave_doubles = (int)(wave_bytes(long_rows) / sizeof(double));
     // the row constants: 144 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
@@ -1705,7 +1747,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
-    const unsigned g2 = long_rows ? grid_for(a.n) : grid;
+    const unsigned g2 = long_rows ? grid_for(a.n, true) : grid;
     t_last_rowc = a.rowc;
     t_last_pruned = prune;
     if (prune) {
@@ -1714,7 +1756,8 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         const long pilot_batches = long_rows ? np : (np + a.B - 1) / a.B;
         RowsArgs ap = a;
         ap.part = 1;
-        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_batches + 7) / 8)), lds);
+        const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
+        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
             hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc);
             ap.part = 2;
@@ -1732,9 +1775,9 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
             else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, true>), dim3(g2), dim3(64), lds, st, a);
         }
     } else {
-        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, false, false>), dim3(g2), dim3(64), lds, st, a);
-        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, false, false>), dim3(g2), dim3(64), lds, st, a);
-        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false, false>), dim3(g2), dim3(64), lds, st, a);
+        if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, false, false>), dim3(g2), dim3(64 * kBatchWaves), lds, st, a);
+        else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, false, false>), dim3(g2), dim3(64 * kBatchWaves), lds, st, a);
+        else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false, false>), dim3(g2), dim3(64 * kBatchWaves), lds, st, a);
     }
     const hipError_t launched = hipGetLastError();
     if (capturing) TRX_HIP(hipFreeAsync(scratch, st));
