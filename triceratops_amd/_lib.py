@@ -6,6 +6,7 @@ torch is used for device memory, streams and torch.distributed only.
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch  # noqa: F401  (imported first so libtrx binds to the HIP runtime torch loaded)
@@ -40,6 +41,15 @@ CELL_PACKING_BELOW = 320
 # work counters of the scenario layer (bench.py reads them): rows and (row, time) cells that
 # went through trx_lnz_scenario since the last reset
 STATS = {"rows": 0, "cells": 0, "launches": 0}
+_stats_lock = threading.Lock()
+
+
+def count_launch(rows, n_time):
+    """bench bookkeeping; the worker threads of sharding.threads update it side by side"""
+    with _stats_lock:
+        STATS["rows"] += rows
+        STATS["cells"] += rows * n_time
+        STATS["launches"] += 1
 # measurement hook (bench.py --mode batch): a list that receives, per trx_lnz_scenario launch,
 # (model, flags, n, n_time, start_event, end_event, first rows of the parameter block)
 TRACE = None
@@ -299,9 +309,7 @@ def lnz_scenario(model, flags, time_d, flux_d, sigma, params_d, exptime, nsample
     n = params_d.shape[1]
     device = params_d.device
     flags |= EXTRA_FLAGS
-    STATS["rows"] += n
-    STATS["cells"] += n * time_d.numel()
-    STATS["launches"] += 1
+    count_launch(n, time_d.numel())
     h = torch.empty(max(n, 1), dtype=torch.float64, device=device)
     out = torch.empty(1, dtype=torch.float64, device=device)
     ws = workspace(device)

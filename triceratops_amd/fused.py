@@ -153,9 +153,7 @@ class Pending:
             row = rec[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT]
             n = int(row[ncol + 1])
             with _stats_lock:
-                _lib.STATS["rows"] += n
-                _lib.STATS["cells"] += n * self.n_time
-                _lib.STATS["launches"] += 1
+                _lib.count_launch(n, self.n_time)
             res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
         return res[0] if planet else (res[0], res[1])
 
