@@ -8,12 +8,15 @@ rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/draw_${TAG} -- pyt
 python3 - <<PY
 import csv,glob,statistics,collections
 f=glob.glob("$R/gpurun_out/draw_${TAG}/*/*kernel_trace.csv")[0]
-rows=[r for r in csv.DictReader(open(f)) if "draw_kernel" in r["Kernel_Name"]]
-rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-rows=rows[-48:]
-d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in rows]
-per=collections.defaultdict(list)
-for j,x in enumerate(d): per[j%12].append(x)
+allrows=list(csv.DictReader(open(f)))
 names=["TP","EB","PTP","PEB","STP","SEB","DTP","DEB","BTP","BEB","NTP","NEB"]
-print("== ${TAG}: draw_kernel us per call, N = 1e6: "+"  ".join("%s %.0f"%(names[j],statistics.mean(per[j])) for j in range(12))+"   | mean %.1f"%statistics.mean(d))
+for kern in ("draw_kernel","fill_kernel"):
+    rows=[r for r in allrows if kern in r["Kernel_Name"]]
+    if not rows: continue
+    rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+    rows=rows[-48:]
+    d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in rows]
+    per=collections.defaultdict(list)
+    for j,x in enumerate(d): per[j%12].append(x)
+    print("== ${TAG}: %s us per call, N = 1e6: "%kern+"  ".join("%s %.0f"%(names[j],statistics.mean(per[j])) for j in range(12))+"   | mean %.1f"%statistics.mean(d))
 PY

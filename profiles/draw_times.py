@@ -1,8 +1,6 @@
-"""draw_kernel time per scenario: one calc_probs-like pass of the ten lnZ_* calls at N = 1e6 (device sampling),
-kernel durations from HIP events around each call would include the likelihood, so this script runs the draw
-kernel alone through trx_draw_scenario's counted variant -- via fused.DUMP-free calls under rocprofv3:
-    rocprofv3 --kernel-trace --stats -d out -- python3 profiles/draw_times.py
-and prints nothing itself; see profiles/draw_stats.sh."""
+"""Workload of profiles/draw_stats.sh: three passes over four synthetic TOIs (twelve lnZ_* calls each, N = 1e6,
+device sampling, ONE stream so that nothing overlaps); run under rocprofv3 --kernel-trace, the script
+prints nothing itself -- draw_stats.sh reads draw_kernel's and fill_kernel's durations from the trace."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
