@@ -286,12 +286,15 @@ typedef struct {
                                     lacks (the reference raises ValueError) */
     /* in-kernel random numbers: with use_philox = 1 every random input left NULL above is generated
      * in the kernel by Philox4x32-10, key = seed, counter = (draw index, slot, sub-draw): slot 0 P,
-     * 1 q_companion, 2 R_p, 3 inc, 4 q, 5 ecc (binaries), 6 argp, 7 field-star index, 8-9 the two
-     * gamma variates of the planets' Beta(0.867, 3.030) eccentricities (Marsaglia-Tsang).  A draw's
+     * 1 q_companion, 2 R_p, 3 inc, 4 q, 5 ecc (binaries), 6 argp, 7 field-star index (two slots share
+     * one counter block: (2 | 4, 3), (5, 6), (1 | 7, 0)), 8-9 the two gamma variates of the planets'
+     * Beta(0.867, 3.030) eccentricities (Marsaglia-Tsang, one block per attempt, fp32 arithmetic).  A draw's
      * numbers depend on (seed, draw index) only, not on N or on the launch geometry. */
     int use_philox;
     int range_P;                 /* the period is drawn from [P_lo, P_hi] (implied by uP != NULL) */
     long n_field_draw;           /* field-star index drawn from [0, n_field_draw) */
+    int pretest;                 /* trx_scenario_enqueue only: 1 = the geometry masks of the draws that fail a cheap fp32
+                                  * necessary condition are written as 0 without the fp64 evaluation (same masks) */
     unsigned long long seed;
     double* dump;                /* [9][N] or NULL (tests): the random numbers each draw used, rows =
                                     P q_c R_p inc q ecc_u argp index ecc_beta (as uniforms / values) */

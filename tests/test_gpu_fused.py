@@ -234,3 +234,78 @@ def test_in_kernel_random_numbers_depend_on_seed_and_draw_index_only():
         triceratops_amd.set_sampling("numpy")
     assert np.array_equal(out[0], out[1][:, :3000])          # same seed: the first draws do not depend on N
     assert not np.array_equal(out[0][2], out[2][2])           # another seed: other numbers
+
+
+@pytest.mark.parametrize("star", [(0.82, 0.8, 5100.0), (0.44, 0.43, 3600.0)], ids=["K", "M"])
+@pytest.mark.parametrize("name", NAMES)
+def test_fp32_pretest_of_the_geometry_leaves_the_masks_unchanged(name, star):
+    """trx_scenario_enqueue evaluates the fp64 geometry mask only for the draws that pass may_transit(), an fp32
+    necessary condition (csrc/trx_draw.hip).  With and without it: the same number of masked draws in either
+    branch, the same lnZ bits, the same best draw -- at N = 1e6, fixed period and period range, both `parallel`
+    semantics, a K dwarf and an M dwarf below the 0.45 M_sun switch of the planet-radius law."""
+    import triceratops_amd
+    from triceratops_amd import _lib, fused
+    from triceratops_amd import marginal_likelihoods as ml
+    triceratops_amd.set_sampling("device")
+    saved_rows, saved_pre = fused.TABLE_ROWS, fused.PRETEST
+    fused.TABLE_ROWS = 1                       # the native scenario call (what calc_probs uses)
+    try:
+        for P in (3.3, [2.5, 4.0]):
+            for parallel in (True, False):
+                out = []
+                for pre in (True, False):
+                    fused.PRETEST = pre
+                    torch.manual_seed(77)
+                    _lib.reset_stats()
+                    res = _call(ml, name, P=P, N=1_000_000, parallel=parallel, cc=CC, filt="J", star=star)
+                    out.append((res, _lib.STATS["rows"]))
+                (a, na), (b, nb) = out
+                assert na == nb and na > 0, (name, P, parallel, na, nb)
+                da = a if isinstance(a, tuple) else (a,)
+                db = b if isinstance(b, tuple) else (b,)
+                for x, y in zip(da, db):
+                    for k in y:
+                        assert np.array_equal(np.asarray(x[k]), np.asarray(y[k]), equal_nan=True), (name, P, parallel, k)
+    finally:
+        fused.TABLE_ROWS, fused.PRETEST = saved_rows, saved_pre
+        triceratops_amd.set_sampling("numpy")
+
+
+def _philox4x32_10(counter, key):
+    """Random123's Philox4x32-10 (known answer: zero counter and key -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8)"""
+    M = 0xffffffff
+    c, (k0, k1) = list(counter), key
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k0, p1 & M, (p0 >> 32) ^ c[3] ^ k1, p0 & M]
+        k0, k1 = (k0 + 0x9E3779B9) & M, (k1 + 0xBB67AE85) & M
+    return c
+
+
+def test_in_kernel_random_numbers_are_philox_blocks():
+    """the uniforms a draw used (dumped) against a Python restatement of the generator: key = the call's seed,
+    counter = (draw index, slot group, sub-draw); two 53-bit uniforms per block, numpy's construction"""
+    assert _philox4x32_10([0, 0, 0, 0], (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    import triceratops_amd
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    triceratops_amd.set_sampling("device")
+    fused.DUMP = []
+    try:
+        torch.manual_seed(5)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # what fused draws for the call
+        torch.manual_seed(5)
+        _call(ml, "TEB", P=[2.5, 4.0], N=5000, parallel=True, cc=None, filt="TESS")
+        d = fused.DUMP[0]["dump"].cpu().numpy()
+    finally:
+        fused.DUMP = None
+        triceratops_amd.set_sampling("numpy")
+    for i in (0, 1, 63, 64, 4999):
+        def pair(group):
+            r = _philox4x32_10([i, 0, 16 + group, 0], (seed & 0xffffffff, seed >> 32))
+            return (((r[0] >> 5) * 67108864 + (r[1] >> 6)) / 9007199254740992.0,
+                    ((r[2] >> 5) * 67108864 + (r[3] >> 6)) / 9007199254740992.0)
+        q, inc = pair(0)            # rows of the dump: 0 P, 3 inc, 4 q, 5 ecc, 6 argp
+        ecc, argp = pair(1)
+        _, P = pair(2)
+        assert (d[4, i], d[3, i], d[5, i], d[6, i], d[0, i]) == (q, inc, ecc, argp, P), i

@@ -24,7 +24,11 @@ constexpr double kG = 6.6743e-08, kMsun = 1.988409870698051e+33, kRsun = 6957000
                  kRearth = 637810000.0, kAu = 14959787070000.0;
 
 // ---- counter-based random numbers ------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011): ten rounds of two 32x32 -> 64 multiplies.
+// Philox4x32-10 (Salmon, Moraes, Dror & Shaw 2011): ten rounds of two 32x32 -> 64 multiplies (one v_mad_u64_u32
+// each) and three xors -- ~70 instructions a block.  (Threefry4x32-12 from the same paper -- adds, rotates and
+// xors only -- was tried on the assumption that the integer multiplies run at a quarter rate here: ~90
+// instructions a block, and the draw kernel got 8 % slower.)  Counter = (draw index lo, hi, slot, sub-draw),
+// key = the call's seed.
 struct U4 { unsigned x, y, z, w; };
 
 __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1)
@@ -41,12 +45,18 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1)
     return c;
 }
 
+// one block of 128 random bits for (seed, draw index, slot, sub-draw)
+__device__ __forceinline__ U4 random_block(unsigned long long seed, long i, unsigned slot, unsigned sub)
+{
+    return philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), slot, sub},
+                         (unsigned)seed, (unsigned)(seed >> 32));
+}
+
 // two uniforms in [0, 1) with 53 random bits each (numpy's construction: (a >> 5) 2^26 + (b >> 6))
 __device__ __forceinline__ void philox_uniform2(unsigned long long seed, long i, unsigned slot, unsigned sub,
                                                 double& u0, double& u1)
 {
-    const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), slot, sub},
-                               (unsigned)seed, (unsigned)(seed >> 32));
+    const U4 r = random_block(seed, i, slot, sub);
     u0 = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) * (1.0 / 9007199254740992.0);
     u1 = ((double)(r.z >> 5) * 67108864.0 + (double)(r.w >> 6)) * (1.0 / 9007199254740992.0);
 }
@@ -62,37 +72,46 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, long i
 // correctly rounded pow, whose double-double arithmetic is a third of this kernel's instructions
 __device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
 
-// Gamma(alpha, 1) by Marsaglia & Tsang (2000); alpha < 1 through Gamma(alpha + 1) U^(1/alpha).
-// One counter block per attempt: 53 bits for the radius of the Box-Muller normal, 32 for its angle, 32 for
-// the acceptance uniform.  The variate is a random DRAW, not a model quantity: its arithmetic runs in fp32 on
-// the hardware's log / cos / sqrt / exp (relative error ~1e-7, a shift of the sampled distribution far below
-// what 1e6 draws resolve; the fp64 libm versions were a third of a planet scenario's draw kernel).  The
-// normal's argument 1 - u0 keeps its fp64 exponent, so the tails reach 8.5 sigma.
-__device__ __forceinline__ double philox_gamma(unsigned long long seed, long i, unsigned slot, double alpha)
+// The planets' eccentricity, Beta(0.867, 3.030) (priors.py:146-148), as X / (X + Y) of two gamma variates by
+// Marsaglia & Tsang (2000); Gamma(0.867) through Gamma(1.867) U^(1/0.867).  ONE counter block per attempt
+// serves both variates: 32 bits for the radius and 32 for the angle of a Box-Muller pair -- its cosine branch
+// proposes for X, its sine branch for Y -- and 24 bits for each acceptance test; an attempt is repeated (next
+// block) for the variate(s) it did not settle.  The variate is a random DRAW, not a model quantity: its
+// arithmetic runs in fp32 on the hardware's log / cos / sqrt / exp (relative error ~1e-7, a shift of the sampled
+// distribution far below what 1e6 draws resolve; the fp64 libm versions were a third of a planet scenario's draw
+// kernel).  The radius' argument keeps its fp64 exponent (>= 2^-33): the normals reach 6.7 sigma.
+__device__ __forceinline__ double random_ecc_beta(unsigned long long seed, long i)
 {
-    const float a1 = (float)((alpha < 1.0) ? alpha + 1.0 : alpha);
-    const float d = a1 - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
-    float g = d;
-    for (unsigned att = 0; att < 64u; ++att) {
-        const U4 r = philox4x32_10(U4{(unsigned)i, (unsigned)((unsigned long long)i >> 32), slot, att + 1u},
-                                   (unsigned)seed, (unsigned)(seed >> 32));
-        const double u0 = ((double)(r.x >> 5) * 67108864.0 + (double)(r.y >> 6)) * (1.0 / 9007199254740992.0);
-        const float u1 = (float)r.z * (1.0f / 4294967296.0f);
-        const float u2 = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);       // in (0, 1)
-        const float x = sqrtf(-2.0f * __logf((float)(1.0 - u0))) * __cosf(6.2831853071795865f * u1);
-        const float t = 1.0f + c * x;
-        if (t <= 0.0f) continue;
-        const float v = t * t * t, x2 = x * x;
-        if (__logf(u2) < 0.5f * x2 + d * (1.0f - v + __logf(v))) { g = d * v; break; }
+    const float dx = 1.867f - 1.0f / 3.0f, dy = 3.030f - 1.0f / 3.0f;
+    const float cx = 1.0f / sqrtf(9.0f * dx), cy = 1.0f / sqrtf(9.0f * dy);
+    float gx = dx, gy = dy;
+    bool okx = false, oky = false;
+    for (unsigned att = 0; att < 64u && !(okx && oky); ++att) {
+        const U4 r = random_block(seed, i, 8u, att + 1u);
+        const float rad = sqrtf(-2.0f * __logf((float)(((double)r.x + 0.5) * (1.0 / 4294967296.0))));
+        const float ang = 6.2831853071795865f * ((float)r.y * (1.0f / 4294967296.0f));
+        const float ua = ((float)(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f);       // in (0, 1)
+        const float ub = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (!okx) {
+            const float x = rad * __cosf(ang), t = 1.0f + cx * x;
+            const float v = t * t * t;
+            if (t > 0.0f && __logf(ua) < 0.5f * x * x + dx * (1.0f - v + __logf(v))) { gx = dx * v; okx = true; }
+        }
+        if (!oky) {
+            const float y = rad * __sinf(ang), t = 1.0f + cy * y;
+            const float v = t * t * t;
+            if (t > 0.0f && __logf(ub) < 0.5f * y * y + dy * (1.0f - v + __logf(v))) { gy = dy * v; oky = true; }
+        }
     }
-    if (alpha < 1.0) {                      // sub-draw 0: the boost uniform
-        const float ub = (float)(1.0 - philox_uniform(seed, i, slot));
-        g *= __expf(__logf(ub) * (float)(1.0 / alpha));
-    }
-    return (double)g;
+    // sub-draw 0: the uniform that takes Gamma(1.867) to Gamma(0.867)
+    const float boost = (float)(1.0 - philox_uniform(seed, i, 8u));
+    gx *= __expf(__logf(boost) * (1.0f / 0.867f));
+    return (double)(gx / (gx + gy));
 }
 
 // ---- tables staged in LDS ------------------------------------------------------------------
+constexpr int kDrawChunk = 1024;        // draws a workgroup pre-tests before it regroups the candidates
+
 struct Tables {
     double spl[TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES];
     double cc_sep[TRX_DRAW_MAX_CC], cc_con[TRX_DRAW_MAX_CC];
@@ -220,6 +239,146 @@ __device__ __forceinline__ bool transits(double Ptra, double inc, bool parallel)
     return parallel ? hit : (hit && ok);
 }
 
+// A draw's uniform random inputs: the staged array, or the kernel's own counter-based stream.  One block yields
+// two 53-bit uniforms, and the eight inputs fall into three blocks whose halves no scenario needs both of more
+// than once: (R_p | q, inc), (ecc, argp), (q_comp | field index, P).
+// (the struct holds the seed, not the argument block: a reference to the kernel's by-value arguments would
+// force all 1.2 KB of them into scratch memory)
+struct Uniforms {
+    const unsigned long long seed;
+    const long i;
+    double u00, u01, u10, u11, u20, u21;
+    bool d0 = false, d1 = false, d2 = false;
+    __device__ __forceinline__ Uniforms(unsigned long long seed_, long i_) : seed(seed_), i(i_) {}
+    __device__ __forceinline__ double operator()(const double* staged, unsigned slot)
+    {
+        if (staged) return staged[i];
+        if (slot == 2u || slot == 4u || slot == 3u) {
+            if (!d0) { philox_uniform2(seed, i, 16u, 0u, u00, u01); d0 = true; }
+            return slot == 3u ? u01 : u00;
+        }
+        if (slot == 5u || slot == 6u) {
+            if (!d1) { philox_uniform2(seed, i, 17u, 0u, u10, u11); d1 = true; }
+            return slot == 6u ? u11 : u10;
+        }
+        if (!d2) { philox_uniform2(seed, i, 18u, 0u, u20, u21); d2 = true; }
+        return slot == 0u ? u21 : u20;
+    }
+};
+
+// ---- a cheap necessary condition for the geometry mask -------------------------------------------
+// Both masks of a scenario need cos(inc) <= P_tra and P_tra <= 1 (transits(): inc >= acos(P_tra), which no draw
+// meets at P_tra > 1), where P_tra = (R_1 + R_2) / a * (1 + e sin w) / (1 - e^2); the twin branch's P_tra at 2 P
+// is smaller still.  5-10 % of the draws meet it.  may_transit() evaluates the same chain -- the same
+// counter-based random numbers, samplers, mass-radius spline and Kepler's law -- in fp32 on the hardware's
+// log2 / exp2 / sin (relative error ~1e-5 at worst) and rejects a draw only when cos(inc) exceeds P_tra by more
+// than 0.1 %: the fp64 mask is then evaluated for the draws it lets through (draw_kernel, trx_scenario_enqueue's
+// path), regrouped so that its ~1600 fp64 instructions per draw run on full waves of candidates.  NaN anywhere
+// compares false and keeps the draw.  tests/test_gpu_fused.py holds the masks with and without the pre-test equal.
+__device__ __forceinline__ float pow_f(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+
+__device__ __forceinline__ float plaw_inv_f(const trx_power_law& L, float x)
+{
+    if (L.ones) return 1.0f;
+    const float t0 = x / (float)L.norm;
+    float arg = 0.0f, ip = 0.0f;
+    bool hit = false;
+    for (int j = 0; j < L.nseg; ++j) {
+        const bool sel = (j == 0) ? (x <= (float)L.hi[j]) : (x > (float)L.lo[j] && x <= (float)L.hi[j]);
+        if (sel) {
+            float t = (t0 - (float)L.cum[j]) * (float)L.p1[j];
+            if (L.amp[j] != 0.0) t = t / (float)L.amp[j];
+            arg = t + (float)L.base[j];
+            ip = (float)L.ip[j];
+            hit = true;
+        }
+    }
+    return hit ? pow_f(arg, ip) : x;
+}
+
+__device__ __forceinline__ float spline_eval_f(const double* s, float v)
+{
+    const int m = (int)s[0];
+    const double* x = s + 1;
+    int i = 0;
+    for (int k = 1; k < m; ++k) i += ((float)x[k] <= v) ? 1 : 0;
+    const float d = v - (float)x[i];
+    const double* c = x + TRX_DRAW_MAX_KNOTS;
+    return (((float)c[i] * d + (float)c[TRX_DRAW_MAX_KNOTS + i]) * d + (float)c[2 * TRX_DRAW_MAX_KNOTS + i]) * d +
+           (float)c[3 * TRX_DRAW_MAX_KNOTS + i];
+}
+
+// radius of funcs.stellar_relations in fp32 (the knots sit within 1e-6 of a node only for one draw in 10^6, and
+// there the two branches of the spline agree: it is continuous)
+__device__ __forceinline__ float stellar_radius_f(const Tables& T, float M, float maxR)
+{
+    float R = (M > 0.63f) ? spline_eval_f(T.spl[TRX_SPL_R_HOT], M) : spline_eval_f(T.spl[TRX_SPL_R_COOL], M);
+    if (M != M) R = 0.0f;
+    if (R > maxR) R = maxR;
+    return (R < 0.1f) ? 0.1f : R;
+}
+
+__device__ __forceinline__ bool may_transit(const trx_draw_args& a, const Tables& T, const long i)
+{
+    Uniforms rnd(a.seed, i);
+    bool unsure = false;          // an input sits on a branch point of the fp64 chain: left to the fp64 mask
+    // a [R_sun] = kSma (M [M_sun] P [d]^2)^(1/3)
+    const float kSma = 4.2082785f, kRe = (float)(kRearth / kRsun);
+    float P = (float)a.P_lo;
+    if (a.uP || a.range_P) P = (float)(a.P_lo + (a.P_hi - a.P_lo) * rnd(a.uP, 0u));
+    float mc = 0.0f;
+    long k = 0;
+    if (a.comp == TRX_COMP_BOUND) {
+        const float qc = a.qc_in ? (float)a.qc_in[i] : plaw_inv_f(a.law_qc, (float)rnd(a.uQc, 1u));
+        mc = qc * (float)a.M_s;
+    } else if (a.comp == TRX_COMP_FIELD) {
+        if (a.idx) k = a.idx[i];
+        else {
+            k = (long)(rnd(nullptr, 7u) * (double)a.n_field_draw);
+            k = k < a.n_field_draw ? k : a.n_field_draw - 1;
+        }
+    }
+    float Mh = (float)a.M_s, Rh = (float)a.R_s;
+    if (a.host == TRX_HOST_COMPANION) {
+        Mh = mc;
+        Rh = stellar_radius_f(T, mc, (float)a.R_s);
+        unsure = unsure || fabsf(mc - 0.63f) < 1e-4f;          // the two branches of the mass-radius relation
+    } else if (a.host == TRX_HOST_FIELD) {
+        Mh = (float)a.f_mass[k];
+        Rh = (float)a.f_radius[k];
+    }
+    const float cosi = (float)(1.0 - rnd(a.uInc, 3u));
+    const float sinw = __sinf((float)rnd(a.uW, 6u) * 6.2831853f);
+    float ecc, size, mtot;
+    if (a.planet) {
+        if (a.ecc_in) ecc = (float)a.ecc_in[i];
+        else {
+            ecc = (float)random_ecc_beta(a.seed, i);
+        }
+        const float dRp = (float)rnd(a.uRp, 2u);
+        float rp;
+        if (a.flat) rp = dRp * 19.5f + 0.5f;
+        else rp = (Mh > 0.45f) ? plaw_inv_f(a.law_rp_hi, dRp) : plaw_inv_f(a.law_rp_lo, dRp);
+        unsure = unsure || (!a.flat && fabsf(Mh - 0.45f) < 1e-4f);     // the two radius laws
+        size = rp * kRe + Rh;
+        mtot = Mh;
+    } else {
+        ecc = pow_f((float)rnd(a.uEcc, 5u), (float)a.ecc_pow);
+        const float q = plaw_inv_f(a.law_q, (float)rnd(a.uQ, 4u));
+        const float m = q * Mh;
+        size = stellar_radius_f(T, m, Rh) + Rh;
+        unsure = unsure || fabsf(m - 0.63f) < 1e-4f;
+        mtot = Mh + m;
+    }
+    const float sm = kSma * pow_f(mtot * P * P, 1.0f / 3.0f);
+    const float Ptra = size / sm * ((1.0f + ecc * sinw) / (1.0f - ecc * ecc));
+    // the twin branch of a binary scenario transits at 2 P: its P_tra is P_tra / 4^(1/3), the only one that can
+    // be <= 1 while P_tra itself is not
+    const float Pmin = a.planet ? Ptra : Ptra * 0.62996052f;
+    const bool reject = (cosi > Ptra * 1.001f + 1e-6f) || (Pmin > 1.001f);
+    return unsure || !reject;
+}
+
 // One draw: its random inputs, the scenario's parameters, the geometry mask(s), the prior.
 //   PHASE 0  everything (trx_draw_scenario: the torch-operator chain reads whole columns)
 //   PHASE 1  the mask(s) only -- what does not feed them (flux ratios, the prior) is not computed and no
@@ -232,21 +391,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
 {
     const long N = a.N;
     hit = hit_twin = false;
-    // a random input: the staged array, or the kernel's own Philox stream.  One counter block yields two
-    // 53-bit uniforms, and the eight inputs fall into three blocks whose halves no scenario needs both of
-    // more than once: (R_p | q, inc), (ecc, argp), (q_comp | field index, P)
-    double gu[3][2];
-    bool gdone[3] = {false, false, false};
-    auto rnd = [&](const double* staged, unsigned slot) -> double {
-        if (staged) return staged[i];
-        const int g = (slot == 2u || slot == 4u || slot == 3u) ? 0 : ((slot == 5u || slot == 6u) ? 1 : 2);
-        const int h = (slot == 3u || slot == 6u || slot == 0u) ? 1 : 0;
-        if (!gdone[g]) {
-            philox_uniform2(a.seed, i, 16u + (unsigned)g, 0u, gu[g][0], gu[g][1]);
-            gdone[g] = true;
-        }
-        return gu[g][h];
-    };
+    Uniforms rnd(a.seed, i);
     double dP = 0.0, dQc = 0.0, dRp = 0.0, dQ = 0.0, dEcc = 0.0, dIdx = 0.0, dBeta = 0.0;
     double P = a.P_lo;
     if (a.uP || a.range_P) { dP = rnd(a.uP, 0u); P = a.P_lo + (a.P_hi - a.P_lo) * dP; }
@@ -309,8 +454,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
     if (a.planet) {
         if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
         else {
-            const double gx = philox_gamma(a.seed, i, 8u, 0.867), gy = philox_gamma(a.seed, i, 9u, 3.030);
-            ecc = gx / (gx + gy);
+            ecc = random_ecc_beta(a.seed, i);
         }
         dBeta = ecc;
         dRp = rnd(a.uRp, 2u);
@@ -436,12 +580,14 @@ __device__ __forceinline__ void stage_tables(const trx_draw_args& a, Tables& T)
     __syncthreads();
 }
 
-// blk_cnt == null (trx_draw_scenario): every draw in full, grid-stride.
-// blk_cnt != null (trx_scenario_evidence): workgroup b takes the `per` consecutive draws from b * per, writes
+// KIND 0 (trx_draw_scenario): every draw in full, grid-stride.
+// KIND 1, 2 (trx_scenario_evidence; 2 = with the fp32 pre-test): workgroup b takes the `per` consecutive draws from b * per, writes
 // their mask(s) only and leaves the number of its draws that passed in blk_cnt[b] (and blk_cnt[gridDim.x + b]
 // for the twin branch) -- the first half of the ordered compaction (compact_kernel, trx_scenario.hip); the
 // columns of the draws that passed follow in fill_kernel.  A draw's numbers depend on its index only, so the
-// mapping of draws to threads changes no result.
+// mapping of draws to threads changes no result.  (Three kernels, not one with branches: with two inlined
+// copies of the draw in one kernel the compiler moved the 1.2 KB argument block into scratch memory.)
+template <int KIND>
 __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restrict__ blk_cnt, long per)
 {
     __shared__ Tables T;
@@ -450,7 +596,7 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restr
     const long N = a.N;
     const bool parallel = a.parallel != 0;
     int hits = 0, hits_twin = 0;
-    if (!blk_cnt) {
+    if (KIND == 0) {
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
             bool h0, h1;
             draw_one<0>(a, T, i, parallel, h0, h1);
@@ -458,11 +604,37 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restr
         return;
     }
     const long i_end = ((long)(blockIdx.x + 1) * per < N) ? (long)(blockIdx.x + 1) * per : N;
-    for (long i = (long)blockIdx.x * per + threadIdx.x; i < i_end; i += blockDim.x) {
-        bool h0, h1;
-        draw_one<1>(a, T, i, parallel, h0, h1);
-        hits += h0 ? 1 : 0;
-        hits_twin += h1 ? 1 : 0;
+    if (KIND == 1) {
+        for (long i = (long)blockIdx.x * per + threadIdx.x; i < i_end; i += blockDim.x) {
+            bool h0, h1;
+            draw_one<1>(a, T, i, parallel, h0, h1);
+            hits += h0 ? 1 : 0;
+            hits_twin += h1 ? 1 : 0;
+        }
+    } else {
+        // kDrawChunk draws at a time: the fp32 pre-test of all of them (may_transit), the candidates' indices
+        // regrouped through LDS, the fp64 mask of the candidates on full lanes
+        __shared__ int cand[kDrawChunk];
+        __shared__ int ncand;
+        for (long c0 = (long)blockIdx.x * per; c0 < i_end; c0 += kDrawChunk) {
+            if (threadIdx.x == 0) ncand = 0;
+            __syncthreads();
+            const long c1 = (c0 + kDrawChunk < i_end) ? c0 + kDrawChunk : i_end;
+            for (long i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
+                a.mask[i] = 0;
+                if (!a.planet) a.mask_twin[i] = 0;
+                if (may_transit(a, T, i)) cand[atomicAdd(&ncand, 1)] = (int)(i - c0);
+            }
+            __syncthreads();
+            const int nc = ncand;
+            for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+                bool h0, h1;
+                draw_one<1>(a, T, c0 + cand[j], parallel, h0, h1);
+                hits += h0 ? 1 : 0;
+                hits_twin += h1 ? 1 : 0;
+            }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -525,7 +697,7 @@ extern "C" int trx_draw_scenario(const trx_draw_args* args, void* stream)
     if (int rc = check_draw_args(a)) return rc;
     long blocks = (a.N + 255) / 256;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+    hipLaunchKernelGGL(draw_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a,
                        (int*)nullptr, 0L);
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }
@@ -539,7 +711,8 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
     long per = (a.N + kDrawMaxGroups - 1) / kDrawMaxGroups;
     per = ((per + 255) / 256) * 256;
     const int groups = (int)((a.N + per - 1) / per);
-    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)groups), dim3(256), 0, st, a, blk_cnt, per);
+    if (a.pretest) hipLaunchKernelGGL(draw_kernel<2>, dim3((unsigned)groups), dim3(256), 0, st, a, blk_cnt, per);
+    else           hipLaunchKernelGGL(draw_kernel<1>, dim3((unsigned)groups), dim3(256), 0, st, a, blk_cnt, per);
     *per_out = per;
     *groups_out = groups;
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;

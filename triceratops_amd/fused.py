@@ -89,7 +89,7 @@ class DrawArgs(ctypes.Structure):
                                       "uP", "uQc", "uRp", "uInc", "uQ", "uEcc", "uW", "ecc_in", "qc_in",
                                       "idx", "cols", "mask", "mask_twin", "lnprior", "flag")]
                 + [("use_philox", ctypes.c_int), ("range_P", ctypes.c_int), ("n_field_draw", ctypes.c_long),
-                   ("seed", ctypes.c_ulonglong), ("dump", _vp)])
+                   ("pretest", ctypes.c_int), ("seed", ctypes.c_ulonglong), ("dump", _vp)])
 
 
 class ScenarioArgs(ctypes.Structure):
@@ -106,6 +106,9 @@ SCENARIO_OUT = 16      # TRX_SCENARIO_OUT
 # generator) is ONE library call, trx_scenario_evidence; False: the chain of torch operators around
 # trx_draw_scenario / trx_lnz_scenario below (the path of the 100-row table; kept as cross-check)
 NATIVE = os.environ.get("TRX_NATIVE", "1") != "0"      # TRX_NATIVE=0: A/B runs of whole programs
+# the draw kernel's fp32 pre-test of the geometry (csrc/trx_draw.hip, may_transit): the fp64 mask is evaluated
+# only for the draws it lets through.  Same masks; TRX_PRETEST=0 / PRETEST = False evaluates every draw (tests)
+PRETEST = os.environ.get("TRX_PRETEST", "1") != "0"
 _bound = False
 _bound_scenario = False
 
@@ -569,6 +572,7 @@ class _Scenario:
         """the whole call in the library: draws, masks, compaction, likelihood, evidence, best draw --
         enqueued without a host synchronisation (trx_scenario_enqueue)"""
         a, dev = self.a, self.dev
+        a.pretest = int(PRETEST)
         sa = ScenarioArgs()
         sa.draw = ctypes.pointer(a)
         sa.time, sa.flux = self.time.data_ptr(), self.flux.data_ptr()
