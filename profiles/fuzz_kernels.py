@@ -96,6 +96,19 @@ while time.time() - t_start < budget:
     if not ok or df > 5e-13 + cond or df_big > 1e-11 + 10 * cond or dh > 1e-9:
         fails.append((n_time, exptime, S, kind, model, nrow, is_host, below, B, st, df, dh, ok))
         print("FAIL", fails[-1])
+        # where, and what the same launch gives with the Kepler stepping off (full solves everywhere) and with every
+        # sub-exposure evaluated: a difference that survives both is not the reduced node sets' nor the stepping's
+        i, j = np.unravel_index(np.nanargmax(np.where(np.isnan(d), -1, d)), d.shape)
+        print("   worst cell: row %d time %d  flux oracle %.15f  kernel %.15f  row parameters %s" % (i, j, gw[i, j], g[i, j], rows[:, i]))
+        for what, call in (("Kepler stepping off", lambda v: L.trx_set_kepler_stepping(v)), ("all sub-exposures", lambda v: L.trx_set_supersample_tiers(v))):
+            call(0)
+            try:
+                L.trx_set_cell_packing_below(below); L.trx_set_rows_per_wave(B); L.trx_set_stencil(st)
+                g2 = _lib.flux_grid(model, fl, t_d, r_d, exptime, S, want_secdepth=False)[0].cpu().numpy()
+            finally:
+                call(1)
+                L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW); L.trx_set_rows_per_wave(0); L.trx_set_stencil(1)
+            print("   %s: worst |dflux| %.3e (that cell: %.3e)" % (what, float(np.nanmax(np.abs(g2 - gw))), abs(g2[i, j] - gw[i, j])))
         if model == _lib.MODEL_RAW and df > 5e-13:
             dd = np.where(big[:, None], 0.0, np.nan_to_num(d))
             r, j = np.unravel_index(np.argmax(dd), dd.shape)
