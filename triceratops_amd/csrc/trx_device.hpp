@@ -518,8 +518,8 @@ __device__ __forceinline__ bool kepler_step(double dM, double e, double& sE, dou
             dc = fma(cE, c1, -sE * sd);  // cos(E+d) - cos E
             const double g = fma(-e, ds, d) - dM;
             const double gp = fma(-e, cE + dc, 1.0);
-            rho = rho * fma(-gp, rho, 2.0);              // Newton on 1/gp -- twice when a lane stops at its own
-            if (FREEZE) rho = rho * fma(-gp, rho, 2.0);  // first small step, which must then be a good one
+            rho = rho * fma(-gp, rho, 2.0);              // Newton on 1/gp, twice: what the last step (< 1e-9) leaves behind
+            rho = rho * fma(-gp, rho, 2.0);              // is step x (rho's relative error), see kepler_step_wide
             step = g * rho;
             d -= step;
             // a step below 1e-9 leaves an error ~ step^2: done after applying it
@@ -559,8 +559,13 @@ __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE
             dc = fma(cE, c1, -sE * sd);
             const double g = fma(-e, ds, d) - dM;
             const double gp = fma(-e, cE + dc, 1.0);
+            // Newton on 1 / g', twice: over a step of up to 0.3 rad g' moves by up to e x 0.3, one refinement leaves
+            // rho that far off squared, and what a last step of < 1e-9 leaves behind is step x (rho's relative
+            // error) -- with one refinement up to 1e-14 in E, which a wide orbit (a / R = 30) turns into several
+            // 1e-13 of flux where the Mandel-Agol expressions are badly conditioned (z near k; found by
+            // profiles/fuzz_kernels.py, profiles/r03_fuzz.txt).  The second refinement squares it away.
             rho = rho * fma(-gp, rho, 2.0);
-            if (FREEZE) rho = rho * fma(-gp, rho, 2.0);
+            rho = rho * fma(-gp, rho, 2.0);
             step = g * rho;
             d -= step;
             settled = fabs(step) < 1e-9;
