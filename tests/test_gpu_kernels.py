@@ -695,3 +695,24 @@ def test_rows_excluded_by_the_secondary_rule_are_skipped_not_changed():
         _lib.flux_grid(1, 0, t_d, r_d[:, :200].contiguous(), synth.EXPTIME, 20)
         _lib.check(L.trx_skipped_rows(ctypes.byref(n), 1))
         assert n.value == 0
+
+
+@pytest.mark.parametrize("below", [0, 1 << 30], ids=["one-row-per-wave", "batches"])
+def test_exposure_centres_stepped_from_conjunction_are_solved_to_rounding(below):
+    """A deep (45 %) eclipse on a wide eccentric orbit (a / R = 30, e = 0.37) sampled where the occulting disc's
+    edge crosses the star's centre: the Mandel-Agol expressions turn 2e-15 in z into several 1e-13 in flux there.
+    The exposure-centre solution reached by Newton steps from conjunction once carried 1e-14 in E (its running
+    reciprocal of g' was refined once per iteration) and this row came out 6e-13 off (profiles/r03_fuzz.txt)."""
+    row = np.array([1.23759087e+00, 5.99053086e-02, 2.87708804e+01, 8.93703694e+01, 3.03686223e+12, 1.44694079e+00,
+                    3.71469911e-01, 2.44530025e-01, 3.66301601e-01, 6.16838000e+01, 4.60773272e-02])[:, None]
+    rng = np.random.default_rng(3)
+    t = np.sort(np.linspace(-0.2, 0.2, 2000) + rng.uniform(-1e-4, 1e-4, 2000))
+    L = _lib.lib()
+    for exptime, S in ((0.005, 8), (0.005, 20), (0.00139, 20)):
+        want = O.flux_grid(_lib.MODEL_EB, t, row, companion_is_host=False, exptime=exptime, nsamples=S)[0]
+        L.trx_set_cell_packing_below(below)
+        try:
+            got = _lib.flux_grid(_lib.MODEL_EB, 0, _lib.dev(t), _lib.dev(row), exptime, S, want_secdepth=False)[0].cpu().numpy()
+        finally:
+            L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
+        assert np.max(np.abs(got - want)) < 1e-13, (exptime, S, float(np.max(np.abs(got - want))))
