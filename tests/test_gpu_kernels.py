@@ -428,10 +428,17 @@ def test_entry_points_capture_into_a_hip_graph_and_replay():
         rows = synth.tp_rows(rng, 2000, True)
         rows_d.copy_(_lib.dev(rows))              # new inputs in the captured buffers
         h_d.zero_()
+        torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
         want_h = O.lnl_batch(0, t, flux, synth.SIGMA, rows)
-        _cmp_h(h_d.cpu().numpy(), want_h)
+        got_h = h_d.cpu().numpy()
+        if not np.allclose(got_h, want_h, rtol=1e-6, atol=0, equal_nan=True):
+            # (seen once in ~20 runs of the whole suite and never in this file alone: say what the replay returned)
+            bad = np.flatnonzero(~np.isclose(got_h, want_h, rtol=1e-6, atol=0, equal_nan=True))
+            print("replay %d: %d of 2000 rows differ, first %s: got %s want %s; zeros in the output: %d"
+                  % (rep, bad.size, bad[:5], got_h[bad[:5]], want_h[bad[:5]], int((got_h == 0).sum())))
+        _cmp_h(got_h, want_h)
         lnL = np.full(20000, -np.inf)
         lnL[:2000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h + prior_d.cpu().numpy()
         assert abs(float(lnz_d.cpu()[0]) - O.log_mean_exp(lnL, 20000)) < 1e-9
