@@ -265,7 +265,8 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
     const int nb = (int)((n - base < 64) ? (n - base < 0 ? 0 : n - base) : 64);
     double ysec = 0.0, fdil = 0.0;
     double* dst = a.rowc + (base + lane) * kRowDoubles;
-    if (blk == 0 && a.flux && (lane >> 6) == 3) {
+    const bool one_wave = blockDim.x == 64;      // (no secondary scan: the first wave does block 0's extra duties too)
+    if (blk == 0 && a.flux && ((lane >> 6) == 3 || one_wave)) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
         double acc = 0.0;
@@ -285,7 +286,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             hdr[kHdrProbe] = 1.0;
         }
     }
-    if (blk == 0 && (lane >> 6) == 2) {
+    if (blk == 0 && ((lane >> 6) == 2 || one_wave)) {
         // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
         double* hdr = a.rowc + n * kRowDoubles;
         const int l = lane & 63, nt = a.n_time;
@@ -423,7 +424,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
     {
         const double* src = reinterpret_cast<const double*>(rows_out);
         double* out = a.rowc + base * kRowDoubles;
-        for (int i = lane; i < nb * kRowDoubles; i += 256) out[i] = src[i];
+        for (int i = lane; i < nb * kRowDoubles; i += (int)blockDim.x) out[i] = src[i];
     }
     // the scan decides the exclusion rule of lnL_EB_p (likelihoods.py:535-538) and the secdepth
     // output of simulate_EB_transit_p; lnL_EB_twin_p (:542-587) uses neither
@@ -486,9 +487,14 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
     }
 }
 
+// SEC: the launch needs the secondary-eclipse scan (256 threads per 64 rows: all four waves share it).  Without it
+// only the first wave of such a workgroup had work -- three working waves per CU, a serial chain of ~1500 fp64
+// instructions each: the kernel was latency-bound at a third of a CU's wave slots.  Those launches now take 64
+// threads per 64 rows and half the LDS: twelve working waves per CU (32 -> 13 us per 1e5 rows).
+template <bool SEC>
 __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
 {
-    __shared__ RowC srows[64];
+    __shared__ RowC srows[SEC ? 64 : 1];
     __shared__ RowC rows_out[64];
     __shared__ double secmin[64];
     __shared__ int secnan[64];
@@ -1743,7 +1749,8 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     {
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
-        hipLaunchKernelGGL(rowc_kernel, dim3((unsigned)rb), dim3(256), 0, st, a);
+        if (a.need_sec) hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb), dim3(256), 0, st, a);
+        else            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb), dim3(64), 0, st, a);
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
