@@ -265,8 +265,12 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
     const int nb = (int)((n - base < 64) ? (n - base < 0 ? 0 : n - base) : 64);
     double ysec = 0.0, fdil = 0.0;
     double* dst = a.rowc + (base + lane) * kRowDoubles;
-    const bool one_wave = blockDim.x == 64;      // (no secondary scan: the first wave does block 0's extra duties too)
-    if (blk == 0 && a.flux && ((lane >> 6) == 3 || one_wave)) {
+    // the launch's header (flat-model chi^2, stencil verdict): waves 3 and 2 of block 0 beside its rows -- or, in a
+    // launch of one-wave workgroups, a workgroup of its own (blk < 0: the last one of the grid), since a single wave
+    // doing them before its rows would be the launch's long pole on a 2000-point light curve
+    const bool one_wave = blockDim.x == 64;
+    const bool header_only = blk < 0;
+    if ((one_wave ? header_only : (blk == 0 && (lane >> 6) == 3)) && a.flux) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
         double acc = 0.0;
@@ -286,7 +290,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             hdr[kHdrProbe] = 1.0;
         }
     }
-    if (blk == 0 && ((lane >> 6) == 2 || one_wave)) {
+    if (one_wave ? header_only : (blk == 0 && (lane >> 6) == 2)) {
         // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
         double* hdr = a.rowc + n * kRowDoubles;
         const int l = lane & 63, nt = a.n_time;
@@ -348,6 +352,7 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             if (a.memo) *a.memo = (radius > 0.0) ? 2 : 1;
         }
     }
+    if (header_only) return;
     if (lane < nb) {
         // row r = column r of the [n_param][n] block, or draw src_idx[r] of a [n_param][src_stride] one
         const double* p = a.params + (a.src_idx ? (long)a.src_idx[base + lane] : base + lane);
@@ -502,6 +507,15 @@ __global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
     const long nblk = (n + 63) / 64;
     // one block of 64 rows per workgroup; with the row count on the device the grid is a guess and the
     // workgroups stride over the blocks (block 0 always runs: it writes the launch header)
+    if (!SEC) {
+        // (one-wave workgroups: the last one writes the launch header, the others stride over the blocks of rows)
+        if (blockIdx.x == gridDim.x - 1) { rowc_block(a, n, -1, srows, rows_out, secmin, secnan); return; }
+        for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x - 1) {
+            rowc_block(a, n, blk, srows, rows_out, secmin, secnan);
+            __syncthreads();
+        }
+        return;
+    }
     for (long blk = blockIdx.x; blk < (nblk > 0 ? nblk : 1); blk += gridDim.x) {
         rowc_block(a, n, blk, srows, rows_out, secmin, secnan);
         __syncthreads();
@@ -1750,7 +1764,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
         if (a.need_sec) hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb), dim3(256), 0, st, a);
-        else            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb), dim3(64), 0, st, a);
+        else            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
