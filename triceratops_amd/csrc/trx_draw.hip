@@ -1,4 +1,4 @@
-// libtrx.so, part 2: the per-draw half of a scenario evidence as ONE kernel.
+// libtrx.so, part 2: the per-draw half of a scenario evidence.
 //
 // Every lnZ_* of the reference (marginal_likelihoods.py:39-2362) turns N uniform draws into
 // per-draw stellar and orbital columns, a geometry mask and a companion prior through ~25 length-N
@@ -6,11 +6,16 @@
 // lookup): priors.py:16-383 (inverse-CDF samplers), funcs.py:54-140 (stellar and flux relations),
 // priors.py:580-1005 (bound-companion and background priors), marginal_likelihoods.py:101-123
 // (transit probability, collision and inclination masks).  draw_kernel does all of it for one
-// draw per thread, for any of the ten scenarios, from staged random numbers (torch's Philox
-// generator on the device, or numpy's global stream copied over in the reference's draw order),
-// and writes the SoA parameter block trx_lnl_batch consumes plus the mask(s) and lnprior.  The
-// host prepares nothing per draw: only the constants of the broken power laws, the spline
-// coefficients and the small lookup tables (trx_draw_args, include/trx.h).
+// draw per thread, for any of the ten scenarios, from staged random numbers (torch's generator on
+// the device, or numpy's global stream copied over in the reference's draw order)
+// or from its own Philox4x32-10 blocks, and writes the SoA parameter block trx_lnl_batch consumes plus the
+// mask(s) and lnprior.  The host prepares nothing per draw: only the constants of the broken power laws, the
+// spline coefficients and the small lookup tables (trx_draw_args, include/trx.h).
+//
+// One body, draw_one<PHASE>, three uses: trx_draw_scenario evaluates every draw in full (draw_kernel<0>);
+// trx_scenario_enqueue first takes the geometry mask(s) of all draws (draw_kernel<1>, or <2> behind an fp32
+// pre-test of the geometry that leaves the fp64 mask to the draws near it) and, once the survivors are listed,
+// the columns and the prior of those alone (fill_kernel) -- nine draws in ten fail the geometry.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
