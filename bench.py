@@ -757,20 +757,23 @@ def usable_cores():
     return n, {"sched_getaffinity": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count()}
 
 
-def native_oracle():
+def native_oracle(window_skip=False):
     """the oracle compiled on THIS box with -O3 -march=native; falls back to the shipped
-    -O2 build when there is no compiler"""
+    -O2 build when there is no compiler.  window_skip: the build with -DTRXO_WINDOW_SKIP (oracle/bench_window_skip.h,
+    the GPU kernels' transit-window early-out on the CPU) -- only this function ever builds it, for the
+    `window_early_out` legs; returns None when it cannot be built."""
     from oracle import oracle as O
     src = os.path.join(ROOT, "oracle", "trx_oracle.c")
-    out = os.path.join(tempfile.mkdtemp(prefix="trx_oracle_", dir="/tmp"), "libtrx_oracle_native.so")
+    out = os.path.join(tempfile.mkdtemp(prefix="trx_oracle_", dir="/tmp"),
+                       "libtrx_oracle_native%s.so" % ("_window" if window_skip else ""))
     cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-           "-shared", "-o", out, src, "-lm"]
+           "-shared", "-o", out, src, "-lm"] + (["-DTRXO_WINDOW_SKIP"] if window_skip else [])
     try:
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         O.use_library(out)
-        return "gcc -O3 -march=native -fopenmp, built on this box"
+        return "gcc -O3 -march=native -fopenmp%s, built on this box" % (" -DTRXO_WINDOW_SKIP" if window_skip else "")
     except Exception:
-        return "shipped build (gcc -O2 -fopenmp): no compiler on this box"
+        return None if window_skip else "shipped build (gcc -O2 -fopenmp): no compiler on this box"
 
 
 def cpu_baseline(t, flux, rows_h, fams, budget_s):
@@ -850,14 +853,17 @@ def cpu_baseline(t, flux, rows_h, fams, budget_s):
     try:
         allc = leg(fused, cores, "fused C restatement, OpenMP over rows on all usable cores")
         one = leg(fused, 1, "fused C restatement, one thread")
-        O.set_window_skip(1)
-        try:
-            win = leg(fused, cores, "fused C restatement + the GPU kernels' transit-window early-out, all usable cores")
-            win1 = leg(fused, 1, "fused C restatement + transit-window early-out, one thread")
-        finally:
-            O.set_window_skip(0)
         grid = leg(numpy_grid, cores, "numpy materialised-grid pipeline of the reference around the oracle's "
                                       "evaluate_pv, model on all usable cores, numpy passes on one")
+        win = win1 = None
+        if native_oracle(window_skip=True) is not None:       # a second library: the checker's build has no such code
+            O.set_window_skip(1)
+            try:
+                win = leg(fused, cores, "fused C restatement + the GPU kernels' transit-window early-out "
+                                        "(oracle/bench_window_skip.h, -DTRXO_WINDOW_SKIP), all usable cores")
+                win1 = leg(fused, 1, "fused C restatement + transit-window early-out, one thread")
+            finally:
+                O.set_window_skip(0)
     finally:
         O.set_num_threads(omp_default)
     allc["single_thread"] = one

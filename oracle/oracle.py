@@ -69,8 +69,9 @@ def lib():
         L.trxo_normalize_probabilities.argtypes = [_dp, ctypes.c_int, _dp]
         L.trxo_num_threads.restype = ctypes.c_int
         L.trxo_set_num_threads.argtypes = [ctypes.c_int]
-        L.trxo_set_window_skip.argtypes = [ctypes.c_int]
-        L.trxo_set_window_skip.restype = None
+        if hasattr(L, "trxo_set_window_skip"):      # only in bench.py's -DTRXO_WINDOW_SKIP build
+            L.trxo_set_window_skip.argtypes = [ctypes.c_int]
+            L.trxo_set_window_skip.restype = None
         _lib = L
     return _lib
 

@@ -22,7 +22,7 @@
  * PARITY STATUS
  *   - _log_mean_exp / _normalize_probabilities: PINNED against the imported
  *     reference module and the exact values in the reference's
- *     tests/test_log_mean_exp.py (see tests/test_oracle_numerics.py).
+ *     tests/test_log_mean_exp.py (see tests/test_oracle.py).
  *   - unit conversion, k-tweak, dilution, secondary depth, chi^2/2, +inf rule:
  *     PINNED by golden vectors produced by running the reference's own
  *     likelihoods.py / marginal_likelihoods.py (imported in the build container,
@@ -35,7 +35,7 @@
  *     curve.  This file restates the published algorithm (Mandel & Agol 2002,
  *     ApJ 580, L171, section 4 / Table 1; Kepler's equation) and is pinned instead
  *     against an independent arbitrary-precision quadrature of the limb-darkened
- *     disk (tests/test_oracle_flux.py, mpmath) to <= 1e-13 absolute in flux.
+ *     disk (tests/test_oracle.py, mpmath) to <= 1e-13 absolute in flux.
  *
  * Conventions follow the pytransit call sites: pvp columns = [k, t0, p, a, i, e, w],
  * exposure integration = mean of `nsamples` sub-exposures centred at
@@ -205,46 +205,12 @@ double trxo_kepler_E(double M, double e)
 /* Per-row orbit constants derived once from pvp = [k, t0, p, a, i, e, w]. */
 typedef struct {
     double k, t0, n /* 2pi/p */, e, Mtr, ax, ay, bx, by, cosi;
-    double wlo, whi;   /* mean-anomaly window around inferior conjunction outside which no occultation is possible */
+    double wlo, whi;   /* (-inf, inf) in the checker; bench_window_skip.h narrows them */
 } trxo_orbit;
 
-/* cpu_baseline leg of bench.py only: 1 = an exposure whose centre lies outside the transit window returns 1
- * without touching the orbit (the early-out the GPU kernels have), so that one CPU figure
- * is like for like with the GPU's algorithm.  The plain restatement (0, default) evaluates every point, as the
- * reference does. */
-static int trxo_window_skip = 0;
-static double trxo_exptime_hint = 0.0;      /* exposure the window's margin is taken for (set per call) */
-void trxo_set_window_skip(int on) { trxo_window_skip = on ? 1 : 0; }
-
-/* Window: X(E) = ax (cosE - e) + bx sinE = A cos(E - phi) - ax e; an occultation needs |X| < 1 + k.  The arc of
- * E around conjunction on which that holds maps to a mean-anomaly interval; when the mirror arc can lie on the
- * near side too (very eccentric orbits seen along the major axis) the window is the hull of both. */
-static void trxo_orbit_window(trxo_orbit* o, double Etr, double exptime)
-{
-    const double e = o->e, R = (1.0 + o->k) * (1.0 + 1e-9) + 1e-12;
-    const double A = sqrt(o->ax * o->ax + o->bx * o->bx), phi = atan2(o->bx, o->ax);
-    const double clo = (o->ax * e - R) / A, chi = (o->ax * e + R) / A;
-    const double psi = remainder(Etr - phi, TRXO_TWOPI);
-    const int open_hi = !(chi < 1.0), open_lo = !(clo > -1.0);
-    const double xlo = acos(fmin(fmax(clo, -1.0), 1.0)), xhi = acos(fmin(fmax(chi, -1.0), 1.0));
-    double plo, phi2;
-    if (open_hi && open_lo) { plo = psi - TRXO_TWOPI; phi2 = psi + TRXO_TWOPI; }
-    else if (open_hi) { plo = -xlo; phi2 = xlo; }
-    else if (open_lo) { if (psi >= 0.0) { plo = xhi; phi2 = TRXO_TWOPI - xhi; } else { plo = xhi - TRXO_TWOPI; phi2 = -xhi; } }
-    else {
-        if (psi >= 0.0) { plo = xhi; phi2 = xlo; } else { plo = -xlo; phi2 = -xhi; }
-        const double o1 = (psi >= 0.0) ? -xlo : xhi, o2 = (psi >= 0.0) ? -xhi : xlo;
-        const double Ay = sqrt(o->ay * o->ay + o->by * o->by), phy = atan2(o->by, o->ay);
-        const double d1 = remainder(Etr + (o1 - psi) - phy, TRXO_TWOPI), span = o2 - o1;
-        const int peak = (d1 <= 0.0 && d1 + span >= 0.0) || (d1 + span >= TRXO_TWOPI);
-        const double cmax = peak ? 1.0 : fmax(cos(d1), cos(d1 + span));
-        if (!(Ay * cmax - o->ay * e < -1e-9 * (Ay + fabs(o->ay * e)))) { plo = fmin(plo, o1); phi2 = fmax(phi2, o2); }
-    }
-    const double Elo = Etr + (plo - psi), Ehi = Etr + (phi2 - psi);
-    const double mg = 0.5 * fabs(o->n * exptime) * (1.0 + 1e-9) + 1e-11;
-    o->wlo = (Elo - Etr) - e * (sin(Elo) - sin(Etr)) - mg;
-    o->whi = (Ehi - Etr) - e * (sin(Ehi) - sin(Etr)) + mg;
-}
+#ifdef TRXO_WINDOW_SKIP
+#include "bench_window_skip.h"      /* bench.py's cpu_baseline only; not in the checker's default build */
+#endif
 
 static void trxo_orbit_init(trxo_orbit* o, double k, double t0, double p, double a,
                             double inc, double e, double w)
@@ -260,7 +226,9 @@ static void trxo_orbit_init(trxo_orbit* o, double k, double t0, double p, double
     o->ay = a * sw;  o->by =  a * rt * cw;
     o->cosi = cos(inc);
     o->wlo = -INFINITY; o->whi = INFINITY;
+#ifdef TRXO_WINDOW_SKIP
     if (trxo_window_skip) trxo_orbit_window(o, Etr, trxo_exptime_hint);
+#endif
 }
 
 /* projected separation at time t; returns a negative number behind the star */
@@ -280,13 +248,9 @@ static double trxo_point_flux(const trxo_orbit* o, double u1, double u2, double 
                               double exptime, int nsamples)
 {
     double acc = 0.0;
-    if (trxo_window_skip) {
-        const double ph = o->n * (t - o->t0);
-        const double dM = remainder(ph, TRXO_TWOPI), slack = 1e-15 * fabs(ph);
-        const int out = ((dM < o->wlo - slack) && !(dM + TRXO_TWOPI <= o->whi + slack)) ||
-                        ((dM > o->whi + slack) && !(dM - TRXO_TWOPI >= o->wlo - slack));
-        if (out) return 1.0;
-    }
+#ifdef TRXO_WINDOW_SKIP
+    if (trxo_window_skip && trxo_outside_window(o, t)) return 1.0;
+#endif
     for (int s = 1; s <= nsamples; ++s) {
         const double off = exptime * (((double)s - 0.5) / (double)nsamples - 0.5);
         const double z = trxo_orbit_z(o, t + off);
@@ -303,7 +267,9 @@ static double trxo_point_flux(const trxo_orbit* o, double u1, double u2, double 
 void trxo_evaluate_pv(const double* time, int n_time, const double* pvp, const double* ldc,
                       long n, double exptime, int nsamples, double* out)
 {
+#ifdef TRXO_WINDOW_SKIP
     trxo_exptime_hint = exptime;
+#endif
     if (nsamples < 1) nsamples = 1;
 #pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r) {
@@ -428,7 +394,9 @@ void trxo_lnl_batch(int model, int flags, const double* time, const double* flux
                     double sigma, const double* params, long n, double exptime, int nsamples,
                     double* out_halfchi2)
 {
+#ifdef TRXO_WINDOW_SKIP
     trxo_exptime_hint = exptime;
+#endif
     if (nsamples < 1) nsamples = 1;
 #pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r)
@@ -440,7 +408,9 @@ void trxo_lnl_batch(int model, int flags, const double* time, const double* flux
 void trxo_flux_grid(int model, int flags, const double* time, int n_time, const double* params,
                     long n, double exptime, int nsamples, double* out_flux, double* out_secdepth)
 {
+#ifdef TRXO_WINDOW_SKIP
     trxo_exptime_hint = exptime;
+#endif
     if (nsamples < 1) nsamples = 1;
 #pragma omp parallel for schedule(dynamic, 2)
     for (long r = 0; r < n; ++r) {

@@ -90,3 +90,35 @@ def test_evidence_and_best_draw_do_not_depend_on_which_rows_stop():
             assert all(abs(z - z0) <= 1e-13 * abs(z0) for z, _ in out[1])
     finally:
         L.trx_set_debug_bounded_lnl(0)
+
+
+@pytest.mark.parametrize("n_time,rows_per_wave,packing_below", [(100, 22, None), (60, 16, None), (900, 0, 1000)])
+def test_batches_that_span_several_window_passes_are_evaluated_in_full(n_time, rows_per_wave, packing_below):
+    """The batched variant's verdict after the probe phase is only a lower bound when the batch's cells fit ONE
+    768-cell window pass (its flat-model charge for the in-window cells not done yet covers the windows tested so
+    far).  The public knobs can exceed that -- trx_set_rows_per_wave(22) at 100 points, a raised
+    trx_set_cell_packing_below -- and such launches must not abandon anything: every row exact, none counted."""
+    L = _lib.lib()
+    rng = np.random.default_rng(13)
+    t_d, f_d = _light_curve(n_time, rng, True)
+    n = 20000
+    cnt = ctypes.c_ulonglong(0)
+    try:
+        L.trx_set_rows_per_wave(rows_per_wave)
+        if packing_below:
+            L.trx_set_cell_packing_below(packing_below)
+        for fam in synth.FAMILIES[:6]:
+            rows_d = _lib.dev(synth.family_rows(rng, fam, n))
+            flags = _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0
+            L.trx_set_debug_bounded_lnl(0)
+            full = _lib.lnl_batch(fam[1], flags, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_set_debug_bounded_lnl(1)
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            got = _lib.lnl_batch(fam[1], flags, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            assert cnt.value == 0, (fam[0], cnt.value)
+            assert np.array_equal(full, got, equal_nan=True), fam[0]
+    finally:
+        L.trx_set_debug_bounded_lnl(0)
+        L.trx_set_rows_per_wave(0)
+        L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)

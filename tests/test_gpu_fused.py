@@ -273,6 +273,46 @@ def test_fp32_pretest_of_the_geometry_leaves_the_masks_unchanged(name, star):
         triceratops_amd.set_sampling("numpy")
 
 
+@pytest.mark.parametrize("name", ["STP", "SEB"])
+def test_missing_limb_darkening_cell_raises_with_and_without_the_pretest(name):
+    """lnZ_STP / lnZ_SEB look up the limb-darkening cell of EVERY draw's companion and raise when the Claret grid
+    lacks it (marginal_likelihoods.py:945-972: .item() on an empty selection), whether the draw transits or not.
+    The pre-test must not narrow that to the draws it lets through: blanking the cells of the companion lattice
+    one at a time, the same cells raise with the pre-test on and off -- at N = 400 about half of the cells that any
+    draw hits are hit by no transiting draw."""
+    import triceratops_amd
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    triceratops_amd.set_sampling("device")
+    saved_rows, saved_pre = fused.TABLE_ROWS, fused.PRETEST
+    fused.TABLE_ROWS = 1
+    try:
+        torch.manual_seed(3)
+        _call(ml, name, P=3.3, N=400, parallel=True, cc=None, filt="TESS")     # fills the lattice cache
+        (key, (lut, n_lut)), = [(k, v) for k, v in fused._lut_cache.items()][-1:]
+        clean = lut.clone()
+        raised = {True: set(), False: set()}
+        for cell in range(n_lut):
+            if bool(torch.isnan(clean[cell])):
+                continue
+            lut.copy_(clean)
+            lut[cell] = float("nan")
+            for pre in (True, False):
+                fused.PRETEST = pre
+                torch.manual_seed(3)
+                try:
+                    _call(ml, name, P=3.3, N=400, parallel=True, cc=None, filt="TESS")
+                except ValueError:
+                    raised[pre].add(cell)
+        lut.copy_(clean)
+        assert raised[True] == raised[False]
+        assert len(raised[False]) >= 3                      # the draws do spread over several cells
+    finally:
+        fused.TABLE_ROWS, fused.PRETEST = saved_rows, saved_pre
+        fused._lut_cache.clear()
+        triceratops_amd.set_sampling("numpy")
+
+
 def _philox4x32_10(counter, key):
     """Random123's Philox4x32-10 (known answer: zero counter and key -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8)"""
     M = 0xffffffff

@@ -119,9 +119,11 @@ def test_world2_gloo_matches_single_process():
     assert res0[3] is None      # the dropped PEB unit stays empty
 
 
-def test_ranks_seeded_differently_are_refused():
-    """the seed base is drawn on every rank instead of being broadcast; the all_gather carries it and a
-    mismatch raises on every rank"""
+def test_ranks_seeded_differently_still_agree_on_one_table():
+    """the seed base is drawn on every rank instead of being broadcast.  Ranks that were not seeded alike --
+    the reference's normal, unseeded usage -- draw different bases: the run completes, a unit is seeded from the
+    base of the rank that owns it, every rank ends with the same table, and the bases the all_gather carried
+    are on record (round 3 raised here, so an unseeded multi-GPU calc_probs always failed)"""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -131,7 +133,26 @@ def test_ranks_seeded_differently_are_refused():
     got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert all(isinstance(g[1], str) and "seed numpy alike" in g[1] for g in got)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    (_, res0, own0), (_, res1, own1) = got
+    assert own0 == own1
+    for a, b in zip(res0, res1):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    # rank r's units are what a single process computes from rank r's base (np.random.seed(100 + r))
+    units = _fake_units()
+    live = [k for k, u in enumerate(units) if u[4] is not None]
+    for r in range(world):
+        np.random.seed(100 + r)
+        sharding.per_unit_seed = True
+        try:
+            single = _flatten(sharding.run_units(_fake_units(), verbose=0))
+        finally:
+            sharding.per_unit_seed = False
+        mine = [k for i, k in enumerate(live) if own0[i] == r]
+        assert mine
+        for k in mine:
+            assert np.array_equal(res0[k], single[k])
 
 
 def test_single_process_consumes_the_stream_sequentially():

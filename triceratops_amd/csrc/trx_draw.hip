@@ -348,6 +348,28 @@ __device__ __forceinline__ bool may_transit(const trx_draw_args& a, const Tables
         Mh = mc;
         Rh = stellar_radius_f(T, mc, (float)a.R_s);
         unsure = unsure || fabsf(mc - 0.63f) < 1e-4f;          // the two branches of the mass-radius relation
+        // The reference looks up the limb-darkening cell of EVERY draw (lnZ_STP / lnZ_SEB: .item() over the unique
+        // (Teff, logg) of all N draws) and raises when the Claret grid lacks one, whether that draw transits or not.
+        // The cell in fp32; a draw whose cell is missing -- or too close to a rounding boundary of the lattice for
+        // fp32 to tell -- goes to the fp64 pass, which raises the flag from the fp64 cell (draw_one).
+        {
+            float Th = (mc > 0.63f) ? spline_eval_f(T.spl[TRX_SPL_T_HOT], mc) : spline_eval_f(T.spl[TRX_SPL_T_COOL], mc);
+            if (mc != mc) Th = 0.0f;
+            if (Th > (float)a.Teff) Th = (float)a.Teff;
+            Th = (Th < 2800.0f) ? 2800.0f : Th;
+            // log10(G M_sun / R_sun^2) = 4.4380676; the hardware log is log2
+            const float xg = (4.4380676f + 0.30103f * (__builtin_amdgcn_logf(mc) - 2.0f * __builtin_amdgcn_logf(Rh))) * 2.0f;
+            const float xt = Th * (1.0f / 250.0f);
+            const bool edge = fabsf(xg - floorf(xg) - 0.5f) < 2e-3f || fabsf(xt - floorf(xt) - 0.5f) < 2e-3f;
+            float ig = fminf(fmaxf(rintf(xg) * 0.5f, 3.5f), 5.0f);
+            float it = fminf(fmaxf(rintf(xt) * 250.0f, 3500.0f), (float)a.teff_cap);
+            float code = rintf((it - 3500.0f) * (1.0f / 250.0f)) * 4.0f + rintf((ig - 3.5f) * 2.0f);
+            if (code != code) code = 0.0f;
+            int ci = (int)code;
+            ci = ci < 0 ? 0 : (ci >= a.n_lut ? a.n_lut - 1 : ci);
+            const double cell = T.lut[0][ci];
+            unsure = unsure || edge || (cell != cell);
+        }
     } else if (a.host == TRX_HOST_FIELD) {
         Mh = (float)a.f_mass[k];
         Rh = (float)a.f_radius[k];

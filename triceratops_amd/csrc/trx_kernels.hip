@@ -5,7 +5,7 @@
 //                             constants, transit window, dilution, limb weights) of 64 rows per
 //                             workgroup, lanes = rows; for EB rows the 25-point secondary-eclipse
 //                             scan with lanes = (row, point) -> depth / exclusion flag.  Output:
-//                             one 18-double block per row in stream-ordered scratch.
+//                             one 19-double block per row (152 B) in the stream's scratch.
 //   cells_kernel<MODE, STEP, FP32, LONG, ST>
 //                             the light-curve model and its chi^2.  One wavefront (64-thread
 //                             workgroup) per row (LONG) or per batch of rows (short curves); the
@@ -160,8 +160,8 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 // different node counts (3-9 Gauss nodes, S next to a contact), so a per-lane node loop runs to
 // the largest.  Here
 //   * rowc_kernel derives the row constants of 64 rows per workgroup -- lanes = rows, then lanes =
-//     (row, point) for the secondary-eclipse scan -- and stores the 18-double blocks in device
-//     scratch (144 B per row, stream-ordered allocation inside the call);
+//     (row, point) for the secondary-eclipse scan -- and stores the 19-double blocks in device
+//     scratch (152 B per row of the library's per-stream scratch);
 //   * cells_kernel takes one row (LONG, 320 points and more) or a batch of B <= 22 rows per wave.
 //     The (row, time) cells form ONE index space, cell = r * n_time + j, walked in windows of
 //     cells_window() cells: pass 1 applies the transit-window test to 64 cells at a time (across row
@@ -418,8 +418,8 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
         const Limb L = limb_weights(u1, u2);
         c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
         c.excl = 0.0;
-        // through LDS to memory: 64 x 18 doubles leave the block as one contiguous 9 KB run (a lane
-        // writing its own 144-byte block made every store instruction touch 64 cache lines)
+        // through LDS to memory: 64 x 19 doubles leave the block as one contiguous 9.5 KB run (a lane
+        // writing its own 152-byte block made every store instruction touch 64 cache lines)
         const double* src = reinterpret_cast<const double*>(&c);
         double* stage = reinterpret_cast<double*>(&rows_out[lane]);
 #pragma unroll
@@ -1710,8 +1710,12 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // 46 -> 39 ms; at 100 binned points the batched variant gains or loses ~3 % (the probe phase, the pilot
     // launch and the second window pass eat what the abandoned rows save): profiles/r03_bounded_e2e.txt)
     const int prune_mode = a.prune == 2 ? 2 : g_prune.load(std::memory_order_relaxed);
+    // (batched variant: the verdict after the probe phase reads flat + corrections - hrem, and hrem holds only the
+    // in-window cells of the window passes done so far -- a valid bound only when the batch's cells fit ONE window;
+    // a forced rows-per-wave or a raised trx_set_cell_packing_below can exceed it: those launches evaluate in full)
     const bool prune = MODE == MODE_LNL && a.prune && g_step.load(std::memory_order_relaxed) &&
-                       (prune_mode == 2 || (prune_mode == 1 && long_rows));
+                       (prune_mode == 2 || (prune_mode == 1 && long_rows)) &&
+                       (long_rows || (long)a.B * a.n_time <= (long)kCellsWindowBatch);
     a.prune = prune ? 1 : 0;
     a.pstride = prune ? (a.n_time >= 48 ? a.n_time / 16 : 1) : 1;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
@@ -1752,7 +1756,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     a.wave_off = (int)(shared / sizeof(double));
     a.wave_doubles = (int)(wave_bytes(long_rows) / sizeof(double));
-    // the row constants: 144 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
+    // the row constants: 152 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;

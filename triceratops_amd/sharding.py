@@ -11,11 +11,15 @@ is the right primitive (no ring, no bucketing).
 
 Random numbers.  world == 1: the generator of the sampling mode is consumed unit after unit (numpy modes:
 identical to the reference under the same np.random.seed), unless per_unit_seed is set.  world > 1: each
-unit draws from its own seed, derived from (base, unit index), so the result does not depend on the
-partition or on the world size (per_unit_seed = True gives the same numbers on one GPU).  base is one draw
-of numpy's global stream, taken on EVERY rank: the ranks must be seeded alike (np.random.seed(s) on all of
-them), which the all_gather verifies at no extra cost -- each rank's base rides in its chunk and a mismatch
-raises.  No seed broadcast: the all_gather is the only collective of a calc_probs.
+unit draws from its own seed, derived from (base of the rank that owns it, unit index).  base is one draw of
+the sampling mode's host generator -- torch's CPU generator in "device" mode (torch.manual_seed governs every
+path of that mode), numpy's global stream in the numpy modes -- taken on EVERY rank.  Ranks seeded alike
+(the way to a reproducible run) draw the same base, and the result then depends neither on the partition nor
+on the world size (per_unit_seed = True gives the same numbers on one GPU).  Ranks that were not seeded -- the
+reference's normal usage -- draw different bases: each unit is still an independent draw, the run is just
+not reproducible, which is what "unseeded" means.  No seed broadcast: the all_gather is the only collective
+of a calc_probs; every rank's base rides in its chunk's header row and is kept in `last_seed_bases` (all
+equal = the run can be repeated from the seed).
 """
 import os
 
@@ -40,11 +44,25 @@ threads = 1
 streams = int(os.environ.get("TRX_STREAMS", "6"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
 timing = {"enqueue_s": 0.0, "wait_s": 0.0}
+# seed bases of the ranks of the last multi-rank run_units (from the all_gather's header rows)
+last_seed_bases = None
+# The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
+# their scratch together stays near this many draws' worth (6 streams at N = 1e6, 2 at N >= 3e6)
+scratch_budget_draws = 6_000_000
 
 # relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
 # secondary-eclipse scan; companion/background hosts add per-draw stellar relations
 _COST = {"TP": 1.0, "PTP": 1.1, "STP": 1.2, "DTP": 1.1, "BTP": 1.2, "NTP": 1.0,
          "EB": 1.7, "PEB": 1.8, "SEB": 1.9, "DEB": 1.8, "BEB": 1.9, "NEB": 1.7}
+
+
+def _draw_base():
+    """one 31-bit seed base from the host generator that governs the current sampling mode"""
+    from . import fused as _fused
+    if _fused.threadable():
+        import torch
+        return int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).item())
+    return int(np.random.randint(0, 2 ** 31 - 1))
 
 
 def _dist():
@@ -98,7 +116,7 @@ def run_units(units, verbose=0):
     owner = {k: 0 for k in live}
     base = None
     if dist:
-        base = int(np.random.randint(0, 2 ** 31 - 1))     # the same on every rank (verified in the all_gather)
+        base = _draw_base()         # ranks seeded alike draw the same one (module docstring)
         own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
                         for k in live], world)
         owner = {k: own[i] for i, k in enumerate(live)}
@@ -107,7 +125,7 @@ def run_units(units, verbose=0):
     from . import fused as _fused
     if not dist and (per_unit_seed or (threads > 1 and _fused.threadable())):
         # (threads only apply to the device generator: the numpy modes keep consuming the caller's stream)
-        base = int(np.random.randint(0, 2 ** 31 - 1))
+        base = _draw_base()
     _fused.TABLE_ROWS = 1
     try:
         return _run_units(units, live, owner, base, dist, world, rank, verbose)
@@ -178,9 +196,12 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         # one host thread, a few streams: every call is enqueued, then one wait per stream
         import torch
         device = torch.cuda.current_device()
-        pool = _worker_streams(device, max(1, min(streams, len(mine_k))))
+        n_draws = max([units[k][7] for k in mine_k if len(units[k]) > 7] + [1])
+        cap = max(2, int(scratch_budget_draws // n_draws))
+        pool = _worker_streams(device, max(1, min(streams, cap, len(mine_k))))
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
         _fused.begin_deferred(len(mine_k))
+        drained = False
         try:
             import time
             t0 = time.perf_counter()
@@ -196,9 +217,16 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
                 st.synchronize()
+            drained = True
             timing["wait_s"] = time.perf_counter() - t0 - timing["enqueue_s"]
             resolve()
         finally:
+            if not drained:
+                # a call failed after others were enqueued: their kernels and record copies still use the
+                # pinned block and the cached tables -- wait for them before anything is released
+                for st in pool:
+                    st.synchronize()
+            pending.clear()
             _fused.end_deferred()
     else:
         import queue
@@ -224,10 +252,10 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                         except queue.Empty:
                             break
                         one(k)
-                stream.synchronize()
             except BaseException as exc:              # re-raised in the caller's thread
                 errors.append(exc)
             finally:
+                stream.synchronize()                  # (also after an error: calls enqueued before it are in flight)
                 _fused.end_deferred()
 
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
@@ -237,6 +265,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         for t in pool:
             t.join()
         if errors:
+            pending.clear()
             raise errors[0]
         resolve()
 
@@ -258,9 +287,8 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=dev)
         dist.all_gather_into_tensor(gathered, mine)          # the single collective
         g = gathered.cpu().numpy().reshape((world,) + chunk.shape)
-        if not np.all(g[:, 0, 0] == float(base)):
-            raise RuntimeError("triceratops_amd.sharding: the ranks drew different seed bases %s -- seed numpy "
-                               "alike on every rank (np.random.seed(s)) before calc_probs" % g[:, 0, 0].tolist())
+        global last_seed_bases
+        last_seed_bases = [int(b) for b in g[:, 0, 0]]
         at = [1] * world
         for k in live:
             r = owner[k]

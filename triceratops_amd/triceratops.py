@@ -122,50 +122,62 @@ class target:
     def _units(self, filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file, filt, N,
                parallel, drop_scenario, flatpriors, exptime, nsamples, molusc_file):
         """The independent (star, lnZ_* call) work units of one calc_probs, in the reference's
-        order.  Each unit = (first row, scenario names, star_num, ID, thunk or None)."""
+        order.  Each unit = (first row, scenario names, star_num, ID, thunk or None, drop key).
+        Building the list touches nothing but the star table's columns (once each): a unit's arguments --
+        the light curve renormalised to its star, the argument tuples -- are put together when its thunk
+        is called, i.e. only on the rank that owns it (sharding.run_units)."""
         units = []
         ok = True
-        for i, ID in enumerate(filtered["ID"].values):
-            row = {c: filtered[c].values[i] for c in ("fluxratio", "mass", "rad", "Teff", "Tmag",
-                                                      "Jmag", "Hmag", "Kmag", "plx")}
-            flux, flux_err = renorm_flux(flux_0, flux_err_0, row["fluxratio"])
-            M_s, R_s, Teff, plx, Z = row["mass"], row["rad"], row["Teff"], row["plx"], 0.0
-            mags = (row["Tmag"], row["Jmag"], row["Hmag"], row["Kmag"])
-            tail = (N, parallel, self.mission, flatpriors, exptime, nsamples)
+        col = {c: filtered[c].to_numpy() for c in ("fluxratio", "mass", "rad", "Teff", "Tmag", "Jmag",
+                                                   "Hmag", "Kmag", "plx")}
+        tail = (N, parallel, self.mission, flatpriors, exptime, nsamples)
+        trilegal = self.trilegal_fname
+        fns = {"TP": lnZ_TTP, "EB": lnZ_TEB, "PTP": lnZ_PTP, "PEB": lnZ_PEB, "STP": lnZ_STP, "SEB": lnZ_SEB,
+               "DTP": lnZ_DTP, "DEB": lnZ_DEB, "BTP": lnZ_BTP, "BEB": lnZ_BEB}
+
+        def star_args(i, cache={}):
+            """(time, flux, flux_err, P_orb, M_s, R_s, Teff) of star i, built on first use"""
+            if i not in cache:
+                flux, flux_err = renorm_flux(flux_0, flux_err_0, col["fluxratio"][i])
+                M_s, R_s, Teff = col["mass"][i], col["rad"][i], col["Teff"][i]
+                if i > 0:      # nearby star: unknown properties default to solar values
+                    Teff = 5777 if np.isnan(Teff) else Teff
+                    M_s = 1.0 if np.isnan(M_s) else M_s
+                    R_s = 1.0 if np.isnan(R_s) else R_s
+                cache[i] = (time, flux, flux_err, P_orb, M_s, R_s, Teff)
+            return cache[i]
+
+        def target_call(key):
+            b, Z = star_args(0), 0.0
+            if key in ("TP", "EB"):
+                return fns[key](*b, Z, *tail)
+            if key in ("PTP", "PEB", "STP", "SEB"):
+                return fns[key](*b, Z, col["plx"][0], contrast_curve_file, filt, *tail, molusc_file)
+            mags = (col["Tmag"][0], col["Jmag"][0], col["Hmag"][0], col["Kmag"][0])
+            field = mags + (trilegal, contrast_curve_file, filt) + tail
+            if key in ("DTP", "DEB"):
+                return fns[key](*b, Z, *field)
+            return fns[key](*b, *field)
+
+        def nearby_call(i, fn):
+            return fn(*star_args(i), 0.0, *tail)
+
+        for i, ID in enumerate(filtered["ID"].to_numpy()):
             if i == 0:
-                if np.isnan(M_s) or np.isnan(R_s) or np.isnan(Teff) or np.isnan(plx):
+                if (np.isnan(col["mass"][0]) or np.isnan(col["rad"][0]) or np.isnan(col["Teff"][0])
+                        or np.isnan(col["plx"][0])):
                     print("Insufficient information to validate " + str(ID)
                           + ". Please ensure a stellar mass (in M_Sun), radius (in R_Sun), Teff "
                           + "(in K), and plx (in mas) are provided in the .stars dataframe.")
                     ok = False
                     break
-                base = (time, flux, flux_err, P_orb, M_s, R_s, Teff)
-                bound = (plx, contrast_curve_file, filt) + tail + (molusc_file,)
-                field = mags + (self.trilegal_fname, contrast_curve_file, filt) + tail
-                calls = {
-                    "TP": lambda b=base: lnZ_TTP(*b, Z, *tail),
-                    "EB": lambda b=base: lnZ_TEB(*b, Z, *tail),
-                    "PTP": lambda b=base: lnZ_PTP(*b, Z, *bound),
-                    "PEB": lambda b=base: lnZ_PEB(*b, Z, *bound),
-                    "STP": lambda b=base: lnZ_STP(*b, Z, *bound),
-                    "SEB": lambda b=base: lnZ_SEB(*b, Z, *bound),
-                    "DTP": lambda b=base: lnZ_DTP(*b, Z, *field),
-                    "DEB": lambda b=base: lnZ_DEB(*b, Z, *field),
-                    "BTP": lambda b=base: lnZ_BTP(*b, *field),
-                    "BEB": lambda b=base: lnZ_BEB(*b, *field),
-                }
                 for key, names, j0, snum in _TARGET_CALLS:
-                    fn = None if key in drop_scenario else calls[key]
+                    fn = None if key in drop_scenario else (lambda k=key: target_call(k))
                     units.append((j0, names, snum, ID, fn, key))
             else:
-                # nearby star: unknown properties default to solar values
-                Teff = 5777 if np.isnan(Teff) else Teff
-                M_s = 1.0 if np.isnan(M_s) else M_s
-                R_s = 1.0 if np.isnan(R_s) else R_s
-                base = (time, flux, flux_err, P_orb, M_s, R_s, Teff, Z) + tail
                 j0 = 15 + 3 * (i - 1)
-                units.append((j0, ("NTP",), 1, ID, lambda b=base: lnZ_TTP(*b), "NTP"))
-                units.append((j0 + 1, ("NEB", "NEBx2P"), 1, ID, lambda b=base: lnZ_TEB(*b), "NEB"))
+                units.append((j0, ("NTP",), 1, ID, lambda i=i: nearby_call(i, lnZ_TTP), "NTP"))
+                units.append((j0 + 1, ("NEB", "NEBx2P"), 1, ID, lambda i=i: nearby_call(i, lnZ_TEB), "NEB"))
         return units, ok
 
     def calc_probs(self, time, flux_0, flux_err_0: float, P_orb, contrast_curve_file: str = None,
@@ -201,19 +213,22 @@ class target:
         units, _ok = self._units(filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file,
                                  filt, N, parallel, drop_scenario, flatpriors, exptime, nsamples,
                                  molusc_file)
-        # relative size of this job's units for the multi-GPU schedule
+        # relative size of this job's units for the multi-GPU schedule, and the draws per unit (stream scratch)
         weight = float(N) * max(1, time.size)
-        return [u + (weight,) for u in units], n_scen
+        return [u + (weight, int(N)) for u in units], n_scen
 
     def _finish(self, units, results, n_scen):
         """Scenario table, normalised probabilities, FPP and NFPP from the per-unit results
-        (triceratops.py:1430-1485)."""
+        (triceratops.py:1430-1485).  Plain arrays here; the `.probs` DataFrame of the reference is put
+        together when it is first read (a batch of 64 targets spent as long building 64 DataFrames nobody
+        had asked for yet as waiting for the GPU)."""
         targets = np.zeros(n_scen, dtype=np.dtype("i8"))
         star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
         scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
         best = {c: np.zeros(n_scen) for c in _COLS}
         lnZ = np.zeros(n_scen)
-        for (j0, names, snum, ID, fn, key, _w), res in zip(units, results):
+        for u, res in zip(units, results):
+            j0, names, snum, ID = u[:4]
             for off, name in enumerate(names):
                 j = j0 + off
                 targets[j], star_num[j], scenarios[j] = ID, snum, name
@@ -242,21 +257,35 @@ class target:
         else:
             self.FPP_degenerate = False
 
-        self.probs = DataFrame({
+        self._probs_columns = {
             "ID": targets, "scenario": scenarios, "M_s": best["M_s"], "R_s": best["R_s"],
             "P_orb": best["P_orb"], "inc": best["inc"], "b": best["b"], "ecc": best["ecc"],
             "w": best["argp"], "R_p": best["R_p"], "M_EB": best["M_EB"], "R_EB": best["R_EB"],
-            "prob": relative_probs})
+            "prob": relative_probs}
+        self._probs = None
         self.lnZ = lnZ
         self.star_num = star_num
         self.u1 = best["u1"]
         self.u2 = best["u2"]
         self.fluxratio_EB = best["fluxratio_EB"]
         self.fluxratio_comp = best["fluxratio_comp"]
-        prob = self.probs.prob
+        prob = relative_probs
         self.FPP = 1 - (prob[0] + prob[3] + prob[9])
         self.NFPP = np.sum(prob[15:]) if len(prob) > 15 else 0.0
         return
+
+    @property
+    def probs(self):
+        """the scenario table of the last calc_probs (triceratops.py:1449-1463)"""
+        if getattr(self, "_probs", None) is None:
+            if getattr(self, "_probs_columns", None) is None:
+                raise AttributeError("'target' object has no attribute 'probs'")
+            self._probs = DataFrame(self._probs_columns)
+        return self._probs
+
+    @probs.setter
+    def probs(self, value):
+        self._probs = value
 
     # -----------------------------------------------------------------------------------
     def fit_curves(self, time, flux_0, flux_err_0: float, n_model: int = 100,
