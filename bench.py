@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each of the three CPU legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel, census and e2e legs")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-batch-leg", action="store_true",
+                    help="grid mode: skip the `batch` object (the configs[3] strong-scaling step measured in the same job)")
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
                     help="collect FETCH_SIZE / WRITE_SIZE of the dominant kernel with rocprofv3 child runs (N = 1)")
     # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
@@ -445,6 +447,15 @@ def run_grid(ctx):
     value = evals_per_step_per_gpu * world * args.steps / elapsed
     kern_ms = np.array([[a.elapsed_time(b) for (a, b) in ev[s]] for s in range(args.steps)])
     mean_launch_s = float(kern_ms.mean()) * 1e-3
+    # the configs[3] step in the same job, on every rank count (collective inside: all ranks take part)
+    batch = None
+    if not args.no_batch_leg:
+        try:
+            batch = batch_object(ctx)
+        except Exception as exc:                  # the grid line stands on its own
+            if world > 1:
+                raise
+            batch = {"error": repr(exc)}
     if rank != 0:
         return None
 
@@ -555,9 +566,91 @@ def run_grid(ctx):
                                      "point); `value` is BASELINE configs[1]'s uniform grid, on which the "
                                      "centre-value stencil applies",
                    "parallelism": "scenario-sharded x%d, one all_gather of lnZ" % world},
-        "roofline": roof, "shapes": shapes, "kernels": kernels, "cpu_baseline": cpu, "e2e": e2e,
+        "roofline": roof, "shapes": shapes, "kernels": kernels, "cpu_baseline": cpu, "e2e": e2e, "batch": batch,
         "lnZ_checksum": float(np.nansum(lnz_host[np.isfinite(lnz_host)])),
     }
+
+
+
+def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False):
+    """The configs[3] step -- calc_probs_many over `tois` synthetic TOIs x 18 scenarios x N draws, the lnZ_* units
+    dealt to the ranks (strong scaling) -- timed like the main loop: barrier + synchronize on both sides, max over
+    ranks.  Returns (on every rank) elapsed seconds, the targets of the last step and the per-rank host timings:
+    prepare (unit lists), enqueue (argument blocks + library calls of this rank's units), wait (streams), gather
+    (the one collective), finish (tables of all targets), other (the rest of the step)."""
+    import torch
+    import torch.distributed as dist
+    import triceratops_amd
+    from triceratops_amd import sharding, synth
+    world, rank, device = ctx["world"], ctx["rank"], ctx["device"]
+    prev = triceratops_amd.get_sampling()
+    triceratops_amd.set_sampling("device")
+    if fp32:
+        triceratops_amd.set_precision("fp32")
+    try:
+        tri = os.path.join(GOLD, "trilegal_synth.csv")
+        cc = os.path.join(GOLD, "contrast_curve_synth.csv")
+        # every rank builds the same jobs (tiny host tables + one light curve per TOI)
+        jobs = synth.toi_jobs(tois, n_time=n_time, N=N, seed=synth.SEED, trilegal_fname=tri, contrast_curve_file=cc)
+        small = synth.toi_jobs(min(tois, 2 * world), n_time=n_time, N=20000, seed=synth.SEED, trilegal_fname=tri,
+                               contrast_curve_file=cc)
+
+        def step(js, seed):
+            np.random.seed(seed)
+            torch.manual_seed(seed)          # ranks seeded alike: the run can be repeated (sharding's seed base)
+            t0 = time.perf_counter()
+            out = triceratops_amd.calc_probs_many(js)
+            return out, time.perf_counter() - t0
+
+        step(small, 1)                           # library load, tables, allocator
+        for w in range(warmup):
+            step(jobs, 10 + w)
+        _sync(ctx)
+        host = np.zeros(7)
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            out, dt = step(jobs, 100 + s_)
+            tm = sharding.timing
+            host += [tm["prepare_s"], tm["enqueue_s"], tm["wait_s"], tm["gather_s"] if world > 1 else 0.0,
+                     tm["finish_s"], dt, 0.0]
+        _sync(ctx)
+        elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
+        host /= max(steps, 1)
+        host[6] = host[5] - host[:5].sum()       # other
+        per_rank = host[None, :]
+        if world > 1:
+            mine = torch.as_tensor(host, dtype=torch.float64, device="cpu" if ctx["debug_one"] else device)
+            allr = torch.empty(world * host.size, dtype=torch.float64, device=mine.device)
+            dist.all_gather_into_tensor(allr, mine)
+            per_rank = allr.cpu().numpy().reshape(world, -1)
+        names = ("prepare_s", "enqueue_s", "wait_s", "gather_s", "finish_s", "step_s", "other_s")
+        timing = {k: [float(v) for v in per_rank[:, i]] for i, k in enumerate(names)}
+        # what a rank's host does on the critical path of a step apart from waiting (for its GPU, for the others)
+        timing["host_path_s"] = [float(per_rank[r, 0] + per_rank[r, 1] + per_rank[r, 4] + per_rank[r, 6])
+                                 for r in range(per_rank.shape[0])]
+        return elapsed, out, jobs, timing
+    finally:
+        triceratops_amd.set_sampling(prev)
+        if fp32:
+            triceratops_amd.set_precision("fp64")
+
+
+def batch_object(ctx, steps=2, warmup=1):
+    """`batch` object of the grid-mode line: the configs[3] strong-scaling step measured in the same job"""
+    args = ctx["args"]
+    elapsed, out, jobs, timing = batch_leg(ctx, args.tois, args.batch_n, 200, steps, warmup, fp32=args.fp32_model)
+    if ctx["rank"] != 0:
+        return None
+    from triceratops_amd import sharding
+    n_scen = sum(len(tg.lnZ) for tg in out)
+    return {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, 200-point light curves, "
+                        "calc_probs_many, lnZ_* units dealt to %d rank(s) by cost, one all_gather of the records"
+                        % (args.tois, args.batch_n, ctx["world"]),
+            "scaling": "strong", "n_gpus": ctx["world"], "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "calc_probs_per_s": args.tois * steps / elapsed,
+            "nominal_evals_per_s": float(args.batch_n) * 200 * n_scen * steps / elapsed,
+            "per_rank": timing, "streams": sharding.streams,
+            "fpp_checksum": float(np.sum([float(tg.FPP) for tg in out]))}
 
 
 # ---------------------------------------------------------------------------------------------

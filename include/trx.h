@@ -342,6 +342,18 @@ int trx_scenario_evidence(const trx_scenario_args* args, void* stream);
 int trx_scenario_enqueue(const trx_scenario_args* args, double* out, void* stream);
 size_t trx_scenario_args_size(void);
 
+/* The lnZ_* calls of one star of calc_probs (triceratops.py:784-1340: TP, EB, PTP, PEB, STP, SEB, DTP, DEB, BTP,
+ * BEB for the target; TP, EB for a nearby star) -- or any other group of calls -- in ONE library call:
+ * trx_scenario_enqueue(&calls[i], out[i], streams[i]) for i = 0 .. n_calls - 1, in that order.  A host binding
+ * builds the argument blocks of a star once and crosses the FFI once instead of ten times.
+ *   calls    HOST, [n_calls]
+ *   out      HOST, [n_calls] pointers to pinned records of 2 * TRX_SCENARIO_OUT + 1 doubles
+ *   streams  HOST, [n_calls] hipStream_t handles (they may repeat; calls on one stream run in order)
+ * Returns the status of the first call that failed (the later ones are not enqueued; *n_done, if given, receives
+ * the number of calls that were). */
+int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, double* const* out, void* const* streams,
+                     int* n_done);
+
 /* Frees the per-stream scratch described above (every device); all streams must be idle. */
 int trx_release_scratch(void);
 

@@ -2,7 +2,7 @@
 tests/golden/make_golden.py: oracle QuadraticModel at the pytransit seam) at N = 1e6 on the
 notebook inputs, on the CPU of the build container.  Tells apart "our device path differs from the
 current reference code" from "the notebooks were made by an older release / by pytransit itself".
-    python profiles/reference_fpp_cpu.py toi465_nocc 5 > profiles/r03_reference_fpp_cpu.txt"""
+    python profiles/reference_fpp_cpu.py toi465_nocc 5 [N] [first seed] > profiles/r03_reference_fpp_cpu.txt"""
 import contextlib
 import io
 import os
@@ -24,9 +24,10 @@ import anchors  # noqa: E402
 case = sys.argv[1] if len(sys.argv) > 1 else "toi465_nocc"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 N = int(float(sys.argv[3])) if len(sys.argv) > 3 else 1_000_000
+first = int(sys.argv[4]) if len(sys.argv) > 4 else 1000          # first seed
 c = anchors.CASES[case]
 stars, t, f, sigma, P = anchors.inputs(case)
-for seed in range(1000, 1000 + runs):
+for seed in range(first, first + runs):
     tg = object.__new__(rtr.target)
     tg.ID, tg.mission, tg.sectors = c["ID"], c["mission"], np.array([1])
     tg.search_radius, tg.N_pix, tg.trilegal_fname, tg.trilegal_url = 10, 22, anchors.TRILEGAL, None

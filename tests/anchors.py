@@ -64,10 +64,18 @@ def run(case, seed, N=1_000_000, sampling="device"):
             float(tg.probs["R_p"].values[0]))
 
 
+_run_cache = {}
+
+
 def run_many(case, seeds, N=1_000_000, sampling="device"):
-    out = [run(case, s, N, sampling) for s in seeds]
-    return (np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out]),
-            np.array([o[3] for o in out]))
+    """(lnZ [runs][15], prob [runs][15], FPP [runs], R_p of the TP row [runs]); kept per (case, seeds, N, mode) so
+    that the test files that look at the same runs share them"""
+    key = (case, tuple(seeds), N, sampling)
+    if key not in _run_cache:
+        out = [run(case, s, N, sampling) for s in seeds]
+        _run_cache[key] = (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+                           np.array([o[2] for o in out]), np.array([o[3] for o in out]))
+    return _run_cache[key]
 
 
 def notebook(case):

@@ -143,6 +143,12 @@ def main():
     for c in st.columns:
         out["kep10_stars_" + c] = st[c].values.astype(float)
     np.savez_compressed(os.path.join(HERE, "notebook_anchors.npz"), **out)
+    # the two unbinned example light curves (data files of the reference's examples/): the input of the
+    # binning variants of profiles/anchor_sensitivity.py (columns: time, flux, flux_err)
+    raw = {}
+    for key, fname in (("toi411", "TOI411_02_lightcurve.csv"), ("toi465", "TOI465_01_lightcurve.csv")):
+        raw[key] = pd.read_csv(os.path.join(EX, fname), header=None).values.astype(float)
+    np.savez_compressed(os.path.join(HERE, "example_lightcurves.npz"), **raw)
     print("toi411: %d points, sigma %.3e; kep10: %d points, sigma %.3e"
           % (tb.size, sg, keep.sum(), out["kep10_sigma"][0]))
 

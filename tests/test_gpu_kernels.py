@@ -468,7 +468,8 @@ def test_mixed_precision_model_tolerance(n_time):
         z64 = float(_lib.lnz_from_halfchi2(h64, None, 30000, np.log(synth.SIGMA)).cpu()[0])
         z32 = float(_lib.lnz_from_halfchi2(h32, None, 30000, np.log(synth.SIGMA)).cpu()[0])
         if np.isfinite(z64):
-            assert abs(z32 - z64) < 0.25, (model, z32, z64, c0)
+            print("fp32 model, %d points, model %d: |d lnZ| = %.3g" % (n_time, model, abs(z32 - z64)))
+            assert abs(z32 - z64) < 0.02, (model, z32, z64, c0)
 
 
 def test_large_batches_spot_checked():

@@ -111,9 +111,12 @@ def test_seeded_run_with_numpy_stream_on_device(tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("sampling", ["numpy", "numpy-device", "device"])
 def test_full_size_run_inside_the_notebook_band(sampling):
-    """N = 1e6, real star table + contrast curve: the notebook reports FPP = 0.0032 +- 0.005 over
-    20 runs of the reference (its TRILEGAL table came from the web; ours is the synthetic fixture).
-    Bar: FPP within 3 standard deviations of that mean, NFPP = 0, TP the leading scenario."""
+    """N = 1e6, real star table + contrast curve, one run in each sampling mode: its FPP must lie inside the
+    distribution of the 64 device-mode runs that tests/test_gpu_notebook_anchors.py holds against the
+    notebook's "0.0032 +- 0.005 over 20 runs" by Welch's statistic (mean +- 4 standard deviations of those
+    runs -- the three modes sample the same distribution; round 3's band here, [0, 0.018], passed anything),
+    NFPP = 0, TP the leading scenario."""
+    import anchors
     import torch
     import triceratops_amd
     triceratops_amd.set_sampling(sampling)
@@ -126,7 +129,9 @@ def test_full_size_run_inside_the_notebook_band(sampling):
         triceratops_amd.set_sampling("numpy")
     print("TOI-465.01 real table, N=1e6, %s sampling: %.2f s, FPP=%.5f NFPP=%.3g" % (sampling, dt, tg.FPP, tg.NFPP))
     assert tg.FPP_degenerate is False and len(tg.lnZ) == 15
-    assert -1e-9 <= tg.FPP < NOTEBOOK_FPP + 3 * NOTEBOOK_STD, tg.FPP     # 1 - sum(p) rounds to -1e-15
+    many = anchors.run_many("toi465_cc", range(1000, 1064))[2]           # shared with the notebook-anchor tests
+    print("   64 device-mode runs: FPP %.5f +- %.5f" % (many.mean(), many.std(ddof=1)))
+    assert -1e-9 <= tg.FPP and abs(tg.FPP - many.mean()) < 4.0 * many.std(ddof=1), (tg.FPP, many.mean(), many.std(ddof=1))
     assert tg.NFPP == 0.0
     assert tg.probs.prob[0] > 0.5 and tg.probs.scenario[0] == "TP"      # TP + PTP + DTP carry 1 - FPP
 
@@ -152,4 +157,7 @@ def test_config3_blend_at_full_size(sampling):
     # a neighbour diluted to 1 % of the aperture flux would need a 50 % deep eclipse: the data rule
     # every nearby scenario out, as in the seeded reference run (NFPP = 2.7e-55 there)
     assert tg.NFPP < 1e-6 and tg.probs.prob[0] > 0.5 and tg.probs.scenario[0] == "TP"
-    assert -1e-9 <= tg.FPP < NOTEBOOK_FPP + 3 * NOTEBOOK_STD, tg.FPP
+    # (the 20 extra stars carry no probability: the blend's FPP is drawn from the distribution of the 15-scenario runs)
+    import anchors
+    many = anchors.run_many("toi465_cc", range(1000, 1064))[2]
+    assert -1e-9 <= tg.FPP and abs(tg.FPP - many.mean()) < 4.0 * many.std(ddof=1), (tg.FPP, many.mean(), many.std(ddof=1))

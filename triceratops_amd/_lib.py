@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "trx_lnl_batch", "trx_flux_grid", "trx_chi2_grid", "trx_workspace_bytes",
     "trx_log_mean_exp", "trx_lnz_scenario", "trx_lnz_from_halfchi2", "trx_lnl_batch_host", "trx_flux_grid_host",
     "trx_log_mean_exp_host", "trx_set_rows_per_wave", "trx_set_supersample_tiers", "trx_set_stencil", "trx_set_skip_excluded", "trx_skipped_rows",
-    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_pruned_rows", "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error",
+    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_pruned_rows", "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_star_enqueue", "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error",
     "trx_device_count",
 )
 
@@ -173,15 +173,21 @@ def compute_device():
 # ---------------------------------------------------------------------------------------
 # device helpers
 _upload_streams = {}
+# events of uploads that may still be in flight: every stream about to read library inputs waits for them ON THE
+# DEVICE (wait_uploads), the host never blocks
+_pending_uploads = []
+_pending_lock = threading.Lock()
 
 
 def dev(x, device=None):
     """float64 contiguous device tensor from array-like / tensor.
 
-    Host arrays go up on a stream of their own: a copy from pageable memory returns when it has completed,
-    so on the caller's stream it would wait for every kernel enqueued there before it -- a lnZ_* call
-    enqueued behind another one's likelihood kernel would stall the host for that kernel's duration.  The
-    data is in place when this returns, whichever stream reads it next."""
+    Host arrays go up asynchronously on a stream of their own, through a pinned staging block: a copy from
+    pageable memory returns when it has COMPLETED, and with the GPU busy that was 0.5 ms per small table (a
+    third of the host time of a 64-target batch step, profiles/r03_f_batch_host_profile.txt).  Nothing waits on
+    the host: the upload leaves an event, the stream that is current here waits for it on the device, and so does
+    every stream a library call is enqueued on while the event is pending (wait_uploads; cached tables are read
+    by calls on other streams a few microseconds later)."""
     if isinstance(x, torch.Tensor):
         return x.to(device=device or "cuda", dtype=torch.float64).contiguous()
     a = np.ascontiguousarray(x, dtype=np.float64)
@@ -190,10 +196,30 @@ def dev(x, device=None):
         return torch.as_tensor(a).to(d).contiguous()
     if d.index is None:
         d = torch.device("cuda", torch.cuda.current_device())
-    with upload_stream(d):
-        t = torch.as_tensor(a).to(d)
-    t.record_stream(torch.cuda.current_stream(d))      # the allocator must not hand the block out early
+    up = upload_stream(d).stream
+    staged = torch.empty(a.shape, dtype=torch.float64, pin_memory=True)    # (torch caches pinned blocks)
+    staged.numpy()[...] = a
+    with torch.cuda.stream(up):
+        t = staged.to(d, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(up)
+    cur = torch.cuda.current_stream(d)
+    cur.wait_event(ev)
+    t.record_stream(cur)      # the allocator must not hand the block out early
+    with _pending_lock:
+        _pending_uploads.append(ev)
     return t
+
+
+def wait_uploads(stream):
+    """`stream` waits (on the device) for every upload that has not completed yet"""
+    if not _pending_uploads:
+        return
+    with _pending_lock:
+        live = [ev for ev in _pending_uploads if not ev.query()]
+        _pending_uploads[:] = live
+    for ev in live:
+        stream.wait_event(ev)
 
 
 class upload_stream:
@@ -225,7 +251,10 @@ class upload_stream:
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """the stream a library call is enqueued on (behind the uploads still in flight)"""
+    st = torch.cuda.current_stream(t.device)
+    wait_uploads(st)
+    return st.cuda_stream
 
 
 _ws = {}

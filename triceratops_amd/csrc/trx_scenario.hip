@@ -210,6 +210,19 @@ extern "C" int trx_scenario_enqueue(const trx_scenario_args* s, double* out, voi
     return enqueue(s, out, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, double* const* out, void* const* streams,
+                                int* n_done)
+{
+    if (n_done) *n_done = 0;
+    if (n_calls < 0 || (n_calls > 0 && (!calls || !out || !streams))) return TRX_ERR_ARG;
+    for (int i = 0; i < n_calls; ++i) {
+        if (!calls[i].draw || !out[i]) return TRX_ERR_ARG;
+        if (int rc = enqueue(&calls[i], out[i], static_cast<hipStream_t>(streams[i]))) return rc;
+        if (n_done) *n_done = i + 1;
+    }
+    return TRX_OK;
+}
+
 extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
 {
     if (!s || !s->draw || !s->out || !s->out_flag) return TRX_ERR_ARG;

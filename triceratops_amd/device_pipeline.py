@@ -70,12 +70,15 @@ class _Field:
         d = self._device = ctx["device"]
         self._mission = mission
         self.N_comp = h.N_comp
-        # the nine columns in one upload (a few thousand stars): rows of one block
-        block = _lib.dev(np.stack([h.masses, h.loggs, h.Teffs, h.fluxratios, h.dT, h.dJ, h.dH, h.dK, h.radii()]), d)
+        # the nine columns and the four band flux ratios in ONE upload (a few thousand stars): rows of one block.
+        # (the band flux ratios were torch expressions on the device until round 3: three launches and a stream
+        # synchronisation per star for numbers numpy has in microseconds -- marginal_likelihoods._Field)
+        bands = [h.band_fluxratio(b) for b in ("T", "J", "H", "K")]
+        block = _lib.dev(np.stack([h.masses, h.loggs, h.Teffs, h.fluxratios, h.dT, h.dJ, h.dH, h.dK, h.radii()] + bands), d)
         self.masses, self.loggs, self.Teffs, self.fluxratios = block[0], block[1], block[2], block[3]
         self.delta = {"T": block[4], "J": block[5], "H": block[6], "K": block[7]}
         self.radii = block[8]
-        self._band_fr = {}
+        self._band_fr = {"T": block[9], "J": block[10], "H": block[11], "K": block[12]}
         self.u1 = self.u2 = None
         if need_ldc:
             self.need_ldc()
@@ -92,10 +95,4 @@ class _Field:
         return self.delta.get(filt, self.delta["T"])
 
     def band_fluxratio(self, filt):
-        key = filt if filt in self.delta else "T"
-        fr = self._band_fr.get(key)
-        if fr is None:
-            dm = self.delta[key]
-            with _lib.upload_stream(self._device):       # kept: calls on other streams read it later
-                fr = self._band_fr[key] = 10 ** (dm / 2.5) / (1 + 10 ** (dm / 2.5))
-        return fr
+        return self._band_fr.get(filt, self._band_fr["T"])

@@ -122,6 +122,9 @@ def _fn_scenario():
         L.trx_scenario_evidence.argtypes = [ctypes.POINTER(ScenarioArgs), _vp]
         L.trx_scenario_enqueue.restype = ctypes.c_int
         L.trx_scenario_enqueue.argtypes = [ctypes.POINTER(ScenarioArgs), _vp, _vp]
+        L.trx_star_enqueue.restype = ctypes.c_int
+        L.trx_star_enqueue.argtypes = [ctypes.POINTER(ScenarioArgs), ctypes.c_int, ctypes.POINTER(_vp),
+                                       ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int)]
         L.trx_scenario_args_size.restype = ctypes.c_size_t
         if L.trx_scenario_args_size() != ctypes.sizeof(ScenarioArgs):
             raise _lib.TrxError("trx_scenario_args layout mismatch: library %d bytes, binding %d"
@@ -166,13 +169,42 @@ _stats_lock = threading.Lock()
 
 def begin_deferred(n_calls):
     """this thread's native lnZ_* calls return Pending objects until end_deferred(); n_calls bounds
-    their number (one pinned block holds all their records)"""
-    _tls.records = torch.empty((max(int(n_calls), 1), RECORD), dtype=F64).pin_memory()
+    their number (one pinned block holds all their records).  The calls are not handed to the library one by
+    one: they collect in a list that flush() passes on in ONE call (trx_star_enqueue) -- sharding.run_units
+    flushes at the end of every star's units."""
+    _tls.records = torch.empty((max(int(n_calls), 1), RECORD), dtype=F64, pin_memory=True)
     _tls.next_record = 0
+    _tls.batch = []
+
+
+def flush():
+    """hand the calls collected since the last flush to the library: one trx_star_enqueue"""
+    batch = getattr(_tls, "batch", None)
+    if not batch:
+        return
+    _tls.batch = []
+    n = len(batch)
+    calls = (ScenarioArgs * n)()
+    outs, sts = (_vp * n)(), (_vp * n)()
+    waited = set()
+    for i, (sa, out, stream, dev) in enumerate(batch):
+        calls[i] = sa
+        outs[i], sts[i] = out.data_ptr(), stream.cuda_stream
+        if stream.cuda_stream not in waited:
+            waited.add(stream.cuda_stream)
+            _lib.wait_uploads(stream)
+    done = ctypes.c_int(0)
+    _fn_scenario()
+    with torch.cuda.device(batch[0][3]):
+        rc = _lib.lib().trx_star_enqueue(calls, n, outs, sts, ctypes.byref(done))
+    if rc:
+        raise _lib.TrxError("trx_star_enqueue failed at call %d of %d with status %d: %s"
+                            % (done.value, n, rc, _lib.lib().trx_last_error().decode()))
 
 
 def end_deferred():
     _tls.records = None
+    _tls.batch = None
 
 
 def _record_slot():
@@ -235,8 +267,21 @@ def _rp_laws():
     return out
 
 
+_q_law_cache = {}
+
+
 def _q_law(M_s, p_hi, F_twin):
-    """tests/torch_pipeline._mass_ratio (priors.py:168-383)"""
+    """tests/torch_pipeline._mass_ratio (priors.py:168-383); constants of a star's calls are built once"""
+    key = (float(M_s), p_hi, F_twin)
+    law = _q_law_cache.get(key)
+    if law is None:
+        if len(_q_law_cache) > 256:
+            _q_law_cache.clear()
+        law = _q_law_cache[key] = _q_law_build(M_s, p_hi, F_twin)
+    return law
+
+
+def _q_law_build(M_s, p_hi, F_twin):
     if M_s <= 0.1:
         law = PowerLaw()
         law.ones = 1
@@ -259,6 +304,7 @@ def _q_law(M_s, p_hi, F_twin):
 
 _RP = None
 _tab_cache = {}
+_ldc_star_cache = {}
 
 
 def _spline_table(device, band):
@@ -283,9 +329,19 @@ def _spline_table(device, band):
     return _tab_cache[key]
 
 
+_flux0_cache = {}
+
+
 def _flux0(M_s, band):
-    """flux_relation(M_s) as tests/torch_pipeline._flux_share forms it"""
-    return float(10 ** funcs._flux_spl[band](np.array([M_s]))[0])
+    """flux_relation(M_s) as tests/torch_pipeline._flux_share forms it (the ten calls of a star ask for the
+    same two or three values: kept)"""
+    key = (float(M_s), band)
+    v = _flux0_cache.get(key)
+    if v is None:
+        if len(_flux0_cache) > 256:
+            _flux0_cache.clear()
+        v = _flux0_cache[key] = float(10 ** funcs._flux_spl[band](np.array([M_s]))[0])
+    return v
 
 
 _cc_cache = {}
@@ -421,7 +477,13 @@ class _Scenario:
         a = self.a
         a.M_s, a.R_s, a.Teff = float(M_s), float(R_s), float(Teff)
         if Z is not None:
-            a.u1, a.u2 = ml._ldc(self.mission).star(Z, Teff, ml._logg(M_s, R_s))
+            key = (self.mission, float(Z), float(Teff), float(M_s), float(R_s))
+            uu = _ldc_star_cache.get(key)
+            if uu is None:
+                if len(_ldc_star_cache) > 256:
+                    _ldc_star_cache.clear()
+                uu = _ldc_star_cache[key] = ml._ldc(self.mission).star(Z, Teff, ml._logg(M_s, R_s))
+            a.u1, a.u2 = uu
         a.f0_tess = _flux0(M_s, "TESS")
         a.law_q = _q_law(M_s, -0.5, 0.30)
 
@@ -539,6 +601,7 @@ class _Scenario:
             a.dump = dump.data_ptr()
             DUMP.append({"dump": dump, "cols": cols, "mask": mask, "mask_twin": mask2, "lnprior": lnprior})
         with torch.cuda.device(dev):
+            _lib.wait_uploads(torch.cuda.current_stream(dev))
             rc = _fn()(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             raise _lib.TrxError("trx_draw_scenario failed with status %d" % rc)
@@ -582,15 +645,19 @@ class _Scenario:
                     | _lib.EXTRA_FLAGS)
         sa.want_prior = int(self.want_prior)
         out, deferred = _record_slot()
+        stream = torch.cuda.current_stream(dev)
+        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time)
+        self.keep = []
+        if deferred and getattr(_tls, "batch", None) is not None:
+            _tls.batch.append((sa, out, stream, dev))      # (sa.draw points at self.a: alive in the Pending)
+            return pend
         fn = _fn_scenario()
+        _lib.wait_uploads(stream)
         with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev)
             rc = fn(ctypes.byref(sa), out.data_ptr(), stream.cuda_stream)
         if rc:
             raise _lib.TrxError("trx_scenario_enqueue failed with status %d: %s"
                                 % (rc, _lib.lib().trx_last_error().decode()))
-        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time)
-        self.keep = []
         if deferred:
             return pend
         stream.synchronize()

@@ -43,7 +43,8 @@ threads = 1
 # step on one stream, 0.49 on three, 0.43 on six, no gain beyond.
 streams = int(os.environ.get("TRX_STREAMS", "6"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
-timing = {"enqueue_s": 0.0, "wait_s": 0.0}
+# (+ the collective, and -- calc_probs_many -- the unit lists and the result tables of all targets)
+timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "finish_s": 0.0}
 # seed bases of the ranks of the last multi-rank run_units (from the all_gather's header rows)
 last_seed_bases = None
 # The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
@@ -209,11 +210,14 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             # dealt round-robin, the planet calls and the dearer binary calls of a star's twelve end up on
             # different streams whenever their number divides twelve, and the step waits for the slowest
             load = [0.0] * len(pool)
-            for k in mine_k:
+            for n_, k in enumerate(mine_k):
                 j = min(range(len(pool)), key=lambda i: (load[i], i))
                 load[j] += _COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
                 with torch.cuda.stream(pool[j]):
                     one(k)
+                # the calls of one star go to the library together (trx_star_enqueue): at the last unit of a star
+                if n_ + 1 == len(mine_k) or units[mine_k[n_ + 1]][3] != units[k][3]:
+                    _fused.flush()
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
                 st.synchronize()
@@ -252,6 +256,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                         except queue.Empty:
                             break
                         one(k)
+                        _fused.flush()
             except BaseException as exc:              # re-raised in the caller's thread
                 errors.append(exc)
             finally:
@@ -273,7 +278,9 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         # ONE collective: every rank contributes the records of its own units (in unit order, padded to the
         # largest share) behind one header row that carries its seed base -- 15 doubles per scenario, a few KB
         # per rank, latency-bound: a direct all_gather, no ring, no bucketing
+        import time
         import torch
+        t_g = time.perf_counter()
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         ncol = len(RECORD_COLS)
         share = [sum(rows[k] for k in live if owner[k] == r) for r in range(world)]
@@ -294,6 +301,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             r = owner[k]
             table[offs[k]:offs[k] + rows[k]] = g[r, at[r]:at[r] + rows[k]]
             at[r] += rows[k]
+        timing["gather_s"] = time.perf_counter() - t_g
 
     out = []
     for k, u in enumerate(units):

@@ -128,8 +128,9 @@ class target:
         is called, i.e. only on the rank that owns it (sharding.run_units)."""
         units = []
         ok = True
-        col = {c: filtered[c].to_numpy() for c in ("fluxratio", "mass", "rad", "Teff", "Tmag", "Jmag",
-                                                   "Hmag", "Kmag", "plx")}
+        keep, stars = filtered
+        col = {c: stars[c].to_numpy()[keep] for c in ("fluxratio", "mass", "rad", "Teff", "Tmag", "Jmag",
+                                                      "Hmag", "Kmag", "plx")}
         tail = (N, parallel, self.mission, flatpriors, exptime, nsamples)
         trilegal = self.trilegal_fname
         fns = {"TP": lnZ_TTP, "EB": lnZ_TEB, "PTP": lnZ_PTP, "PEB": lnZ_PEB, "STP": lnZ_STP, "SEB": lnZ_SEB,
@@ -162,7 +163,7 @@ class target:
         def nearby_call(i, fn):
             return fn(*star_args(i), 0.0, *tail)
 
-        for i, ID in enumerate(filtered["ID"].to_numpy()):
+        for i, ID in enumerate(stars["ID"].to_numpy()[keep]):
             if i == 0:
                 if (np.isnan(col["mass"][0]) or np.isnan(col["rad"][0]) or np.isnan(col["Teff"][0])
                         or np.isnan(col["plx"][0])):
@@ -203,8 +204,11 @@ class target:
         flux_0 = np.asarray(flux_0, dtype=np.float64)
         keep = ~np.isnan(time) & ~np.isnan(flux_0)
         time, flux_0 = time[keep], flux_0[keep]
-        filtered = self.stars[self.stars["tdepth"] > 0]
-        n_scen = 3 * len(filtered) + 12
+        # (the stars that can host the signal, triceratops.py:712; as a row mask over the table's own columns --
+        # a filtered copy of the DataFrame costs more than everything else in here)
+        keep = self.stars["tdepth"].to_numpy() > 0
+        filtered = (keep, self.stars)
+        n_scen = 3 * int(keep.sum()) + 12
         needs_field = not all(k in drop_scenario for k in ("DTP", "DEB", "BTP", "BEB"))
         if self.trilegal_fname is None and needs_field:
             raise ValueError("trilegal_fname is required for the D and B scenarios (the TRILEGAL "
@@ -346,15 +350,23 @@ def calc_probs_many(jobs, verbose: int = 0):
     all_gather as one calc_probs; every target then gets its own table, FPP and NFPP.  On one GPU
     without per-unit seeding this is the jobs' calc_probs calls one after the other on one random
     stream."""
+    import time as _time
+    t0 = _time.perf_counter()
     prepared = []
     for tg, kw in jobs:
         kw = dict(kw)
         kw.pop("verbose", None)
         prepared.append((tg,) + tg._prepare(**kw))
     flat = [u for _, units, _ in prepared for u in units]
+    t1 = _time.perf_counter()
     results = sharding.run_units(flat, verbose=verbose)
+    t2 = _time.perf_counter()
     at = 0
     for tg, units, n_scen in prepared:
         tg._finish(units, results[at:at + len(units)], n_scen)
         at += len(units)
+    # every rank lists the units of all targets (cheap: no argument is built before a unit's owner calls it)
+    # and fills every target's table from the gathered records; both are a few ms for 64 targets
+    sharding.timing["prepare_s"] = t1 - t0
+    sharding.timing["finish_s"] = _time.perf_counter() - t2
     return [tg for tg, _ in jobs]
