@@ -83,6 +83,8 @@ struct RowsArgs {
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS (shared by the workgroup's waves)
     int wave_off, wave_doubles;   // cells_kernel: offset of the first wave's own LDS block and the size of one (in doubles)
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
+    int* scan_list;                      // rowc_kernel -> sec_scan_kernel: the rows whose secondary-eclipse verdict is open
+    unsigned long long* scan_count;      // ... and their number
     // Rows counted on the device (trx_scenario_evidence: the draws that passed the geometry mask): when
     // n_dev is set the kernels read the row count from it and `n` is only its upper bound (grid, scratch);
     // the rows-per-wave of the batched variant and the batch count follow from the count on the device
@@ -248,40 +250,103 @@ constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXm
 constexpr long kPilotRows = 4096;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
-// Row constants of 64 rows per workgroup, every lane of the first wave on a row of its own, written to a.rowc[n][kRowDoubles]; the secondary-eclipse depth goes to a.out_sec (grid).
-// 256 threads per 64 rows: the first wave derives the constants (lanes = rows), then the 64 x 25
-// (row, point) cells of the secondary-eclipse scan are dealt to all four waves -- the scan is an
-// eighth of an EB row's work at 100 points, and one wave per 64 rows leaves the chip a third full.
-// Only the secondary orbits are staged in LDS (9 KB); the scan's minimum is taken with LDS atomics
-// (min ignores NaN, so NaN is flagged separately).
-__device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, const long blk, RowC* srows, RowC* rows_out,
-                                           double* secmin, int* secnan)
+// Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
+// depend on the row count, which may only be known on the device): one 64-bit counter, then one int per row.
+__host__ __device__ inline size_t scan_list_doubles(long n_upper) { return 2 + (size_t)(n_upper + 1) / 2; }
+
+// The constants of one row (lanes = rows): unit conversion (likelihoods.py:337-347, 399-411), the radius-ratio rule,
+// orbit constants and transit window, dilution, limb weights -> c.  EB rows whose secondary depth is used (need_sec)
+// also get the orbit of the secondary eclipse (sc) and the two dilution constants of its depth.
+__device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, const long row, RowC& c, const bool want_sec,
+                                              RowC& sc, double& ysec, double& fdil)
 {
-    const int lane = threadIdx.x;
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
     const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
-    const long base = blk * 64;
-    const int nb = (int)((n - base < 64) ? (n - base < 0 ? 0 : n - base) : 64);
-    double ysec = 0.0, fdil = 0.0;
-    double* dst = a.rowc + (base + lane) * kRowDoubles;
-    // the launch's header (flat-model chi^2, stencil verdict): waves 3 and 2 of block 0 beside its rows -- or, in a
-    // launch of one-wave workgroups, a workgroup of its own (blk < 0: the last one of the grid), since a single wave
-    // doing them before its rows would be the launch's long pole on a 2000-point light curve
-    const bool one_wave = blockDim.x == 64;
-    const bool header_only = blk < 0;
-    if ((one_wave ? header_only : (blk == 0 && (lane >> 6) == 3)) && a.flux) {
+    // row r = column r of the [n_param][n] block, or draw src_idx[r] of a [n_param][src_stride] one
+    const double* p = a.params + (a.src_idx ? (long)a.src_idx[row] : row);
+    const long ps = a.src_idx ? a.src_stride : n;
+    double u1, u2;
+    ysec = 0.0;
+    fdil = 0.0;
+    if (a.model == TRX_MODEL_RAW) {
+        u1 = p[7 * ps]; u2 = p[8 * ps];
+        orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
+        c.rdil = 1.0;
+    } else {
+        double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
+        if (a.model == TRX_MODEL_TP) {
+            const double R_p = p[0];
+            per = p[1 * ps]; inc = p[2 * ps]; acm = p[3 * ps]; R_s = p[4 * ps];
+            u1 = p[5 * ps]; u2 = p[6 * ps]; e = p[7 * ps]; argp = p[8 * ps]; comp_fr = p[9 * ps];
+            k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
+        } else {
+            const double R_EB = p[0], eb_fr = p[1 * ps];
+            per = p[2 * ps]; inc = p[3 * ps]; acm = p[4 * ps]; R_s = p[5 * ps];
+            u1 = p[6 * ps]; u2 = p[7 * ps]; e = p[8 * ps]; argp = p[9 * ps]; comp_fr = p[10 * ps];
+            if (a.twin_cols) {                   // marginal_likelihoods.py:300-339: twice the period and its a
+                per = per * 2.0;
+                acm = p[11 * ps];
+            }
+            feb = eb_fr / (1.0 - eb_fr);                            // :401
+            k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
+            ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
+        }
+        const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
+        const double a_R = acm / (R_s * kRsun);                     // :343, :409
+        const double inc_r = inc * (kPi / 180.0);                   // :344, :410
+        const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
+        orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+        double xeb = 0.0;
+        if (!eblike) {
+            fdil = is_host ? (1.0 / fcomp) : fcomp;                 // :352-357
+        } else {
+            if (want_sec) {
+                const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
+                orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
+                const Limb L = limb_weights(u1, u2);
+                sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
+                sc.rdil = 1.0; sc.excl = 0.0;
+            }
+            if (is_host) {                                          // :427-432
+                xeb = feb / fcomp;
+                ysec = fcomp / feb;
+                fdil = 1.0 / (fcomp + feb);
+            } else {                                                // :433-438
+                xeb = feb / 1.0;
+                ysec = 1.0 / feb;
+                fdil = fcomp / (1.0 + feb);
+            }
+        }
+        // the two dilution stages as one factor on the flux DEFICIT: (m + x)/(1 + x) = 1 - (1 - m)/(1 + x), so
+        // an unocculted point stays exactly 1 and a cell costs one fma instead of two divisions; a flux ratio
+        // that is not finite makes the reference's quotient NaN (inf / inf), hence NaN here
+        c.rdil = 1.0 / ((1.0 + xeb) * (1.0 + fdil));
+        if (!(fabs(xeb) < INFINITY) || !(fabs(fdil) < INFINITY)) c.rdil = NAN;
+    }
+    const Limb L = limb_weights(u1, u2);
+    c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
+    c.excl = 0.0;
+}
+
+// The launch's header (flat-model chi^2, stencil verdict, bounds of the bounded evaluation, the scan's counter):
+// a workgroup of its own (the last one of rowc_kernel's grid), since a wave doing it before its rows would be the
+// launch's long pole on a 2000-point light curve.
+__device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
+{
+    const int lane = threadIdx.x;
+    double* hdr = a.rowc + n * kRowDoubles;
+    if (a.flux) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
         double acc = 0.0;
-        for (int j = lane & 63; j < a.n_time; j += 64) {
+        for (int j = lane; j < a.n_time; j += 64) {
             const double d = a.flux[j] - 1.0;
             acc = fma(d * d, a.rs2, acc);            // (every chi^2 term of the path is (f - m)^2 x (1 / sigma^2): the
                                                      // same operation everywhere, so that flat rows tie exactly)
         }
         acc = wave_sum(acc);
-        if ((lane & 63) == 0) {
-            double* hdr = a.rowc + n * kRowDoubles;
+        if (lane == 0) {
             hdr[kHdrFlat] = acc;
             // running bounds of the launch (cells_kernel<PRUNE>): the smallest chi^2/2 and the largest
             // log-weight among the rows finished so far
@@ -290,10 +355,9 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             hdr[kHdrProbe] = 1.0;
         }
     }
-    if (one_wave ? header_only : (blk == 0 && (lane >> 6) == 2)) {
-        // is the time grid uniform and dense enough for the centre-value stencil?  (wave 2)
-        double* hdr = a.rowc + n * kRowDoubles;
-        const int l = lane & 63, nt = a.n_time;
+    {
+        // is the time grid uniform and dense enough for the centre-value stencil?
+        const int l = lane, nt = a.n_time;
         bool ok = a.use_stencil && nt >= 64 && a.S >= 2 && a.exptime > 0.0;
         double dt = 0.0, t0 = 0.0;
         if (ok) {
@@ -352,172 +416,131 @@ __device__ __forceinline__ void rowc_block(const RowsArgs& a, const long n, cons
             if (a.memo) *a.memo = (radius > 0.0) ? 2 : 1;
         }
     }
-    if (header_only) return;
-    if (lane < nb) {
-        // row r = column r of the [n_param][n] block, or draw src_idx[r] of a [n_param][src_stride] one
-        const double* p = a.params + (a.src_idx ? (long)a.src_idx[base + lane] : base + lane);
-        const long ps = a.src_idx ? a.src_stride : n;
-        RowC c;
-        double u1, u2;
-        if (a.model == TRX_MODEL_RAW) {
-            u1 = p[7 * ps]; u2 = p[8 * ps];
-            orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
-            c.rdil = 1.0;
-        } else {
-            double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
-            if (a.model == TRX_MODEL_TP) {
-                const double R_p = p[0];
-                per = p[1 * ps]; inc = p[2 * ps]; acm = p[3 * ps]; R_s = p[4 * ps];
-                u1 = p[5 * ps]; u2 = p[6 * ps]; e = p[7 * ps]; argp = p[8 * ps]; comp_fr = p[9 * ps];
-                k = R_p * kRearth / (R_s * kRsun);                      // likelihoods.py:340
-            } else {
-                const double R_EB = p[0], eb_fr = p[1 * ps];
-                per = p[2 * ps]; inc = p[3 * ps]; acm = p[4 * ps]; R_s = p[5 * ps];
-                u1 = p[6 * ps]; u2 = p[7 * ps]; e = p[8 * ps]; argp = p[9 * ps]; comp_fr = p[10 * ps];
-                if (a.twin_cols) {                   // marginal_likelihoods.py:300-339: twice the period and its a
-                    per = per * 2.0;
-                    acm = p[11 * ps];
-                }
-                feb = eb_fr / (1.0 - eb_fr);                            // :401
-                k = k_rule(R_EB / R_s, scalar_k);                       // :405-406
-                ksec = scalar_k ? (1.0 / k) : k_rule(R_s / R_EB, false); // :137 / :417-418
-            }
-            const double fcomp = comp_fr / (1.0 - comp_fr);             // :337, :399
-            const double a_R = acm / (R_s * kRsun);                     // :343, :409
-            const double inc_r = inc * (kPi / 180.0);                   // :344, :410
-            const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
-            orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
-            double xeb = 0.0;
-            if (!eblike) {
-                fdil = is_host ? (1.0 / fcomp) : fcomp;                 // :352-357
-            } else {
-                if (a.need_sec) {
-                    RowC& sc = srows[lane];
-                    const double wsec = (90.0 - argp + 180.0) * (kPi / 180.0);  // :419
-                    orbit_init<false>(sc, ksec, 0.0, per, a_R, inc_r, e, wsec, 0.0);
-                    const Limb L = limb_weights(u1, u2);
-                    sc.cle = L.cle; sc.cld = L.cld; sc.ced = L.ced;
-                    sc.rdil = 1.0; sc.excl = 0.0;
-                }
-                if (is_host) {                                          // :427-432
-                    xeb = feb / fcomp;
-                    ysec = fcomp / feb;
-                    fdil = 1.0 / (fcomp + feb);
-                } else {                                                // :433-438
-                    xeb = feb / 1.0;
-                    ysec = 1.0 / feb;
-                    fdil = fcomp / (1.0 + feb);
-                }
-            }
-            // the two dilution stages as one factor on the flux DEFICIT: (m + x)/(1 + x) = 1 - (1 - m)/(1 + x), so
-            // an unocculted point stays exactly 1 and a cell costs one fma instead of two divisions; a flux ratio
-            // that is not finite makes the reference's quotient NaN (inf / inf), hence NaN here
-            c.rdil = 1.0 / ((1.0 + xeb) * (1.0 + fdil));
-            if (!(fabs(xeb) < INFINITY) || !(fabs(fdil) < INFINITY)) c.rdil = NAN;
-        }
-        const Limb L = limb_weights(u1, u2);
-        c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
-        c.excl = 0.0;
-        // through LDS to memory: 64 x 19 doubles leave the block as one contiguous 9.5 KB run (a lane
-        // writing its own 152-byte block made every store instruction touch 64 cache lines)
-        const double* src = reinterpret_cast<const double*>(&c);
-        double* stage = reinterpret_cast<double*>(&rows_out[lane]);
-#pragma unroll
-        for (int q = 0; q < kRowDoubles; ++q) stage[q] = src[q];
+}
+
+// Row constants of 64 rows per workgroup (one wave: lanes = rows), written to a.rowc[n][kRowDoubles] as one
+// contiguous run through LDS.
+//
+// The secondary eclipse of an EB row (likelihoods.py:417-424: the model over np.linspace(-0.05, 0.05, 25) around the
+// secondary conjunction, its minimum diluted into `secdepth`).  Likelihood calls only need the verdict "depth >= 1.5
+// sigma" (:535-538), and the scan's minimum can only be deeper than any one of its points: the point at the
+// secondary conjunction (the 13th of the 25) settles 97 % of the draws of a typical lnZ_*EB call right here, lanes =
+// rows.  The rows it leaves open go on a list in scratch -- one atomic per wave -- and sec_scan_kernel, enqueued
+// behind this kernel, scans only those, compacted ACROSS workgroups (until round 3 the scan ran inside this kernel on
+// the few open rows of each 64-row block: 256 threads per block of which one wave derived the constants, a serial
+// chain of ~2000 fp64 instructions at a quarter of the wave slots -- 232 us per call of a 75-scenario calc_probs).
+// When the depth itself is asked for (trx_flux_grid's out_secdepth) every row is scanned: no list, no quick test, and
+// the secondary orbit is derived by the scan kernel.
+template <bool SEC>
+__global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
+{
+    __shared__ RowC rows_out[64];
+    const int lane = threadIdx.x;
+    const long n = a.n_dev ? *a.n_dev : a.n;
+    const long nblk = (n + 63) / 64;
+    // the last workgroup writes the launch header, the others stride over the blocks of rows (with the row count
+    // on the device the grid is a guess)
+    if (blockIdx.x == gridDim.x - 1) {
+        launch_header(a, n);
+        return;
     }
-    __syncthreads();
-    {
-        const double* src = reinterpret_cast<const double*>(rows_out);
-        double* out = a.rowc + base * kRowDoubles;
-        for (int i = lane; i < nb * kRowDoubles; i += (int)blockDim.x) out[i] = src[i];
-    }
-    // the scan decides the exclusion rule of lnL_EB_p (likelihoods.py:535-538) and the secdepth
-    // output of simulate_EB_transit_p; lnL_EB_twin_p (:542-587) uses neither
-    if (!a.need_sec) return;
-    if (lane < 64) { secmin[lane] = INFINITY; secnan[lane] = 0; }
-    // Likelihood calls only need the verdict "depth >= 1.5 sigma", and the scan's minimum can only be deeper
-    // than any one of its points: the point at the secondary conjunction (the 13th of the 25) alone settles 97 %
-    // of the draws of a typical lnZ_*EB call, the other 24 points are evaluated for the rest (and for every row
-    // when the depth itself is asked for: trx_flux_grid's out_secdepth).
-    __shared__ unsigned char undecided[64];
-    __shared__ int n_undecided;
-    const bool quick = a.out_sec == nullptr;
-#ifdef TRX_SEC_FULL_SCAN
-    const bool use_quick = false;
+    const bool quick = SEC && a.out_sec == nullptr;
+    int* list = a.scan_list;
+    unsigned long long* count = a.scan_count;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x - 1) {
+        const long base = blk * 64;
+        const int nb = (int)((n - base < 64) ? (n - base) : 64);
+        bool open = false;
+        if (lane < nb) {
+            RowC c, sc;
+            double ysec, fdil;
+            row_constants(a, n, base + lane, c, quick, sc, ysec, fdil);
+            if (quick) {
+#ifndef TRX_SEC_FULL_SCAN
+                const Limb L{sc.cle, sc.cld, sc.ced};
+                const double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, 12.0), -0.05);       // linspace(-0.05, 0.05, 25)[12]
+                const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
+                const double m = (f + ysec) / (1.0 + ysec);
+                const double depth = 1.0 - (m + fdil) / (1.0 + fdil);
+                // deep enough already (or NaN: np.min would propagate it) -> RowC::excl, :535; else the scan decides
+                if (!(depth < 1.5 * a.sigma)) c.excl = 1.0;
+                else open = true;
 #else
-    const bool use_quick = quick;
+                open = true;
 #endif
-    if (lane == 0) n_undecided = 0;
-    __syncthreads();
-    bool open = false;                                      // this lane's row still needs the scan
-    if (lane < 64) {
-        open = lane < nb;
-        if (open && use_quick) {
-            const RowC sc = srows[lane];
-            const Limb L{sc.cle, sc.cld, sc.ced};
-            const double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, 12.0), -0.05);       // linspace(-0.05, 0.05, 25)[12]
-            const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
-            const double m = (f + ysec) / (1.0 + ysec);
-            const double depth = 1.0 - (m + fdil) / (1.0 + fdil);
-            if (!(depth < 1.5 * a.sigma)) {                 // deep enough already (or NaN: np.min would propagate it)
-                dst[kRowDoubles - 1] = 1.0;                 // RowC::excl, :535
-                open = false;
+            }
+            // through LDS to memory: 64 x 19 doubles leave the block as one contiguous 9.5 KB run (a lane
+            // writing its own 152-byte block made every store instruction touch 64 cache lines)
+            const double* src = reinterpret_cast<const double*>(&c);
+            double* stage = reinterpret_cast<double*>(&rows_out[lane]);
+#pragma unroll
+            for (int q = 0; q < kRowDoubles; ++q) stage[q] = src[q];
+        }
+        if (quick) {
+            const unsigned long long mo = __ballot(open);
+            if (mo) {
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(count, (unsigned long long)__popcll(mo));
+                at = __shfl(at, 0, 64);
+                if (open) list[at + lanes_below(mo)] = (int)(base + lane);
             }
         }
-        const unsigned long long mo = __ballot(open);
-        if (open) undecided[lanes_below(mo)] = (unsigned char)lane;
-        if (lane == 0) n_undecided = __popcll(mo);
-    }
-    __syncthreads();
-    const int nu = n_undecided;
-    for (int it = lane; it < nu * kSecPoints; it += 256) {
-        const int ri = it / kSecPoints, j = it - ri * kSecPoints;
-        const int r = undecided[ri];
-        const RowC sc = srows[r];
-        const Limb L{sc.cle, sc.cld, sc.ced};
-        // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
-        double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
-        if (j == kSecPoints - 1) ts = 0.05;
-        const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
-        if (f != f) atomicOr(&secnan[r], 1);
-        else __hip_atomic_fetch_min(&secmin[r], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    if (open) {
-        double m = secnan[lane] ? NAN : secmin[lane];                   // np.min propagates NaN
-        m = (m + ysec) / (1.0 + ysec);
-        const double secdepth = 1.0 - (m + fdil) / (1.0 + fdil);
-        dst[kRowDoubles - 1] = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;  // RowC::excl, :535
-        if (a.out_sec) a.out_sec[base + lane] = secdepth;
+        __syncthreads();
+        {
+            const double* src = reinterpret_cast<const double*>(rows_out);
+            double* out = a.rowc + base * kRowDoubles;
+            for (int i = lane; i < nb * kRowDoubles; i += 64) out[i] = src[i];
+        }
+        __syncthreads();
     }
 }
 
-// SEC: the launch needs the secondary-eclipse scan (256 threads per 64 rows: all four waves share it).  Without it
-// only the first wave of such a workgroup had work -- three working waves per CU, a serial chain of ~1500 fp64
-// instructions each: the kernel was latency-bound at a third of a CU's wave slots.  Those launches now take 64
-// threads per 64 rows and half the LDS: twelve working waves per CU (32 -> 13 us per 1e5 rows).
-template <bool SEC>
-__global__ __launch_bounds__(256) void rowc_kernel(RowsArgs a)
+// The 25-point scan of the rows rowc_kernel<true> left open (or of every row when the depth itself is asked for):
+// 64 list entries per workgroup.  Lanes = rows derive the secondary orbit (full lanes: the list is compact), then the
+// 64 x 25 (row, point) cells are dealt to the lanes -- the points are reached by Newton steps from the secondary
+// conjunction -- the minimum is taken with LDS atomics (min ignores NaN, so NaN is flagged separately: np.min
+// propagates it), and lanes = rows turn it into the exclusion flag of the row's block / the secdepth output.
+__global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
 {
-    __shared__ RowC srows[SEC ? 64 : 1];
-    __shared__ RowC rows_out[64];
+    __shared__ RowC srows[64];
     __shared__ double secmin[64];
     __shared__ int secnan[64];
+    const int lane = threadIdx.x;
     const long n = a.n_dev ? *a.n_dev : a.n;
-    const long nblk = (n + 63) / 64;
-    // one block of 64 rows per workgroup; with the row count on the device the grid is a guess and the
-    // workgroups stride over the blocks (block 0 always runs: it writes the launch header)
-    if (!SEC) {
-        // (one-wave workgroups: the last one writes the launch header, the others stride over the blocks of rows)
-        if (blockIdx.x == gridDim.x - 1) { rowc_block(a, n, -1, srows, rows_out, secmin, secnan); return; }
-        for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x - 1) {
-            rowc_block(a, n, blk, srows, rows_out, secmin, secnan);
-            __syncthreads();
+    const bool all_rows = a.out_sec != nullptr;
+    const int* list = a.scan_list;
+    const long nu = all_rows ? n : (long)*a.scan_count;
+    for (long e0 = (long)blockIdx.x * 64; e0 < nu; e0 += (long)gridDim.x * 64) {
+        const int ne = (int)((nu - e0 < 64) ? (nu - e0) : 64);
+        long row = 0;
+        double ysec = 0.0, fdil = 0.0;
+        if (lane < ne) {
+            row = all_rows ? e0 + lane : (long)list[e0 + lane];
+            RowC c;
+            row_constants(a, n, row, c, true, srows[lane], ysec, fdil);
         }
-        return;
-    }
-    for (long blk = blockIdx.x; blk < (nblk > 0 ? nblk : 1); blk += gridDim.x) {
-        rowc_block(a, n, blk, srows, rows_out, secmin, secnan);
+        secmin[lane] = INFINITY;
+        secnan[lane] = 0;
+        __syncthreads();
+        for (int it = lane; it < ne * kSecPoints; it += 64) {
+            const int ri = it / kSecPoints, j = it - ri * kSecPoints;
+            const RowC sc = srows[ri];
+            const Limb L{sc.cle, sc.cld, sc.ced};
+            // np.linspace(-0.05, 0.05, 25): start + j*step, last point exact
+            double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, (double)j), -0.05);
+            if (j == kSecPoints - 1) ts = 0.05;
+            const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
+            if (f != f) atomicOr(&secnan[ri], 1);
+            else __hip_atomic_fetch_min(&secmin[ri], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if (lane < ne) {
+            double m = secnan[lane] ? NAN : secmin[lane];                   // np.min propagates NaN
+            m = (m + ysec) / (1.0 + ysec);
+            const double secdepth = 1.0 - (m + fdil) / (1.0 + fdil);
+            a.rowc[row * kRowDoubles + (kRowDoubles - 1)] = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;  // RowC::excl, :535
+            if (a.out_sec) a.out_sec[row] = secdepth;
+        }
         __syncthreads();
     }
 }
@@ -1760,15 +1783,27 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    const size_t scratch_bytes = ((size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
+    // [scan counter, scan list | row blocks | launch header]
+    const size_t list_doubles = scan_list_doubles(a.n);
+    const size_t scratch_bytes = (list_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
-    a.rowc = static_cast<double*>(scratch);
+    a.scan_count = static_cast<unsigned long long*>(scratch);
+    a.scan_list = reinterpret_cast<int*>(static_cast<double*>(scratch) + 2);
+    a.rowc = static_cast<double*>(scratch) + list_doubles;
     {
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
-        if (a.need_sec) hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb), dim3(256), 0, st, a);
-        else            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
+        if (a.need_sec) {
+            if (!a.out_sec) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
+            // the open rows are ~3 % of the rows of a likelihood call; every row when the depth is asked for
+            long sb = a.out_sec ? (a.n + 63) / 64 : (a.n / 64 + 15) / 16;
+            sb = sb < 64 ? 64 : (sb > 16384 ? 16384 : sb);
+            hipLaunchKernelGGL(sec_scan_kernel, dim3((unsigned)sb), dim3(64), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
+        }
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
