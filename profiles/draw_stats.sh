@@ -10,7 +10,7 @@ import csv,glob,statistics,collections
 f=glob.glob("$R/gpurun_out/draw_${TAG}/*/*kernel_trace.csv")[0]
 allrows=list(csv.DictReader(open(f)))
 names=["TP","EB","PTP","PEB","STP","SEB","DTP","DEB","BTP","BEB","NTP","NEB"]
-for kern in ("draw_kernel","fill_kernel"):
+for kern in ("draw_kernel","compact_fill_kernel"):
     rows=[r for r in allrows if kern in r["Kernel_Name"]]
     if not rows: continue
     rows.sort(key=lambda r:int(r["Start_Timestamp"]))

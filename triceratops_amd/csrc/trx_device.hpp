@@ -903,4 +903,68 @@ __device__ __forceinline__ bool argmin_before(double a, long ia, double b, long 
     return ia < ib;
 }
 
+// ---------------------------------------------------------------------------------------
+// The end of one lnZ_* branch of calc_probs (trx_scenario_enqueue): run by ONE wave -- the first wave of the block of
+// lme_partial_kernel<SCEN> that finishes last -- from the per-block partials of that launch:
+//   the evidence (the fold of lme_final_kernel: lane l takes partials l, l + 64, ... in order, then a fixed butterfly),
+//   the first minimum of chi^2 (NaN first, ties to the lowest index: numpy's / torch's argmin), and the record
+//     res[0 .. ncol)  the best draw's columns (draw 0 when no draw passed the mask)
+//     res[ncol]       lnZ          res[ncol + 1]  the masked count
+//     flag_out[0]     the limb-darkening flag of the draw kernel (branch 0 writes it)
+// `res` may be pinned host memory (the record then needs no copy).  `state` is the persistent block at the head of
+// the stream's scenario scratch: [0] the counter of finished blocks, [1] the draw kernel's flag -- both are left at
+// zero for the next call (the last branch of a call clears the flag).
+constexpr int kScenRecord = 16;       // TRX_SCENARIO_OUT
+struct ScenFinal {
+    const int* idx;                   // the branch's list of masked draws
+    const double* cols;               // [ncol][N]
+    long N, n_total;
+    int ncol, branch, last_branch;
+    double* res;                      // this branch's record
+    double* flag_out;                 // where the flag goes (as a double), or null
+    unsigned* state;                  // persistent: [0] finished blocks, [1] flag
+};
+
+__device__ __forceinline__ void scenario_final(const ScenFinal& f, const double* __restrict__ w,
+                                               const double* __restrict__ pv, const long* __restrict__ pi,
+                                               const long n, const int lane)
+{
+    const int nparts = lme_blocks(n);
+    Lme t{-INFINITY, 0.0, 0};
+    double bv = INFINITY;
+    long bi = -1;
+    if (n > 0) {
+        for (int i = lane; i < nparts; i += 64) {
+            Lme o{w[3 * i], w[3 * i + 1], w[3 * i + 2] != 0.0};
+            lme_merge(t, o);
+            const long oi = pi[i];
+            if (oi >= 0 && (bi < 0 || argmin_before(pv[i], oi, bv, bi))) { bv = pv[i]; bi = oi; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Lme other;
+        other.m = __shfl_xor(t.m, o, 64);
+        other.s = __shfl_xor(t.s, o, 64);
+        other.pinf = __shfl_xor(t.pinf, o, 64);
+        lme_merge(t, other);
+        const double ov = __shfl_xor(bv, o, 64);
+        const long oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || argmin_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    double lnz;
+    if (t.pinf) lnz = INFINITY;                                   // _numerics.py:46-47
+    else if (t.m == -INFINITY) lnz = -INFINITY;                   // :49-50
+    else lnz = log(t.s) + t.m - log((double)f.n_total);           // :51
+    const long best = (bi >= 0) ? (long)f.idx[bi] : 0;
+    if (lane < f.ncol) f.res[lane] = f.cols[(long)lane * f.N + best];
+    if (lane == f.ncol) f.res[f.ncol] = lnz;
+    if (lane == f.ncol + 1) f.res[f.ncol + 1] = (double)n;
+    if (lane == 63) {
+        if (f.flag_out) f.flag_out[0] = (double)f.state[1];
+        if (f.last_branch) f.state[1] = 0u;
+        f.state[0] = 0u;
+    }
+}
+
 }  // namespace trx

@@ -676,21 +676,81 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restr
     }
 }
 
-// The columns and the prior of the draws that passed a mask: idx0 / idx1 are the ordered lists of compact_kernel
-// (n_dev[0], n_dev[1] entries; a draw passes at most one of the two masks of a binary scenario), grid-stride
-// over both.  Draw 0 is always filled: it stands in for the best draw of a branch no draw passed.
-__global__ __launch_bounds__(256) void fill_kernel(trx_draw_args a, const int* __restrict__ idx0,
-                                                   const int* __restrict__ idx1, const long* __restrict__ n_dev)
+// Ordered compaction of the geometry mask(s) AND the columns / prior of the draws that passed, in one kernel
+// (compact_kernel + fill_kernel until round 3: two launches, two tails).  grid = (chunks, branches), one wave per
+// workgroup.  Workgroup (c, br) owns `gper` consecutive workgroups' worth of draw_kernel's draws, [c gper per,
+// (c + 1) gper per): their place in the list idx[br] is the sum of the mask counts of the draw-kernel workgroups
+// before them (<= 2048 numbers, summed here: no scan kernel, no cross-workgroup hand-off), their order the draw
+// index -- the order numpy's / torch's nonzero gives.  The wave walks its draws 64 at a time, appends the indices
+// of the masked ones to idx[br] and to a list in LDS, and whenever that holds a full wave of them (and at the end)
+// evaluates draw_one<2> for them: the same code on the same counter-based random numbers as the mask pass, now
+// writing the columns and the prior.  A draw passes at most one of the two masks of a binary scenario.  Draw 0 is
+// always filled: it stands in for the best draw of a branch no draw passed.
+constexpr int kFillList = 128;
+__global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long per, int groups, int gper,
+                                                          const int* __restrict__ blk_cnt, int* __restrict__ idx0,
+                                                          int* __restrict__ idx1, long* __restrict__ n_out)
 {
     __shared__ Tables T;
-    const long n0 = n_dev[0], n1 = idx1 ? n_dev[1] : 0, total = n0 + n1 + 1;
-    if ((long)blockIdx.x * blockDim.x >= total) return;
+    __shared__ int hits[kFillList];
+    const int br = blockIdx.y, lane = threadIdx.x;
+    const unsigned char* mask = br ? a.mask_twin : a.mask;
+    int* idx = br ? idx1 : idx0;
+    const int* cnt = blk_cnt + (long)br * groups;
+    const int g0 = blockIdx.x * gper, g1 = (g0 + gper < groups) ? g0 + gper : groups;
+    long at = 0;
+    for (int j = lane; j < g0; j += 64) at += cnt[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) at += __shfl_xor(at, o, 64);
+    int mine = 0;
+    for (int j = g0 + lane; j < g1; j += 64) mine += cnt[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (g1 == groups && lane == 0) n_out[br] = at + mine;
+    const bool first = blockIdx.x == 0 && br == 0;          // this workgroup also fills draw 0
+    if (mine == 0 && !first) return;
     stage_tables(a, T);
     const bool parallel = a.parallel != 0;
-    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x) {
-        const long i = (j < n0) ? (long)idx0[j] : ((j < n0 + n1) ? (long)idx1[j - n0] : 0L);
-        bool h0, h1;
-        draw_one<2>(a, T, i, parallel, h0, h1);
+    const long N = a.N;
+    const long end = ((long)g1 * per < N) ? (long)g1 * per : N;
+    int nh = 0;
+    bool zero_done = !first;
+    long i0 = (long)g0 * per;
+    // (ONE call site of draw_one: with two inlined copies of the draw in one kernel the compiler once moved the
+    // 1.2 KB argument block to scratch memory)
+    for (;;) {
+        // gather masked draws until a full wave of them is listed or the input is exhausted
+        while (nh < 64 && i0 < end) {
+            const long i = i0 + lane;
+            const bool hit = i < end && mask[i] != 0;
+            const unsigned long long m = __ballot(hit);
+            i0 += 64;
+            if (m == 0) continue;
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (hit) {
+                idx[at + below] = (int)i;
+                hits[nh + below] = (int)i;
+            }
+            zero_done = zero_done || (i0 == 64 && (m & 1ull));          // (draw 0 is lane 0 of the first trip)
+            at += __popcll(m);
+            nh += __popcll(m);
+        }
+        if (i0 >= end && !zero_done) {     // draw 0 failed this mask: filled all the same
+            if (lane == 0) hits[nh] = 0;
+            ++nh;
+            zero_done = true;
+        }
+        if (nh == 0) break;
+        __syncthreads();
+        const int take = nh < 64 ? nh : 64;
+        if (lane < take) {
+            bool h0, h1;
+            draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1);
+        }
+        __syncthreads();
+        if (lane < nh - take) hits[lane] = hits[take + lane];
+        nh -= take;
+        __syncthreads();
     }
 }
 
@@ -745,14 +805,16 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }
 
-// The columns (and the prior) of the draws on the compacted lists: see fill_kernel.  The lists' lengths are on
-// the device, so the grid is sized for a sixth of the draws -- more than the geometry lets through at the
-// reference's priors -- and strides over whatever there is.
-int trx::fill_draws(const trx_draw_args& a, const int* idx0, const int* idx1, const long* n_dev, hipStream_t st)
+// Ordered compaction of the mask(s) + the columns and the prior of the draws that passed: see compact_fill_kernel.
+// About 1024 workgroups of one wave: at N = 1e6 each owns two of draw_kernel's workgroups (1024 draws, ~100 of which
+// pass at the reference's priors: one full wave of fills and a partial one).
+int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
+                      hipStream_t st)
 {
-    if (a.N < 1 || !idx0 || !n_dev) return TRX_ERR_ARG;
-    long blocks = (a.N / 6 + 255) / 256;
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx0, idx1, n_dev);
+    if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || groups < 1) return TRX_ERR_ARG;
+    const int gper = groups > 1024 ? (groups + 1023) / 1024 : 1;
+    const int chunks = (groups + gper - 1) / gper;
+    hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks, a.planet ? 1u : 2u), dim3(64), 0, st, a, per, groups, gper,
+                       blk_cnt, idx0, idx1, n_dev);
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }

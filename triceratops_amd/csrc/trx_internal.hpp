@@ -15,6 +15,9 @@ namespace trx {
 //   slot 2  (unused since round 3: the masked draws are read in place)
 //   slot 3  (host, pinned) small results on their way back
 constexpr int kScratchSlots = 4;
+// The first kScratchZeroed bytes of a device slot are zero when the buffer is handed out for the first time and
+// after every growth (cleared on the stream): persistent counters that the kernels themselves leave at zero.
+constexpr size_t kScratchZeroed = 256;
 hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out);
 
 // Held while a call enqueues its kernels on `st`: two host threads that share a stream take turns, so
@@ -47,16 +50,21 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
 // First pass of the evidence and of the best-draw search over those chi^2/2 values: per-block
 // (max, sum exp, saw +inf) partials in ws[3 * 2048] and (value, position) argmin partials in
 // amin_pv / amin_pi [2048]; lme_blocks(*n_dev) of them are valid.
+// fin.state != null: the block that finishes last also folds the partials into the branch's record
+// (scenario_final, trx_device.hpp).
+struct ScenFinal;
 int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
               const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base,
-              hipStream_t st);
+              const ScenFinal& fin, hipStream_t st);
 
 // trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
 // [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)
 constexpr int kDrawMaxGroups = 2048;
 int draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* groups_out, hipStream_t st);
-// the columns and the prior of the draws that passed a mask (lists of compact_kernel), enqueued behind it
-int fill_draws(const trx_draw_args& a, const int* idx0, const int* idx1, const long* n_dev, hipStream_t st);
+// behind it: the ordered lists of the draws that passed a mask (idx0 / idx1, their lengths in n_dev[0 / 1]) and the
+// columns and the prior of those draws (and of draw 0)
+int compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
+                 hipStream_t st);
 
 // fail() of trx_kernels.hip for the other translation units (thread-local message of trx_last_error)
 int fail_hip(hipError_t e);

@@ -257,6 +257,8 @@ __host__ __device__ inline size_t scan_list_doubles(long n_upper) { return 2 + (
 // The constants of one row (lanes = rows): unit conversion (likelihoods.py:337-347, 399-411), the radius-ratio rule,
 // orbit constants and transit window, dilution, limb weights -> c.  EB rows whose secondary depth is used (need_sec)
 // also get the orbit of the secondary eclipse (sc) and the two dilution constants of its depth.
+// PRIMARY = false: only the secondary orbit and the dilution constants (sec_scan_kernel; c is left untouched).
+template <bool PRIMARY = true>
 __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, const long row, RowC& c, const bool want_sec,
                                               RowC& sc, double& ysec, double& fdil)
 {
@@ -271,8 +273,10 @@ __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, c
     fdil = 0.0;
     if (a.model == TRX_MODEL_RAW) {
         u1 = p[7 * ps]; u2 = p[8 * ps];
-        orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
-        c.rdil = 1.0;
+        if (PRIMARY) {
+            orbit_init(c, p[0], p[1 * ps], p[2 * ps], p[3 * ps], p[4 * ps], p[5 * ps], p[6 * ps], a.exptime);
+            c.rdil = 1.0;
+        }
     } else {
         double k, ksec = 0.0, per, inc, acm, R_s, e, argp, comp_fr, feb = 0.0;
         if (a.model == TRX_MODEL_TP) {
@@ -296,7 +300,7 @@ __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, c
         const double a_R = acm / (R_s * kRsun);                     // :343, :409
         const double inc_r = inc * (kPi / 180.0);                   // :344, :410
         const double w = (90.0 - argp) * (kPi / 180.0);             // :345, :411
-        orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
+        if (PRIMARY) orbit_init(c, k, 0.0, per, a_R, inc_r, e, w, a.exptime);
         double xeb = 0.0;
         if (!eblike) {
             fdil = is_host ? (1.0 / fcomp) : fcomp;                 // :352-357
@@ -321,12 +325,16 @@ __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, c
         // the two dilution stages as one factor on the flux DEFICIT: (m + x)/(1 + x) = 1 - (1 - m)/(1 + x), so
         // an unocculted point stays exactly 1 and a cell costs one fma instead of two divisions; a flux ratio
         // that is not finite makes the reference's quotient NaN (inf / inf), hence NaN here
-        c.rdil = 1.0 / ((1.0 + xeb) * (1.0 + fdil));
-        if (!(fabs(xeb) < INFINITY) || !(fabs(fdil) < INFINITY)) c.rdil = NAN;
+        if (PRIMARY) {
+            c.rdil = 1.0 / ((1.0 + xeb) * (1.0 + fdil));
+            if (!(fabs(xeb) < INFINITY) || !(fabs(fdil) < INFINITY)) c.rdil = NAN;
+        }
     }
-    const Limb L = limb_weights(u1, u2);
-    c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
-    c.excl = 0.0;
+    if (PRIMARY) {
+        const Limb L = limb_weights(u1, u2);
+        c.cle = L.cle; c.cld = L.cld; c.ced = L.ced;
+        c.excl = 0.0;
+    }
 }
 
 // The launch's header (flat-model chi^2, stencil verdict, bounds of the bounded evaluation, the scan's counter):
@@ -496,31 +504,36 @@ __global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
 }
 
 // The 25-point scan of the rows rowc_kernel<true> left open (or of every row when the depth itself is asked for):
-// 64 list entries per workgroup.  Lanes = rows derive the secondary orbit (full lanes: the list is compact), then the
-// 64 x 25 (row, point) cells are dealt to the lanes -- the points are reached by Newton steps from the secondary
-// conjunction -- the minimum is taken with LDS atomics (min ignores NaN, so NaN is flagged separately: np.min
-// propagates it), and lanes = rows turn it into the exclusion flag of the row's block / the secdepth output.
+// E list entries per workgroup of one wave.  Lanes = rows derive the secondary orbit, then the E x 25 (row, point)
+// cells are dealt to the lanes -- the points are reached by Newton steps from the secondary conjunction -- the
+// minimum is taken with LDS atomics (min ignores NaN, so NaN is flagged separately: np.min propagates it), and
+// lanes = rows turn it into the exclusion flag of the row's block / the secdepth output.
+// E = 64 when every row is scanned (full lanes throughout).  The open rows of a likelihood call are few -- ~3000 of
+// the 1e5 masked draws of a lnZ_*EB call -- and a wave's work is one serial chain (orbit constants, then E x 25 / 64
+// model evaluations of ~1000 fp64 instructions each): E = 8 spreads them over eight times the waves (117 -> 30 us).
+template <int E>
 __global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
 {
-    __shared__ RowC srows[64];
-    __shared__ double secmin[64];
-    __shared__ int secnan[64];
+    __shared__ RowC srows[E];
+    __shared__ double secmin[E];
+    __shared__ int secnan[E];
     const int lane = threadIdx.x;
     const long n = a.n_dev ? *a.n_dev : a.n;
     const bool all_rows = a.out_sec != nullptr;
     const int* list = a.scan_list;
     const long nu = all_rows ? n : (long)*a.scan_count;
-    for (long e0 = (long)blockIdx.x * 64; e0 < nu; e0 += (long)gridDim.x * 64) {
-        const int ne = (int)((nu - e0 < 64) ? (nu - e0) : 64);
+    for (long e0 = (long)blockIdx.x * E; e0 < nu; e0 += (long)gridDim.x * E) {
+        const int ne = (int)((nu - e0 < E) ? (nu - e0) : E);
         long row = 0;
         double ysec = 0.0, fdil = 0.0;
         if (lane < ne) {
             row = all_rows ? e0 + lane : (long)list[e0 + lane];
-            RowC c;
-            row_constants(a, n, row, c, true, srows[lane], ysec, fdil);
+            row = (row >= 0 && row < n) ? row : 0;              // (a list left over by an aborted call cannot reach outside)
+            RowC unused;
+            row_constants<false>(a, n, row, unused, true, srows[lane], ysec, fdil);
+            secmin[lane] = INFINITY;
+            secnan[lane] = 0;
         }
-        secmin[lane] = INFINITY;
-        secnan[lane] = 0;
         __syncthreads();
         for (int it = lane; it < ne * kSecPoints; it += 64) {
             const int ri = it / kSecPoints, j = it - ri * kSecPoints;
@@ -1104,6 +1117,9 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
 __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
 {
+    // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
+    // back to zero for the next call on this stream
+    if (a.need_sec && blockIdx.x == 0 && threadIdx.x == 0) *a.scan_count = 0ull;
     if (a.n_dev) {
         // the grid was sized for an upper bound of the row count: the blocks beyond the batches leave at once
         const long nd = *a.n_dev;
@@ -1237,7 +1253,7 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                                                           const long* __restrict__ n_dev,
                                                           const int* __restrict__ src_idx,
                                                           double* __restrict__ amin_pv, long* __restrict__ amin_pi,
-                                                          const double* __restrict__ bounds_base)
+                                                          const double* __restrict__ bounds_base, const ScenFinal fin)
 {
     typedef double dvec2 __attribute__((ext_vector_type(2)));
     Lme st{-INFINITY, 0.0, 0};
@@ -1435,6 +1451,21 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                 if (ai[w] >= 0 && (bi < 0 || argmin_before(av[w], ai[w], bv, bi))) { bv = av[w]; bi = ai[w]; }
             amin_pv[blockIdx.x] = bv;
             amin_pi[blockIdx.x] = bi;
+        }
+    }
+    if (SCEN && fin.state) {
+        // the block that finishes last turns the partials into the branch's record (scenario_final): what was a
+        // launch of its own (final_kernel) until round 3
+        __shared__ int is_last;
+        if (threadIdx.x == 0) {
+            __threadfence();                                   // this block's partials before its ticket
+            const unsigned ticket = atomicAdd(&fin.state[0], 1u);
+            is_last = ticket == nblocks - 1;
+        }
+        __syncthreads();
+        if (is_last && threadIdx.x < 64) {
+            __threadfence();                                   // the other blocks' partials after their tickets
+            scenario_final(fin, ws, amin_pv, amin_pi, n, (int)threadIdx.x);
         }
     }
 }
@@ -1795,12 +1826,17 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
         if (a.need_sec) {
-            if (!a.out_sec) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
+            // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
+            // that follows a scan; graph memory nodes hold anything)
+            if (capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
             hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
-            // the open rows are ~3 % of the rows of a likelihood call; every row when the depth is asked for
-            long sb = a.out_sec ? (a.n + 63) / 64 : (a.n / 64 + 15) / 16;
-            sb = sb < 64 ? 64 : (sb > 16384 ? 16384 : sb);
-            hipLaunchKernelGGL(sec_scan_kernel, dim3((unsigned)sb), dim3(64), 0, st, a);
+            // every row when the depth is asked for; else the open rows, ~3 % of the rows of a likelihood call (which
+            // are themselves ~10 % of `n` when that is only the upper bound): workgroups stride over the list
+            long sb = (a.n + 63) / 64;
+            if (!a.out_sec && a.n_dev) sb = (sb + 3) / 4;
+            sb = sb < 64 ? 64 : (sb > 8192 ? 8192 : sb);
+            if (a.out_sec) hipLaunchKernelGGL(sec_scan_kernel<64>, dim3((unsigned)sb), dim3(64), 0, st, a);
+            else           hipLaunchKernelGGL(sec_scan_kernel<8>, dim3((unsigned)sb), dim3(64), 0, st, a);
         } else {
             hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
         }
@@ -1864,7 +1900,7 @@ int launch_lme(const double* logw, const double* h, const double* lnprior, doubl
     const int vec_ok = (al % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(lme_partial_kernel<false>, dim3(blocks), dim3(256), 0, st, logw, h, lnprior, c0, n,
                        vec_ok, ws, (const long*)nullptr, (const int*)nullptr, (double*)nullptr, (long*)nullptr,
-                       (const double*)nullptr);
+                       (const double*)nullptr, ScenFinal{});
     TRX_HIP(hipGetLastError());
     hipLaunchKernelGGL(lme_final_kernel, dim3(1), dim3(64), 0, st, ws, blocks, n_total, out);
     TRX_HIP(hipGetLastError());
@@ -1922,6 +1958,8 @@ hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
         e = (slot == 3) ? hipHostMalloc(&en.p[slot], want, hipHostMallocDefault) : hipMalloc(&en.p[slot], want);
         if (e != hipSuccess) return e;
         en.cap[slot] = want;
+        if (slot != 3 && (e = hipMemsetAsync(en.p[slot], 0, kScratchZeroed < want ? kScratchZeroed : want, st)) != hipSuccess)
+            return e;
     }
     *out = en.p[slot];
     return hipSuccess;
@@ -1952,13 +1990,14 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
 }
 
 int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
-              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base, hipStream_t st)
+              const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base,
+              const ScenFinal& fin, hipStream_t st)
 {
     if (!halfchi2 || !n_dev || !src_idx || !ws || !amin_pv || !amin_pi || ((uintptr_t)halfchi2 % 16) != 0)
         return fail(TRX_ERR_ARG, "lme_draws: bad argument%s", "", 0);
     const double c0 = -0.5 * log(kTwoPi) - lnsigma;   // marginal_likelihoods.py:130 etc.
     hipLaunchKernelGGL(lme_partial_kernel<true>, dim3(lme_blocks(n_upper)), dim3(256), 0, st, (const double*)nullptr,
-                       halfchi2, lnprior, c0, n_upper, 1, ws, n_dev, src_idx, amin_pv, amin_pi, bounds_base);
+                       halfchi2, lnprior, c0, n_upper, 1, ws, n_dev, src_idx, amin_pv, amin_pi, bounds_base, fin);
     TRX_HIP(hipGetLastError());
     return TRX_OK;
 }
