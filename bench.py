@@ -572,7 +572,7 @@ def run_grid(ctx):
 
 
 
-def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False):
+def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None):
     """The configs[3] step -- calc_probs_many over `tois` synthetic TOIs x 18 scenarios x N draws, the lnZ_* units
     dealt to the ranks (strong scaling) -- timed like the main loop: barrier + synchronize on both sides, max over
     ranks.  Returns (on every rank) elapsed seconds, the targets of the last step and the per-rank host timings:
@@ -606,6 +606,8 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False):
         for w in range(warmup):
             step(jobs, 10 + w)
         _sync(ctx)
+        if before_timed is not None:
+            before_timed()
         host = np.zeros(7)
         t0 = time.perf_counter()
         for s_ in range(steps):
@@ -668,32 +670,21 @@ def run_batch(ctx):
         triceratops_amd.set_precision("fp32")
     if ctx["debug_one"]:
         import torch.distributed as dist    # noqa: F401  (gloo group: sharding moves host tensors)
-    tri = os.path.join(GOLD, "trilegal_synth.csv")
-    cc = os.path.join(GOLD, "contrast_curve_synth.csv")
-    # every rank builds the same jobs (tiny host tables + one 200-point light curve per TOI)
-    jobs = synth.toi_jobs(args.tois, n_time=args.n_time, N=args.batch_n, seed=synth.SEED,
-                          trilegal_fname=tri, contrast_curve_file=cc)
-    small = synth.toi_jobs(min(args.tois, 2 * world), n_time=args.n_time, N=20000, seed=synth.SEED,
-                           trilegal_fname=tri, contrast_curve_file=cc)
+    import ctypes
+    skipped = ctypes.c_ulonglong(0)
+
+    def clear_counters():
+        _lib.reset_stats()
+        _lib.check(_lib.lib().trx_skipped_rows(None, 1))          # clears the device counter
+
+    elapsed, out, jobs, timing = batch_leg(ctx, args.tois, args.batch_n, args.n_time, args.steps, args.warmup,
+                                           before_timed=clear_counters)
 
     def step(js, seed):
         np.random.seed(seed)
-        torch.manual_seed(seed + 1000 * rank)
+        torch.manual_seed(seed)
         return triceratops_amd.calc_probs_many(js)
 
-    step(small, 1)                           # library load, tables, allocator
-    for w in range(args.warmup):
-        step(jobs, 10 + w)
-    _sync(ctx)
-    _lib.reset_stats()
-    import ctypes
-    skipped = ctypes.c_ulonglong(0)
-    _lib.check(_lib.lib().trx_skipped_rows(None, 1))          # clears the device counter
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        out = step(jobs, 100 + s)
-    _sync(ctx)
-    elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
     stats = dict(_lib.STATS)
     # rows whose light curve was not evaluated: lnL_EB_p's secondary-eclipse rule gives them +inf anyway
     _lib.check(_lib.lib().trx_skipped_rows(ctypes.byref(skipped), 1))
@@ -752,6 +743,9 @@ def run_batch(ctx):
                    "rows_not_evaluated_per_step": float(cells[2]) / args.steps,
                    "nominal_evals_per_s": nominal / elapsed,
                    "calc_probs_per_s": args.tois * args.steps / elapsed,
+                   # host seconds per step and rank: unit lists, argument blocks + library calls of the rank's own units,
+                   # stream wait, the collective, the tables of all targets, the rest; host_path_s = all but the waits
+                   "per_rank": timing,
                    "parallelism": "lnZ_* units dealt to %d ranks by cost (LPT), one all_gather of the tables" % world},
         "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VALU_PEAK_TF, "traffic": None,

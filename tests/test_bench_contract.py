@@ -11,7 +11,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--n-samples", "2048", "--n-time", "256", "--steps", "2", "--warmup", "1", "--no-e2e"]
+SMALL = ["--n-samples", "2048", "--n-time", "256", "--steps", "2", "--warmup", "1", "--no-e2e",
+         "--tois", "4", "--batch-n", "50000"]          # (the `batch` object of the line at a reduced size)
 
 
 def _last_json(out):
@@ -33,6 +34,11 @@ def _check_common(d, n_gpus):
     r = d["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    # the configs[3] strong-scaling step rides in the same line, with the host timings of every rank
+    b = d["batch"]
+    assert b["n_gpus"] == n_gpus and b["scaling"] == "strong" and b["ms_per_step"] > 0
+    for k in ("prepare_s", "enqueue_s", "wait_s", "gather_s", "finish_s", "other_s", "host_path_s"):
+        assert len(b["per_rank"][k]) == n_gpus, k
 
 
 def test_gpus_flag_must_agree_with_the_launcher():
@@ -118,3 +124,29 @@ def test_batch_mode_two_ranks():
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_scenarios"] == 72
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def _batch_line(gpus, extra=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--mode", "batch",
+                        "--tois", "64", "--batch-n", "100000", "--steps", "3", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return _last_json(p.stdout)
+
+
+@pytest.mark.gpu
+def test_host_path_of_a_rank_shrinks_with_the_world_size():
+    """BASELINE configs[3] must strong-scale by construction: what a rank's HOST does per step -- listing the units,
+    building the argument blocks of ITS OWN units and handing them to the library, filling the tables -- has to
+    shrink with the number of ranks, or eight GPUs wait for eight Pythons (round 3: every rank prepared and
+    finished all 64 targets, 0.042 s per step whatever the world size).  Eight gloo ranks on this box's one GPU
+    (the GPU time is meaningless there; the host path is what is measured) against one rank: at most a quarter."""
+    one = _batch_line(1)
+    eight = _batch_line(8, ("--debug-single-device",))
+    h1 = one["config"]["per_rank"]["host_path_s"][0]
+    h8 = max(eight["config"]["per_rank"]["host_path_s"])
+    print("\nhost path per step: 1 rank %.4f s, 8 ranks (max) %.4f s; enqueue %s" %
+          (h1, h8, ["%.4f" % v for v in eight["config"]["per_rank"]["enqueue_s"]]))
+    assert eight["n_gpus"] == 8 and len(eight["config"]["per_rank"]["host_path_s"]) == 8
+    assert h8 <= 0.25 * h1, (h1, h8)
