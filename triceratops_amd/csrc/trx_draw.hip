@@ -807,13 +807,14 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
 
 // Ordered compaction of the mask(s) + the columns and the prior of the draws that passed: see compact_fill_kernel.
 // One workgroup of one wave per workgroup of draw_kernel (2048 at N = 1e6: 512 draws each, ~50 of which pass at the
-// reference's priors -- one wave of fills; with two of draw_kernel's workgroups each, a full wave of fills and a
-// partial one in a row, the kernel took 36 us instead of ...).
+// reference's priors -- one wave of fills): 23-31 us for the planet scenarios against 29-39 with two of draw_kernel's
+// workgroups each (a full wave of fills and a partial one in a row).
 int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
                       hipStream_t st)
 {
     if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || groups < 1) return TRX_ERR_ARG;
-    const int gper = groups > trx::kDrawMaxGroups ? (groups + trx::kDrawMaxGroups - 1) / trx::kDrawMaxGroups : 1;
+    // (binary scenarios: two branches scan the same draws, half as many masked draws each -- two draw workgroups per wave)
+    const int gper = a.planet ? 1 : 2;
     const int chunks = (groups + gper - 1) / gper;
     hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks, a.planet ? 1u : 2u), dim3(64), 0, st, a, per, groups, gper,
                        blk_cnt, idx0, idx1, n_dev);
