@@ -84,6 +84,8 @@ struct RowsArgs {
     int wave_off, wave_doubles;   // cells_kernel: offset of the first wave's own LDS block and the size of one (in doubles)
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     double* hdr;       // the launch header (kHdr*: flat-model chi^2, stencil verdict, running bounds), at a fixed place
+    int row_counter_slot;                // one row per wave (LONG): scan_count[slot] is the next row to hand out (1 or 2;
+                                         // zeroed by the launch header)
     unsigned char* excl;                 // one row per wave (LONG): the EB secondary rule's verdict per row, a byte each --
                                          // the wave derives the row constants itself, there are no row blocks
     int* scan_list;                      // rowc_kernel -> sec_scan_kernel: the rows whose secondary-eclipse verdict is open
@@ -118,6 +120,15 @@ __device__ __forceinline__ double uniform(double v)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// a wave-uniform 64-bit integer (a count loaded from device memory) moved to a scalar register pair: address
+// arithmetic on it then runs on the scalar unit instead of parking products in vector registers
+__device__ __forceinline__ long uniform_long(long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
 }
 
 // number of set bits of `m` below this lane
@@ -215,10 +226,12 @@ constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pas
 // One row per wave (LONG): the wave derives the constants of its rows itself -- no row blocks, no 152 B per row
 // written by rowc_kernel and read back (that round trip was three quarters of the launch's HBM traffic: 40.9 MB
 // against 9.4 MB of algorithmic bytes at 2000 points).  A wave-uniform chain of ~1500 fp64 instructions per row
-// would cost 3.7 % of a 2000-point row, so a workgroup takes kFusedRows rows, one after the other, and derives
-// their constants together (lanes = rows, into LDS) before the first: 1500 / kFusedRows instructions per row.
+// would cost ~7 % of a 2000-point row (the chain is ~3000 instructions), so a wave takes up to kFusedRows rows at a
+// time, one after the other, and derives their constants together (lanes = rows, into LDS) before the first.  A
+// static deal of four rows per workgroup lost 6 % at 1e5 rows -- a quarter of the workgroups, four times as long,
+// leave the chip's last round half empty -- hence the counter and the shrinking chunks (cells_body).
 #ifndef TRX_FUSED_ROWS
-#define TRX_FUSED_ROWS 4
+#define TRX_FUSED_ROWS 8
 #endif
 constexpr int kFusedRows = TRX_FUSED_ROWS;
 
@@ -362,6 +375,8 @@ __device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
 {
     const int lane = threadIdx.x;
     double* hdr = a.hdr;
+    // the row counters of the one-row-per-wave launches that follow (persistent block, slots 1 and 2)
+    if (lane < 2) a.scan_count[1 + lane] = 0ull;
     if (a.flux) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
@@ -731,7 +746,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     long n = a.n, nbatch = a.nbatch;
     int B = Bl;
     if (a.n_dev) {
-        n = *a.n_dev;
+        n = uniform_long(*a.n_dev);
         if (!LONG) {
             B = batch_rows(n, n_time, a.forced_B);
             B = B < Bl ? B : Bl;
@@ -769,35 +784,57 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // of the rows, whose blocks then stay in that XCD's L2
     const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
     const long vstride = (long)gridDim.x * W;
-    int turn = 0;                    // LONG: position in the group of kFusedRows rows whose constants are in rcache
-    for (long v = v0; v < 8 * per_xcd; v += vstride, ++turn) {
+    // One row per wave (LONG): the waves take their rows from a counter in chunks of up to kFusedRows consecutive rows
+    // -- the chunk shrinks towards the end of the launch (guided scheduling: what is left / number of waves), so that
+    // the last rows are dealt one by one and the launch's tail is one row long -- and derive the constants of a chunk's
+    // rows together, lanes = rows, into rcache.  (A chunk of kFusedRows = 8 rows is one 64-byte line of each parameter
+    // column: an XCD's L2 fetches it once.)
+    long gbase = 0;
+    int gcnt = 0, turn = 0;
+    const long span = row1 - row0;
+    for (long v = v0; LONG || v < 8 * per_xcd; v += vstride) {
+        long base;
+        int nb;
         if (LONG) {
-            // the constants of this wave's next kFusedRows rows, lanes = rows (the rows are vstride apart in the
-            // XCD-aware numbering; a lane whose turn lies past the end derives nothing)
-            if (turn == kFusedRows) turn = 0;
-            if (turn == 0) {
+            if (turn == gcnt) {
+                long got = 0, take = 0;
+                if (lane == 0) {
+                    unsigned long long* ctr = a.scan_count + a.row_counter_slot;
+                    const long done = (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    take = (span - done) / (long)gridDim.x;
+                    take = take < 1 ? 1 : (take > kFusedRows ? kFusedRows : take);
+                    got = (long)atomicAdd(ctr, (unsigned long long)take);
+                }
+                gbase = ((long)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                gcnt = __builtin_amdgcn_readfirstlane((int)take);
+                if (gbase >= span) break;
+                if (span - gbase < gcnt) gcnt = (int)(span - gbase);
+                turn = 0;
                 wave_sync();
-                const long vj = v + (long)lane * vstride;
-                const long bj = (vj & 7) * per_xcd + (vj >> 3);
-                if (lane < kFusedRows && vj < 8 * per_xcd && (vj >> 3) < per_xcd && bj < nbatch) {
-                    RowC c, unused;
+                if (lane < gcnt) {
+                    // (straight into LDS: the fields leave the registers as they are derived)
+                    RowC unused;
                     double y_, f_;
-                    row_constants(a, n, row0 + bj, c, false, unused, y_, f_);
-                    if (a.excl) c.excl = a.excl[row0 + bj] ? 1.0 : 0.0;
-                    rcache[lane] = c;
+                    row_constants(a, n, row0 + gbase + lane, rcache[lane], false, unused, y_, f_);
+                    if (a.excl) rcache[lane].excl = a.excl[row0 + gbase + lane] ? 1.0 : 0.0;
                 }
                 wave_sync();
             }
+            base = row0 + gbase + turn;
+            nb = 1;
+        } else {
+            const long batch = (v & 7) * per_xcd + (v >> 3);
+            if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
+            base = row0 + batch * B;
+            nb = (int)((row1 - base < B) ? (row1 - base) : B);
         }
-        const long batch = (v & 7) * per_xcd + (v >> 3);
-        if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
-        const long base = row0 + batch * B;
-        const int nb = (int)((row1 - base < B) ? (row1 - base) : B);
         TRX_TICK(t_pro);
         if (LONG) {
             const double* src = reinterpret_cast<const double*>(&rcache[turn]);
             double* dst = reinterpret_cast<double*>(rows);
             if (lane < kRowDoubles) dst[lane] = src[lane];
+            ++turn;
         } else {
             // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
             const double* src = a.rowc + base * kRowDoubles;
@@ -1202,8 +1239,9 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE || MODE == M
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
     // back to zero for the next call on this stream
     if (a.need_sec && blockIdx.x == 0 && threadIdx.x == 0) *a.scan_count = 0ull;
-    if (a.n_dev) {
+    if (a.n_dev && !LONG) {
         // the grid was sized for an upper bound of the row count: the blocks beyond the batches leave at once
+        // (one row per wave: the waves take rows from a counter and leave when it has passed the count)
         const long nd = *a.n_dev;
         int B = 1;
         if (!LONG) {
@@ -1936,21 +1974,28 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
-    // (one row per wave: a workgroup takes kFusedRows rows in turn)
-    const unsigned g2 = long_rows ? grid_for((a.n + kFusedRows - 1) / kFusedRows, true) : grid;
+    // One row per wave: as many one-wave workgroups as the chip holds at once (256 CUs x 16: four waves per SIMD), each
+    // taking rows from the launch's counter until it runs out -- fewer when there are fewer rows
+    auto long_grid = [](long rows) -> unsigned {
+        const long want = 8 * ((rows + 7) / 8);
+        return (unsigned)(want < 8 ? 8 : (want > 4096 ? 4096 : want));
+    };
+    const unsigned g2 = long_rows ? long_grid(a.n) : grid;
+    a.row_counter_slot = 1;                      // (persistent block, slot 1; the second launch of a pair takes slot 2)
     t_last_hdr = a.hdr;
     t_last_pruned = prune;
     if (prune) {
         // pilot rows (evaluated to the end; first values of the running bounds), verdict on probing, the rest
         const long np = a.n < kPilotRows ? a.n : kPilotRows;
-        const long pilot_batches = long_rows ? (np + kFusedRows - 1) / kFusedRows : (np + a.B - 1) / a.B;
+        const long pilot_batches = (np + a.B - 1) / a.B;
         RowsArgs ap = a;
         ap.part = 1;
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
-        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
+        launch_pruned<MODE>(ap, st, long_rows, fp32, long_rows ? long_grid(np) : (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
             hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.hdr);
             ap.part = 2;
+            ap.row_counter_slot = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
         }
     } else if (long_rows) {
@@ -1960,6 +2005,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
             else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, false>), dim3(g2), dim3(64), lds, st, a);
         }
         if (a.use_stencil && verdict != 1) {
+            a.row_counter_slot = 2;
             if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, true>), dim3(g2), dim3(64), lds, st, a);
             else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true, true>), dim3(g2), dim3(64), lds, st, a);
             else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, true>), dim3(g2), dim3(64), lds, st, a);
