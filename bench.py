@@ -465,9 +465,10 @@ def run_grid(ctx):
     roof = {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "mean_launch_ms": mean_launch_s * 1e3, "cells_per_launch": cells_per_launch,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            # (until round 3 the row constants made a round trip through scratch between rowc_kernel and cells_kernel, 2 x 152 B
-            # per row; with one row per wave the wave now derives them itself: no design traffic on top of the inputs)
-            "scratch_round_trip_bytes_per_launch": 0.0 if n_time >= 320 else 2.0 * 152.0 * n_rows,
+            # the row constants' round trip between rowc_kernel and cells_kernel (152 B per row: RowC, 19 doubles written and
+            # read once): design traffic on top of the algorithmic bytes, counted in `traffic` (a variant in which the
+            # waves derive the constants themselves was built in round 4 and not kept: profiles/experiments/README.md)
+            "scratch_round_trip_bytes_per_launch": 2.0 * 152.0 * n_rows,
             "hbm_GBps_algorithmic": alg_bytes_per_launch / mean_launch_s / 1e9}
     kernels = {}
     shapes = None

@@ -39,9 +39,9 @@ private:
 // kernels of the stream; n_upper bounds the count).  twin: the EB_TWIN rows (2 P, a of 2 P).
 // The caller reduces the rows to lnZ (with lnprior per draw, or null) and the best draw only, which
 // allows the bounded evaluation of cells_kernel<PRUNE>: a row that can neither carry weight nor be the
-// best draw reports a lower bound of its chi^2/2 instead of the value.  *bounds_base then points at the launch
-// header of the call, which keeps the largest log-weight (lme_draws reads it; the pointer stays valid for work
-// enqueued on this stream); null when every row was evaluated to the end.
+// best draw reports a lower bound of its chi^2/2 instead of the value.  *bounds_base then points at the row
+// blocks of the launch, behind which its header keeps the largest log-weight (lme_draws reads it; the
+// pointer stays valid for work enqueued on this stream); null when every row was evaluated to the end.
 int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
               const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
               int twin, double exptime, int nsupersample, double* out_halfchi2, const double* lnprior,

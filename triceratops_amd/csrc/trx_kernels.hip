@@ -83,11 +83,6 @@ struct RowsArgs {
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS (shared by the workgroup's waves)
     int wave_off, wave_doubles;   // cells_kernel: offset of the first wave's own LDS block and the size of one (in doubles)
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
-    double* hdr;       // the launch header (kHdr*: flat-model chi^2, stencil verdict, running bounds), at a fixed place
-    int row_counter_slot;                // one row per wave (LONG): scan_count[slot] is the next row to hand out (1 or 2;
-                                         // zeroed by the launch header)
-    unsigned char* excl;                 // one row per wave (LONG): the EB secondary rule's verdict per row, a byte each --
-                                         // the wave derives the row constants itself, there are no row blocks
     int* scan_list;                      // rowc_kernel -> sec_scan_kernel: the rows whose secondary-eclipse verdict is open
     unsigned long long* scan_count;      // ... and their number
     // Rows counted on the device (trx_scenario_evidence: the draws that passed the geometry mask): when
@@ -120,15 +115,6 @@ __device__ __forceinline__ double uniform(double v)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-// a wave-uniform 64-bit integer (a count loaded from device memory) moved to a scalar register pair: address
-// arithmetic on it then runs on the scalar unit instead of parking products in vector registers
-__device__ __forceinline__ long uniform_long(long v)
-{
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
-    return (long)(((unsigned long)hi << 32) | lo);
 }
 
 // number of set bits of `m` below this lane
@@ -223,17 +209,6 @@ constexpr int kCellsMaxRows = 22;
 constexpr int kCellsWindowLong = TRX_CELLS_WINDOW, kCellsWindowBatch = 768;
 __host__ __device__ constexpr int cells_window(bool long_rows) { return long_rows ? kCellsWindowLong : kCellsWindowBatch; }
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
-// One row per wave (LONG): the wave derives the constants of its rows itself -- no row blocks, no 152 B per row
-// written by rowc_kernel and read back (that round trip was three quarters of the launch's HBM traffic: 40.9 MB
-// against 9.4 MB of algorithmic bytes at 2000 points).  A wave-uniform chain of ~1500 fp64 instructions per row
-// would cost ~7 % of a 2000-point row (the chain is ~3000 instructions), so a wave takes up to kFusedRows rows at a
-// time, one after the other, and derives their constants together (lanes = rows, into LDS) before the first.  A
-// static deal of four rows per workgroup lost 6 % at 1e5 rows -- a quarter of the workgroups, four times as long,
-// leave the chip's last round half empty -- hence the counter and the shrinking chunks (cells_body).
-#ifndef TRX_FUSED_ROWS
-#define TRX_FUSED_ROWS 8
-#endif
-constexpr int kFusedRows = TRX_FUSED_ROWS;
 
 // Rows per wave of the batched variant: about 640 cells per wave, at most kCellsMaxRows rows.  Measured
 // (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 -- larger
@@ -250,9 +225,8 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
     return B;
 }
 
-// Launch header (RowsArgs::hdr, in front of the row blocks in scratch): [0] chi^2 of the flat model, [1] stencil
-// radius (0 = no stencil), [2 .. 2 + 2 kStM] stencil weights, [15 .. 17] the bounded evaluation's running bounds and
-// probe verdict.
+// Launch header behind the row blocks in scratch: [0] chi^2 of the flat model, [1] stencil radius
+// (0 = no stencil), [2 .. 2 + 2 kStM] stencil weights.
 //
 // Centre-value stencil (dense uniform time grids; cells_kernel<LONG>).  The reference averages the
 // model over S sub-exposures spanning `exptime`.  On a uniform grid whose spacing dt is a fraction
@@ -276,14 +250,9 @@ constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXm
 constexpr long kPilotRows = 4096;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
-// Layout of a likelihood call's scratch (slot 0 of the stream): what does not depend on the row count -- which may
-// only be known on the device -- comes first:
-//   [0, 32)   doubles   the persistent block (zero between calls): [0] the counter of the secondary-eclipse scan's list
-//   [32, 50)            the launch header (kHdr*)
-//   [50, ..)            the scan's list of open rows, one int per row (launches that need it), then the row blocks
-constexpr int kScrHeader = (int)(kScratchZeroed / sizeof(double));
-constexpr int kScrList = kScrHeader + kHdrDoubles;
-__host__ __device__ inline size_t scan_list_doubles(long n_upper) { return (size_t)(n_upper + 1) / 2; }
+// Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
+// depend on the row count, which may only be known on the device): one 64-bit counter, then one int per row.
+__host__ __device__ inline size_t scan_list_doubles(long n_upper) { return 2 + (size_t)(n_upper + 1) / 2; }
 
 // The constants of one row (lanes = rows): unit conversion (likelihoods.py:337-347, 399-411), the radius-ratio rule,
 // orbit constants and transit window, dilution, limb weights -> c.  EB rows whose secondary depth is used (need_sec)
@@ -374,9 +343,7 @@ __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, c
 __device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
 {
     const int lane = threadIdx.x;
-    double* hdr = a.hdr;
-    // the row counters of the one-row-per-wave launches that follow (persistent block, slots 1 and 2)
-    if (lane < 2) a.scan_count[1 + lane] = 0ull;
+    double* hdr = a.rowc + n * kRowDoubles;
     if (a.flux) {
         // chi^2 of the flat model (every cell exactly 1), one number per launch, behind the row
         // blocks: rows whose model is flat over the data get exactly this value and tie
@@ -488,41 +455,6 @@ __global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
     const bool quick = SEC && a.out_sec == nullptr;
     int* list = a.scan_list;
     unsigned long long* count = a.scan_count;
-    if (SEC && a.excl) {
-        // One row per wave downstream (cells_kernel<LONG> derives the row constants itself): all that is needed of
-        // an EB row here is the verdict of the secondary rule, a byte per row -- no primary orbit, no row block
-        for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x - 1) {
-            const long base = blk * 64;
-            const int nb = (int)((n - base < 64) ? (n - base) : 64);
-            bool open = false;
-            if (lane < nb) {
-                RowC unused, sc;
-                double ysec, fdil;
-                row_constants<false>(a, n, base + lane, unused, true, sc, ysec, fdil);
-                unsigned char verdict = 0;
-#ifndef TRX_SEC_FULL_SCAN
-                const Limb L{sc.cle, sc.cld, sc.ced};
-                const double ts = __dadd_rn(__dmul_rn(0.1 / 24.0, 12.0), -0.05);       // linspace(-0.05, 0.05, 25)[12]
-                const double f = exposure_flux(sc, L, ts, 0.0, 1, 1.0, 1.0, false, a.tiers);
-                const double m = (f + ysec) / (1.0 + ysec);
-                const double depth = 1.0 - (m + fdil) / (1.0 + fdil);
-                if (!(depth < 1.5 * a.sigma)) verdict = 1;
-                else open = true;
-#else
-                open = true;
-#endif
-                a.excl[base + lane] = verdict;
-            }
-            const unsigned long long mo = __ballot(open);
-            if (mo) {
-                unsigned long long at = 0;
-                if (lane == 0) at = atomicAdd(count, (unsigned long long)__popcll(mo));
-                at = __shfl(at, 0, 64);
-                if (open) list[at + lanes_below(mo)] = (int)(base + lane);
-            }
-        }
-        return;
-    }
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x - 1) {
         const long base = blk * 64;
         const int nb = (int)((n - base < 64) ? (n - base) : 64);
@@ -619,9 +551,7 @@ __global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
             double m = secnan[lane] ? NAN : secmin[lane];                   // np.min propagates NaN
             m = (m + ysec) / (1.0 + ysec);
             const double secdepth = 1.0 - (m + fdil) / (1.0 + fdil);
-            const bool excluded = !(secdepth < 1.5 * a.sigma);                  // :535
-            if (a.excl) a.excl[row] = excluded ? 1 : 0;
-            else a.rowc[row * kRowDoubles + (kRowDoubles - 1)] = excluded ? 1.0 : 0.0;      // RowC::excl
+            a.rowc[row * kRowDoubles + (kRowDoubles - 1)] = (secdepth < 1.5 * a.sigma) ? 0.0 : 1.0;  // RowC::excl, :535
             if (a.out_sec) a.out_sec[row] = secdepth;
         }
         __syncthreads();
@@ -721,7 +651,6 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
     StencilState& ss = *reinterpret_cast<StencilState*>(&cs + 1);        // LONG only (behind the cell state)
-    RowC* rcache = reinterpret_cast<RowC*>(&ss + 1);                      // LONG only: constants of the wave's next kFusedRows rows
     // short curves: the light curve itself in LDS -- every chunk reads time stamps and fluxes of
     // arbitrary cells, and a global load right before its use costs more than the chunk's other
     // "rest" work
@@ -746,7 +675,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     long n = a.n, nbatch = a.nbatch;
     int B = Bl;
     if (a.n_dev) {
-        n = uniform_long(*a.n_dev);
+        n = *a.n_dev;
         if (!LONG) {
             B = batch_rows(n, n_time, a.forced_B);
             B = B < Bl ? B : Bl;
@@ -766,7 +695,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     }
     if (W > 1) __syncthreads();       // the only workgroup barrier: from here on every wave is on its own
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
-    const double* hdr = a.hdr;
+    const double* hdr = a.rowc + n * kRowDoubles;
     const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
     if (ST && lane <= 2 * kStM) ss.stw[lane] = hdr[kHdrStW + lane];
 
@@ -783,60 +712,14 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // workgroups go round the 8 XCDs (blockIdx & 7) and an XCD's waves take consecutive batches of its share
     // of the rows, whose blocks then stay in that XCD's L2
     const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
-    const long vstride = (long)gridDim.x * W;
-    // One row per wave (LONG): the waves take their rows from a counter in chunks of up to kFusedRows consecutive rows
-    // -- the chunk shrinks towards the end of the launch (guided scheduling: what is left / number of waves), so that
-    // the last rows are dealt one by one and the launch's tail is one row long -- and derive the constants of a chunk's
-    // rows together, lanes = rows, into rcache.  (A chunk of kFusedRows = 8 rows is one 64-byte line of each parameter
-    // column: an XCD's L2 fetches it once.)
-    long gbase = 0;
-    int gcnt = 0, turn = 0;
-    const long span = row1 - row0;
-    for (long v = v0; LONG || v < 8 * per_xcd; v += vstride) {
-        long base;
-        int nb;
-        if (LONG) {
-            if (turn == gcnt) {
-                long got = 0, take = 0;
-                if (lane == 0) {
-                    unsigned long long* ctr = a.scan_count + a.row_counter_slot;
-                    const long done = (long)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    take = (span - done) / (long)gridDim.x;
-                    take = take < 1 ? 1 : (take > kFusedRows ? kFusedRows : take);
-                    got = (long)atomicAdd(ctr, (unsigned long long)take);
-                }
-                gbase = ((long)__builtin_amdgcn_readfirstlane((int)(got >> 32)) << 32) |
-                        (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                gcnt = __builtin_amdgcn_readfirstlane((int)take);
-                if (gbase >= span) break;
-                if (span - gbase < gcnt) gcnt = (int)(span - gbase);
-                turn = 0;
-                wave_sync();
-                if (lane < gcnt) {
-                    // (straight into LDS: the fields leave the registers as they are derived)
-                    RowC unused;
-                    double y_, f_;
-                    row_constants(a, n, row0 + gbase + lane, rcache[lane], false, unused, y_, f_);
-                    if (a.excl) rcache[lane].excl = a.excl[row0 + gbase + lane] ? 1.0 : 0.0;
-                }
-                wave_sync();
-            }
-            base = row0 + gbase + turn;
-            nb = 1;
-        } else {
-            const long batch = (v & 7) * per_xcd + (v >> 3);
-            if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
-            base = row0 + batch * B;
-            nb = (int)((row1 - base < B) ? (row1 - base) : B);
-        }
+    for (long v = v0; v < 8 * per_xcd; v += (long)gridDim.x * W) {
+        const long batch = (v & 7) * per_xcd + (v >> 3);
+        if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
+        const long base = row0 + batch * B;
+        const int nb = (int)((row1 - base < B) ? (row1 - base) : B);
         TRX_TICK(t_pro);
-        if (LONG) {
-            const double* src = reinterpret_cast<const double*>(&rcache[turn]);
-            double* dst = reinterpret_cast<double*>(rows);
-            if (lane < kRowDoubles) dst[lane] = src[lane];
-            ++turn;
-        } else {
-            // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
+        // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
+        {
             const double* src = a.rowc + base * kRowDoubles;
             double* dst = reinterpret_cast<double*>(rows);
             for (int i = lane; i < nb * kRowDoubles; i += 64) dst[i] = src[i];
@@ -1142,7 +1025,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             wave_sync();
             if (PRUNE && nphase == 2 && phase_no == 0) {
                 // the verdict after the probe cells (and, for free, every out-of-window cell)
-                const double* hdr_b = a.hdr;
+                const double* hdr_b = a.rowc + n * kRowDoubles;
                 const double hmin_run = __hip_atomic_load(&hdr_b[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const double xmax_run = __hip_atomic_load(&hdr_b[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (LONG) {
@@ -1190,7 +1073,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (lane == 0) {
                     a.out[base] = h;
                     if (PRUNE && (probing || a.part == 1) && h < INFINITY)
-                        tighten_bounds(a.hdr, h, a.prune_c0 - h + lp_row);
+                        tighten_bounds(a.rowc + n * kRowDoubles, h, a.prune_c0 - h + lp_row);
                 }
             } else {
                 double h = INFINITY;
@@ -1210,7 +1093,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         hb = fmin(hb, __shfl_xor(hb, o, 64));
                         xb = fmax(xb, __shfl_xor(xb, o, 64));
                     }
-                    if (lane == 0) tighten_bounds(a.hdr, hb, xb);
+                    if (lane == 0) tighten_bounds(a.rowc + n * kRowDoubles, hb, xb);
                 }
             }
         }
@@ -1232,16 +1115,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // light curve) is harmless -- the stencil instantiation falls back to the Gauss nodes when the
 // device finds no uniform grid, the other one never uses the stencil.
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
-// (five waves per SIMD for the batched likelihood variant, which fits 96 VGPRs; its grid-mode twin -- model rows for
-// plots and tests -- keeps a few more values alive and takes four rather than spill)
-__global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE || MODE == MODE_GRID) ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
+__global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
 {
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
     // back to zero for the next call on this stream
     if (a.need_sec && blockIdx.x == 0 && threadIdx.x == 0) *a.scan_count = 0ull;
-    if (a.n_dev && !LONG) {
+    if (a.n_dev) {
         // the grid was sized for an upper bound of the row count: the blocks beyond the batches leave at once
-        // (one row per wave: the waves take rows from a counter and leave when it has passed the count)
         const long nd = *a.n_dev;
         int B = 1;
         if (!LONG) {
@@ -1259,7 +1139,7 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE || MODE == M
     double st_radius = 0.0;
     if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
         // centre-value stencil of a dense uniform grid: radius in half exposures, 0 = off
-        st_radius = uniform(a.hdr[kHdrStRadius]);
+        st_radius = uniform(a.rowc[(a.n_dev ? *a.n_dev : a.n) * kRowDoubles + kHdrStRadius]);
         if (a.use_stencil == 1 && (st_radius > 0.0) != ST) return;
         if (!ST) st_radius = 0.0;
     }
@@ -1388,7 +1268,7 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         n = *n_dev;
         nblocks = (unsigned)lme_blocks(n);
         if (blockIdx.x >= nblocks) return;
-        if (bounds_base) floor_x = bounds_base[kHdrXmax] - 90.0;       // (the launch header of the likelihood call)
+        if (bounds_base) floor_x = bounds_base[n * kRowDoubles + kHdrXmax] - 90.0;
     }
     double amin_v = INFINITY;          // SCEN: this thread's first minimum of h
     long amin_i = -1;
@@ -1794,7 +1674,7 @@ StencilMemo g_stencil_memo;
 std::atomic<int> g_cells_below{320};
 
 // what the last launch_cells of this thread did (trx::lnl_draws hands it to the reduction that follows)
-thread_local const double* t_last_hdr = nullptr;
+thread_local const double* t_last_rowc = nullptr;
 thread_local bool t_last_pruned = false;
 
 // After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 35 %
@@ -1802,7 +1682,7 @@ thread_local bool t_last_pruned = false;
 // (a scenario no draw of which comes near the data -- a faint neighbour that would need a 50 % deep eclipse --
 // has all its rows within a few tens of each other: nothing to abandon, and probing costs ~10 %).
 __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
-                                                          double* __restrict__ hdr)
+                                                          double* __restrict__ rowc)
 {
     __shared__ double smin[4];
     __shared__ int sfar[4], sfin[4];
@@ -1831,7 +1711,7 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
     if (threadIdx.x == 0) {
         far = sfar[0] + sfar[1] + sfar[2] + sfar[3];
         fin = sfin[0] + sfin[1] + sfin[2] + sfin[3];
-        hdr[kHdrProbe] = (fin > 0 && 100L * far >= 35L * fin) ? 1.0 : 0.0;
+        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 35L * fin) ? 1.0 : 0.0;
     }
 }
 
@@ -1916,7 +1796,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     auto wave_bytes = [&](bool long_variant) -> size_t {
         return (size_t)a.B * (kRowDoubles + 3) * sizeof(double)
              + (kCellsPairs + cells_window(long_variant)) * sizeof(unsigned short) + sizeof(CellState)
-             + (long_variant ? sizeof(StencilState) + kFusedRows * sizeof(RowC) : 0);
+             + (long_variant ? sizeof(StencilState) : 0);
     };
     a.tl_off = (int)(tables / sizeof(double));
     size_t shared = tables + (long_rows ? 0 : (size_t)2 * a.n_time * sizeof(double));
@@ -1934,35 +1814,22 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    // [persistent block | launch header | scan list | row blocks] -- or, with one row per wave, [... | scan list |
-    // one verdict byte per row]: those launches have no row blocks (cells_kernel<LONG> derives the constants itself)
-    const size_t list_doubles = a.need_sec ? scan_list_doubles(a.n) : 0;
-    const size_t rows_doubles = long_rows ? (a.need_sec ? ((size_t)a.n + 7) / 8 : 0) : (size_t)a.n * kRowDoubles;
-    const size_t scratch_bytes = ((size_t)kScrList + list_doubles + rows_doubles) * sizeof(double);
+    // [scan counter, scan list | row blocks | launch header]
+    const size_t list_doubles = scan_list_doubles(a.n);
+    const size_t scratch_bytes = (list_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     a.scan_count = static_cast<unsigned long long*>(scratch);
-    a.hdr = static_cast<double*>(scratch) + kScrHeader;
-    a.scan_list = reinterpret_cast<int*>(static_cast<double*>(scratch) + kScrList);
-    double* behind = static_cast<double*>(scratch) + kScrList + list_doubles;
-    a.rowc = long_rows ? nullptr : behind;
-    a.excl = (long_rows && a.need_sec) ? reinterpret_cast<unsigned char*>(behind) : nullptr;
+    a.scan_list = reinterpret_cast<int*>(static_cast<double*>(scratch) + 2);
+    a.rowc = static_cast<double*>(scratch) + list_doubles;
     {
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
-        // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
-        // that follows a scan; graph memory nodes hold anything)
-        if (a.need_sec && capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
-        if (long_rows) {
-            // the launch header by a workgroup of its own; EB rows whose secondary depth decides: their verdict bytes
-            if (a.need_sec && !a.out_sec) hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
-            else                          hipLaunchKernelGGL(rowc_kernel<false>, dim3(1), dim3(64), 0, st, a);
-        } else if (a.need_sec) {
-            hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
-        } else {
-            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
-        }
         if (a.need_sec) {
+            // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
+            // that follows a scan; graph memory nodes hold anything)
+            if (capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
             // every row when the depth is asked for; else the open rows, ~3 % of the rows of a likelihood call (which
             // are themselves ~10 % of `n` when that is only the upper bound): workgroups stride over the list
             long sb = (a.n + 63) / 64;
@@ -1970,32 +1837,26 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
             sb = sb < 64 ? 64 : (sb > 8192 ? 8192 : sb);
             if (a.out_sec) hipLaunchKernelGGL(sec_scan_kernel<64>, dim3((unsigned)sb), dim3(64), 0, st, a);
             else           hipLaunchKernelGGL(sec_scan_kernel<8>, dim3((unsigned)sb), dim3(64), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
         }
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
-    // One row per wave: as many one-wave workgroups as the chip holds at once (256 CUs x 16: four waves per SIMD), each
-    // taking rows from the launch's counter until it runs out -- fewer when there are fewer rows
-    auto long_grid = [](long rows) -> unsigned {
-        const long want = 8 * ((rows + 7) / 8);
-        return (unsigned)(want < 8 ? 8 : (want > 4096 ? 4096 : want));
-    };
-    const unsigned g2 = long_rows ? long_grid(a.n) : grid;
-    a.row_counter_slot = 1;                      // (persistent block, slot 1; the second launch of a pair takes slot 2)
-    t_last_hdr = a.hdr;
+    const unsigned g2 = long_rows ? grid_for(a.n, true) : grid;
+    t_last_rowc = a.rowc;
     t_last_pruned = prune;
     if (prune) {
         // pilot rows (evaluated to the end; first values of the running bounds), verdict on probing, the rest
         const long np = a.n < kPilotRows ? a.n : kPilotRows;
-        const long pilot_batches = (np + a.B - 1) / a.B;
+        const long pilot_batches = long_rows ? np : (np + a.B - 1) / a.B;
         RowsArgs ap = a;
         ap.part = 1;
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
-        launch_pruned<MODE>(ap, st, long_rows, fp32, long_rows ? long_grid(np) : (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
+        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
-            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.hdr);
+            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc);
             ap.part = 2;
-            ap.row_counter_slot = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
         }
     } else if (long_rows) {
@@ -2005,7 +1866,6 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
             else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, false>), dim3(g2), dim3(64), lds, st, a);
         }
         if (a.use_stencil && verdict != 1) {
-            a.row_counter_slot = 2;
             if (!step)      hipLaunchKernelGGL((cells_kernel<MODE, false, false, true, true>), dim3(g2), dim3(64), lds, st, a);
             else if (fp32)  hipLaunchKernelGGL((cells_kernel<MODE, true, true, true, true>), dim3(g2), dim3(64), lds, st, a);
             else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, true, true>), dim3(g2), dim3(64), lds, st, a);
@@ -2125,7 +1985,7 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
     a.prune_c0 = -0.5 * log(kTwoPi) - lnsigma;
     a.prune_lp = lnprior;
     const int rc = launch_rows<MODE_LNL>(a, st);
-    if (rc == TRX_OK && t_last_pruned) *bounds_base = t_last_hdr;
+    if (rc == TRX_OK && t_last_pruned) *bounds_base = t_last_rowc;
     return rc;
 }
 
