@@ -101,7 +101,12 @@ struct RowsArgs {
     int pstride;       // every pstride-th time stamp of a row is a probe cell (evaluated first)
     double prune_c0;   // -ln(2 pi)/2 - ln sigma: log-weight of a row = prune_c0 - chi^2/2 + lnprior
     const double* prune_lp;   // lnprior per DRAW (indexed through src_idx), or null
-    int part;          // PRUNE: 1 = the pilot rows [0, min(n, kPilotRows)), 2 = the rows behind them, 0 = all rows
+    int part;          // PRUNE: 1 = the pilot rows [0, min(n, kPilotRows)), 2 = the rows behind them, 0 = all rows;
+                       // split (batches of short light curves): 2 = the PROBE pass over the rows behind the pilot (verdict, the
+                       // rows still alive listed), 3 = the listed rows evaluated to the end
+    int split;
+    int* surv_list;                      // split: the rows the probe pass left alive (any order) ...
+    unsigned long long* surv_count;      // ... and their number (zeroed by pilot_stats_kernel)
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -138,9 +143,16 @@ __device__ unsigned long long g_phase_cycles[8];
 
 // rows whose light curve was not evaluated because lnL_EB_p's secondary-eclipse rule excludes them
 // anyway (statistics for benchmarks: trx_skipped_rows)
-__device__ unsigned long long g_skipped_rows;
-// rows abandoned by the bounded evaluation (cells_kernel<PRUNE>): statistics, trx_pruned_rows
-__device__ unsigned long long g_pruned_rows;
+// rows abandoned by the bounded evaluation (cells_kernel<PRUNE>): statistics, trx_pruned_rows.
+// Both counters are 256 shards, 128 bytes apart, and a wave adds its total ONCE, when it leaves: a device-scope atomic
+// per batch on one address was ~23 ns each at the memory side -- 17 000 batches: 0.4 ms behind a 0.5 ms kernel (found in
+// round 4 under the bounded evaluation's probe pass, which it made slower than the full evaluation).
+constexpr int kStatShards = 256, kStatPad = 16;
+__device__ unsigned long long g_row_stats[2][kStatShards][kStatPad];       // [0] skipped, [1] abandoned
+__device__ __forceinline__ void add_row_stat(int which, unsigned count)
+{
+    if (count) atomicAdd(&g_row_stats[which][blockIdx.x & (kStatShards - 1)][0], (unsigned long long)count);
+}
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
 __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
@@ -242,7 +254,15 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
 // the disc).  Anything else -- non-uniform stamps, coarse grids, cells near a contact, the first
 // and last kStM cells of a chunk -- takes the Gauss nodes as before.
 constexpr int kStM = 6;
-constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXmax = 16, kHdrProbe = 17, kHdrDoubles = 18;
+constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXmax = 16, kHdrProbe = 17;
+// Depth screen of the bounded evaluation (behind the 18 doubles above): a model whose flux deficit never exceeds d cannot
+// fit the data points that lie deeper than that, whatever its timing: chi^2 >= G(d) = sum_j max(0, (1 - d) - f_j)^2 /
+// sigma^2, a function of the light curve alone.  kHdrGrid holds 64 log-spaced depths (1e-5 .. 1), kHdrG the 64 values
+// G(depth); a row's largest possible deficit follows from its constants (depth_bound), and G at the next grid depth
+// above it is a lower bound of the row's chi^2 before a single cell is looked at.  Most prior draws of a planet
+// scenario are too small for a detected signal: this settles them.
+constexpr int kHdrGrid = 18, kHdrG = kHdrGrid + 64, kHdrDoubles = kHdrG + 64;
+__host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.0 * (double)i / 63.0); }
 // Bounded evaluation, two launches (see cells_body, PRUNE): the first kPilotRows rows are evaluated to the end
 // -- they give the launch's running bounds their first values, so that the bound bites from the first wave
 // of the main launch on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
@@ -354,6 +374,17 @@ __device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
                                                      // same operation everywhere, so that flat rows tie exactly)
         }
         acc = wave_sum(acc);
+        {
+            // the depth screen's table: lane i takes depth i of the grid
+            const double dpt = (lane == 63) ? 1.0 : depth_grid(lane);
+            double g = 0.0;
+            for (int j = 0; j < a.n_time; ++j) {
+                const double d = (1.0 - dpt) - a.flux[j];
+                if (d > 0.0) g = fma(d * d, a.rs2, g);
+            }
+            hdr[kHdrGrid + lane] = dpt;
+            hdr[kHdrG + lane] = g;
+        }
         if (lane == 0) {
             hdr[kHdrFlat] = acc;
             // running bounds of the launch (cells_kernel<PRUNE>): the smallest chi^2/2 and the largest
@@ -595,6 +626,35 @@ __device__ __forceinline__ int lane_prefix(int cnt, int& total)
 //               are mostly neighbours), chi^2 summed directly per lane and reduced once per row.
 // ST: the launch uses the centre-value stencil (decided on the device by rowc_kernel: the kernel
 // below picks the instantiation, so a launch without it runs exactly the code it ran before)
+// The largest flux deficit the model of a row can show at any time (depth screen, kHdrG): a body of radius ratio k
+// hides at most the fraction k^2 of the disc, where the intensity is at most Imax against the disc's mean (1 - u1/3 -
+// u2/6 for a unit centre); dilution shrinks it by rdil; the exposure average of deficits below a bound stays below it.
+__device__ __forceinline__ double depth_bound(const RowC& c)
+{
+    const double om4 = 1.0 / (c.cle + c.cld);               // limb_weights: cle + cld = 1 / (1 - u1/3 - u2/6)
+    const double u2 = c.ced * om4, u1 = c.cld * om4 - 2.0 * u2;
+    double imax = fmax(1.0, 1.0 - u1 - u2);                 // 1 - u1 x - u2 x^2 on [0, 1]: the ends ...
+    if (u2 > 0.0 && u1 < 0.0) imax += u1 * u1 / (4.0 * u2); // ... and no more than the vertex adds
+    double d = c.k * c.k * imax * (c.cle + c.cld);
+    d = (d < 1.0) ? d : 1.0;                                // (false for NaN: the bound is then 1, i.e. no bound)
+    if (!(d >= 0.0)) d = 1.0;
+    d *= c.rdil * (1.0 + 1e-12);
+    return (d <= 1.0) ? d : 1.0;                            // (NaN dilution: 1)
+}
+
+// chi^2 / 2 that a row whose deficit never exceeds `d` cannot go below (0 when the table has nothing to say)
+__device__ __forceinline__ double depth_screen(const double* hdr, double d)
+{
+    // first grid depth >= d (the grid is log-spaced: an fp32 logarithm finds the neighbourhood, two steps settle it)
+    int i = (int)ceilf((log10f((float)fmax(d, 1e-30)) + 5.0f) * (63.0f / 5.0f));
+    i = i < 0 ? 0 : (i > 63 ? 63 : i);
+    if (i > 0 && hdr[kHdrGrid + i - 1] >= d) --i;
+    if (hdr[kHdrGrid + i] < d) i = (i < 63) ? i + 1 : 63;
+    if (hdr[kHdrGrid + i] < d) return 0.0;
+    const double g = 0.5 * hdr[kHdrG + i];
+    return g - fma(1e-9, g, 1e-9);
+}
+
 // running bounds of a launch (see PRUNE below): smallest finished chi^2/2, largest finished log-weight
 __device__ __forceinline__ void tighten_bounds(double* hdr, double h, double x)
 {
@@ -701,17 +761,32 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 
     // the rows of this launch: all of them, or (PRUNE) the pilot rows / the rows behind the pilot
     long row0 = 0, row1 = n;
+    const int* rlist = nullptr;        // split, part 3: the rows of this launch are rlist[row0 .. row1)
     if (PRUNE && a.part) {
         const long np = n < kPilotRows ? n : kPilotRows;
-        if (a.part == 1) row1 = np; else row0 = np;
+        if (a.part == 1) row1 = np;
+        else if (a.part == 2) row0 = np;
+        else if (hdr[kHdrProbe] != 0.0) { rlist = a.surv_list; row1 = (long)*a.surv_count; }
+        else row0 = np;                // (no probe pass was run: every row behind the pilot, as they come)
+        if (!LONG && a.part == 3) {
+            // few rows left: fewer per wave, by the host's rule for a launch of that many rows
+            B = batch_rows(row1 - row0, n_time, a.forced_B);
+            B = B < Bl ? B : Bl;
+        }
+        // the pilot's 4096 rows one per wave: six per wave are 683 waves on 256 CUs, each a serial chain of a whole
+        // batch -- 108 us before the launch proper could start (TOI-465.01, 100 points); 4096 short waves fill the chip
+        if (!LONG && a.part == 1 && a.split) B = 1;
         nbatch = (row1 - row0 + B - 1) / B;
     }
-    // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes)
-    const bool probing = PRUNE && a.pstride > 1 && a.part != 1 && hdr[kHdrProbe] != 0.0;
+    // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes, nor
+    // does the pass over the listed rows)
+    const bool probing = PRUNE && a.pstride > 1 && (a.part == 0 || a.part == 2) && hdr[kHdrProbe] != 0.0;
+    if (PRUNE && a.split && a.part == 2 && !probing) return;       // nothing to probe: part 3 takes the rows directly
     const long per_xcd = (nbatch + 7) / 8;
     // workgroups go round the 8 XCDs (blockIdx & 7) and an XCD's waves take consecutive batches of its share
     // of the rows, whose blocks then stay in that XCD's L2
     const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
+    unsigned n_skipped = 0, n_pruned = 0;          // this wave's rows for trx_skipped_rows / trx_pruned_rows
     for (long v = v0; v < 8 * per_xcd; v += (long)gridDim.x * W) {
         const long batch = (v & 7) * per_xcd + (v >> 3);
         if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
@@ -719,7 +794,15 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         const int nb = (int)((row1 - base < B) ? (row1 - base) : B);
         TRX_TICK(t_pro);
         // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
-        {
+        long rowid = base + lane;          // the row of lane `lane` of the batch (lanes < nb)
+        if (PRUNE && rlist) {
+            if (lane < nb) rowid = (long)rlist[base + lane];
+            double* dst = reinterpret_cast<double*>(rows);
+            for (int i = lane; i < nb * kRowDoubles; i += 64) {
+                const int r = i / kRowDoubles, q = i - r * kRowDoubles;
+                dst[i] = a.rowc[(long)rlist[base + r] * kRowDoubles + q];
+            }
+        } else {
             const double* src = a.rowc + base * kRowDoubles;
             double* dst = reinterpret_cast<double*>(rows);
             for (int i = lane; i < nb * kRowDoubles; i += 64) dst[i] = src[i];
@@ -740,7 +823,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         unsigned long long skipmask = 0;
         if (MODE == MODE_LNL && a.skip_excl && a.model == TRX_MODEL_EB) {
             skipmask = __ballot(lane < nb && rows[lane].excl != 0.0);
-            if (lane == 0 && skipmask) atomicAdd(&g_skipped_rows, (unsigned long long)__popcll(skipmask));
+            n_skipped += (unsigned)__popcll(skipmask);
             if (LONG && skipmask) {                  // the wave's only row: done
                 if (lane == 0) a.out[base] = INFINITY;
                 wave_sync();
@@ -765,11 +848,60 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         double lp_row = 0.0;
         unsigned long long deadmask = 0;
         bool long_dead = false;
-        if (PRUNE && a.prune_lp && lane < nb) lp_row = a.prune_lp[a.src_idx ? (long)a.src_idx[base + lane] : base + lane];
+        if (PRUNE && a.prune_lp && lane < nb) lp_row = a.prune_lp[a.src_idx ? (long)a.src_idx[rowid] : rowid];
+        bool probe_done = false;           // split, part 2: the batch ends with the verdict
+        const unsigned long long exclmask = skipmask;       // the rows the EB secondary rule excludes (+inf)
+        // The probe pass (split, part 2) ends with the verdict: an abandoned row reports its bound, an excluded one
+        // +inf, and the rows still alive go on the launch's list -- one atomic per wave -- for the pass that evaluates
+        // them to the end on full chunks (part 3).  Until round 3 a batch went on with its survivors alone: one or two
+        // rows' cells in chunks made for six, behind a second window pass; with nine rows in ten abandoned a call got
+        // 15 % faster where the arithmetic allows 2.5 x.
+        auto finish_probe = [&]() {
+            const bool in_batch = lane < nb;
+            const bool is_dead = (deadmask >> lane) & 1ull, is_excl = (exclmask >> lane) & 1ull;
+            const bool alive = in_batch && !is_dead && !is_excl;
+            if (in_batch && !alive) a.out[rowid] = is_excl ? INFINITY : hrem[lane];
+            const unsigned long long ma = __ballot(alive);
+            if (ma) {
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(a.surv_count, (unsigned long long)__popcll(ma));
+                at = __shfl(at, 0, 64);
+                if (alive) a.surv_list[at + lanes_below(ma)] = (int)rowid;
+            }
+        };
+        if (PRUNE && probing) {
+            // depth screen: a row too shallow (diluted) for the data is settled by its constants alone
+            const double hmin_run = __hip_atomic_load(&hdr[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double xmax_run = __hip_atomic_load(&hdr[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool shallow = false;
+            if (lane < nb && !((skipmask >> lane) & 1ull)) {
+                const double lb = depth_screen(hdr, depth_bound(rows[lane]));
+                shallow = hmout[lane] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp_row) < xmax_run - 90.0;
+#ifdef TRX_PRUNE_NEVER_DEAD
+                shallow = false;
+#endif
+                if (shallow) hrem[lane] = lb;                          // what the row reports
+            }
+            const unsigned long long ms = __ballot(shallow);
+            if (ms) {
+                deadmask |= ms;
+                skipmask |= ms;
+                n_pruned += (unsigned)__popcll(ms);
+                wave_sync();
+                if (LONG) {                          // the wave's only row
+                    if (lane == 0) a.out[base] = hrem[0];
+                    wave_sync();
+                    continue;
+                }
+            }
+        }
         const int nphase = probing ? 2 : 1;
         TRX_TOCK(0, t_pro);
 
-        const int ncell = nb * n_time;
+        // (every row of the batch settled by the depth screen or the EB rule: no cell to look at)
+        const unsigned long long rowsmask = (nb >= 64) ? ~0ull : ((1ull << nb) - 1ull);
+        const bool all_settled = PRUNE && !LONG && (skipmask & rowsmask) == rowsmask;
+        const int ncell = all_settled ? 0 : nb * n_time;
         for (int win0 = 0; win0 < ncell; win0 += kCellsWindow) {
             const int win1 = (win0 + kCellsWindow < ncell) ? (win0 + kCellsWindow) : ncell;
             for (int phase_no = 0; phase_no < nphase; ++phase_no) {
@@ -787,6 +919,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     j = valid ? (cell - rr * n_time) : 0;
                 }
                 bool inw = false;
+                // (a trip all of whose rows are settled -- abandoned, excluded -- has nothing to test)
+                if (PRUNE && !LONG && !__any(valid && !((skipmask >> rr) & 1ull))) continue;
                 if (valid) {
                     const RowC& c = LONG ? cu : rows[rr];
                     const double phase = c.nmot * (tl[j] - c.t0);
@@ -1034,10 +1168,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     const double lp0 = __shfl(lp_row, 0, 64);
                     long_dead = hmout[0] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp0) < xmax_run - 90.0;
                     if (long_dead) {
-                        if (lane == 0) {
-                            a.out[base] = lb;
-                            atomicAdd(&g_pruned_rows, 1ull);
-                        }
+                        if (lane == 0) a.out[base] = lb;
+                        ++n_pruned;
                         break;
                     }
                 } else {
@@ -1054,14 +1186,22 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     const unsigned long long md = __ballot(dead);
                     deadmask |= md;
                     skipmask |= md;
-                    if (lane == 0 && md) atomicAdd(&g_pruned_rows, (unsigned long long)__popcll(md));
+                    n_pruned += (unsigned)__popcll(md);
                     wave_sync();
+                    if (a.split && a.part == 2) {
+                        finish_probe();
+                        probe_done = true;
+                    }
                 }
             }
+            if (PRUNE && probe_done) break;
             }
             if (PRUNE && LONG && long_dead) break;
+            if (PRUNE && probe_done) break;
         }
         if (PRUNE && LONG && long_dead) { wave_sync(); continue; }
+        if (PRUNE && a.split && a.part == 2 && !probe_done) { finish_probe(); probe_done = true; }     // (all_settled)
+        if (PRUNE && probe_done) { wave_sync(); continue; }
         if (MODE == MODE_LNL) {
             if (LONG) {
                 // a row whose model is flat over the data takes the launch's flat-model value, so
@@ -1072,7 +1212,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (a.model == TRX_MODEL_EB && rows[0].excl != 0.0) h = INFINITY;   // :535-538
                 if (lane == 0) {
                     a.out[base] = h;
-                    if (PRUNE && (probing || a.part == 1) && h < INFINITY)
+                    if (PRUNE && (probing || a.part == 1 || a.part == 3) && h < INFINITY)
                         tighten_bounds(a.rowc + n * kRowDoubles, h, a.prune_c0 - h + lp_row);
                 }
             } else {
@@ -1081,9 +1221,9 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
                     if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
                     if (PRUNE && ((deadmask >> lane) & 1ull)) h = hrem[lane];
-                    a.out[base + lane] = h;
+                    a.out[rowid] = h;
                 }
-                if (PRUNE && (probing || a.part == 1)) {
+                if (PRUNE && (probing || a.part == 1 || a.part == 3)) {
                     // the batch's best finished row tightens the launch's running bounds (one wave, one update)
                     const bool fin = lane < nb && !((deadmask >> lane) & 1ull) && h < INFINITY;      // (false for NaN)
                     double hb = fin ? h : INFINITY, xb = fin ? a.prune_c0 - h + lp_row : -INFINITY;
@@ -1098,6 +1238,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             }
         }
         wave_sync();
+    }
+    if (lane == 0) {
+        add_row_stat(0, n_skipped);
+        add_row_stat(1, n_pruned);
     }
 #ifdef TRX_PHASE_TIMERS
     TRX_TOCK(7, t_all);
@@ -1132,6 +1276,14 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS
         if (PRUNE && a.part) {
             const long np = nd < kPilotRows ? nd : kPilotRows;
             rows_here = a.part == 1 ? np : nd - np;
+            if (!LONG && a.part == 1 && a.split) B = 1;
+            if (a.part == 3 && a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) {
+                rows_here = (long)*a.surv_count;
+                if (!LONG) {
+                    B = batch_rows(rows_here, a.n_time, a.forced_B);
+                    B = B < a.B ? B : a.B;
+                }
+            }
         }
         // (the first batch index of this workgroup's first wave, see cells_body)
         if ((long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * cells_waves(LONG)) >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
@@ -1522,12 +1674,12 @@ int n_params(int model)
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
 std::atomic<int> g_tiers{1};
-// bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always (TRX_BOUNDED in
-// the environment sets the initial value: A/B runs of whole programs)
+// bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always (the default since
+// round 4; TRX_BOUNDED in the environment sets the initial value: A/B runs of whole programs)
 static int initial_prune_mode()
 {
     const char* e = getenv("TRX_BOUNDED");
-    return (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : 1;
+    return (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : 2;
 }
 std::atomic<int> g_prune{initial_prune_mode()};
 std::atomic<int> g_prune_lnl{0};      // tests: trx_lnl_batch applies it too (as for an evidence without prior)
@@ -1677,13 +1829,16 @@ std::atomic<int> g_cells_below{320};
 thread_local const double* t_last_rowc = nullptr;
 thread_local bool t_last_pruned = false;
 
-// After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 35 %
+// After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 60 %
 // of the finite ones lie more than 150 above the smallest, the main launch evaluates its rows in one pass
 // (a scenario no draw of which comes near the data -- a faint neighbour that would need a 50 % deep eclipse --
-// has all its rows within a few tens of each other: nothing to abandon, and probing costs ~10 %).
+// has all its rows within a few tens of each other: nothing to abandon; and measured per call in round 4,
+// profiles/r04_bounded_short.txt: with 37 % of the rows abandoned -- TOI-411.02, a 166 ppm signal -- the probe pass
+// costs more than it saves (0.54 -> 0.73 ms), with 76 % it pays (0.59 -> 0.50), with 93 % it halves the call).
 __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
-                                                          double* __restrict__ rowc)
+                                                          double* __restrict__ rowc, unsigned long long* __restrict__ surv_count)
 {
+    if (threadIdx.x == 0 && surv_count) *surv_count = 0ull;
     __shared__ double smin[4];
     __shared__ int sfar[4], sfin[4];
     if (n_dev) n = *n_dev;
@@ -1711,7 +1866,7 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
     if (threadIdx.x == 0) {
         far = sfar[0] + sfar[1] + sfar[2] + sfar[3];
         fin = sfin[0] + sfin[1] + sfin[2] + sfin[3];
-        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 35L * fin) ? 1.0 : 0.0;
+        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 60L * fin) ? 1.0 : 0.0;
     }
 }
 
@@ -1814,14 +1969,20 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    // [scan counter, scan list | row blocks | launch header]
+    // [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list) | row blocks |
+    // launch header]
     const size_t list_doubles = scan_list_doubles(a.n);
-    const size_t scratch_bytes = (list_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
+    const bool split = prune && !long_rows;
+    const size_t surv_doubles = split ? scan_list_doubles(a.n) : 0;
+    const size_t scratch_bytes = (list_doubles + surv_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     a.scan_count = static_cast<unsigned long long*>(scratch);
     a.scan_list = reinterpret_cast<int*>(static_cast<double*>(scratch) + 2);
-    a.rowc = static_cast<double*>(scratch) + list_doubles;
+    a.split = split ? 1 : 0;
+    a.surv_count = split ? reinterpret_cast<unsigned long long*>(static_cast<double*>(scratch) + list_doubles) : nullptr;
+    a.surv_list = split ? reinterpret_cast<int*>(static_cast<double*>(scratch) + list_doubles + 2) : nullptr;
+    a.rowc = static_cast<double*>(scratch) + list_doubles + surv_doubles;
     {
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
@@ -1849,15 +2010,21 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     if (prune) {
         // pilot rows (evaluated to the end; first values of the running bounds), verdict on probing, the rest
         const long np = a.n < kPilotRows ? a.n : kPilotRows;
-        const long pilot_batches = long_rows ? np : (np + a.B - 1) / a.B;
+        const long pilot_batches = (long_rows || split) ? np : (np + a.B - 1) / a.B;      // (split: one pilot row per wave)
         RowsArgs ap = a;
         ap.part = 1;
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
         launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
-            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc);
+            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count);
             ap.part = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+            if (split) {
+                // batches of short light curves: the launch above was the probe pass; the rows it left alive, compacted
+                // across workgroups, are evaluated to the end here
+                ap.part = 3;
+                launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+            }
         }
     } else if (long_rows) {
         if (verdict != 2) {
@@ -2182,16 +2349,26 @@ int trx_set_skip_excluded(int on)
 }
 
 /* statistics (include/trx.h): rows skipped on the current device since the last reset */
-int trx_skipped_rows(unsigned long long* out, int reset)
+static int read_row_stat(int which, unsigned long long* out, int reset)
 {
+    static unsigned long long host[2][kStatShards][kStatPad];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     TRX_HIP(hipDeviceSynchronize());
-    if (out) TRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_skipped_rows), sizeof(unsigned long long)));
+    TRX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_row_stats), sizeof(host)));
+    if (out) {
+        unsigned long long sum = 0;
+        for (int i = 0; i < kStatShards; ++i) sum += host[which][i][0];
+        *out = sum;
+    }
     if (reset) {
-        const unsigned long long zero = 0;
-        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_skipped_rows), &zero, sizeof(zero)));
+        for (int i = 0; i < kStatShards; ++i) host[which][i][0] = 0;
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), host, sizeof(host)));
     }
     return TRX_OK;
 }
+
+int trx_skipped_rows(unsigned long long* out, int reset) { return read_row_stat(0, out, reset); }
 
 /* diagnostics (include/trx.h): 0 = trx_scenario_evidence evaluates every masked draw to the end */
 int trx_set_bounded_evaluation(int mode)
@@ -2209,16 +2386,7 @@ int trx_set_debug_bounded_lnl(int on)
 }
 
 /* statistics (include/trx.h): rows abandoned by the bounded evaluation on the current device since the last reset */
-int trx_pruned_rows(unsigned long long* out, int reset)
-{
-    TRX_HIP(hipDeviceSynchronize());
-    if (out) TRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pruned_rows), sizeof(unsigned long long)));
-    if (reset) {
-        const unsigned long long zero = 0;
-        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pruned_rows), &zero, sizeof(zero)));
-    }
-    return TRX_OK;
-}
+int trx_pruned_rows(unsigned long long* out, int reset) { return read_row_stat(1, out, reset); }
 
 /* diagnostics (include/trx.h): 0 = Gauss nodes everywhere, no centre-value stencil */
 int trx_set_stencil(int on)
