@@ -16,10 +16,8 @@ python profiles/cells_batch_sweep.py 300000 100 >> $O/${T}_cells_batch_sweep.txt
 python profiles/e2e_streams.py > $O/${T}_e2e_streams.txt 2>&1
 python profiles/batch_timing.py > $O/${T}_batch_timing.txt 2>&1
 python profiles/batch_host_profile.py 2>&1 | head -60 > $O/${T}_batch_host_profile.txt
-python profiles/trip_occupancy.py 20000 100 200 > $O/${T}_trip_occupancy.txt 2>&1
-if [ -f profiles/ab_libs/libtrx_agmcount.so ]; then
-  TRX_LIB=$R/profiles/ab_libs/libtrx_agmcount.so python profiles/agm_steps.py 20000 100 2000 > $O/${T}_agm_steps.txt 2>&1
-fi
+python profiles/bounded_short.py > $O/${T}_bounded_short.txt 2>&1
+python profiles/fuzz_kernels.py 300 77 > $O/${T}_fuzz.txt 2>&1
 bash profiles/draw_stats.sh ${T} > $O/${T}_draw_kernel.txt 2>&1
 bash profiles/stats_batch.sh ${T}batch > $O/${T}_batch_kernel_stats.txt 2>&1
 python profiles/step_union.py $(ls $O/stats_${T}batch/*/*kernel_trace.csv | head -1) >> $O/${T}_batch_kernel_stats.txt 2>&1

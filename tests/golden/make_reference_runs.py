@@ -2,13 +2,14 @@
 """tests/golden/reference_runs.npz: results of the REFERENCE's own calc_probs at N = 1e6 on the notebook
 inputs, run on the CPU of the build container by profiles/reference_fpp_cpu.py (the reference imported from
 /root/reference under the shims of make_golden.py: oracle QuadraticModel at the pytransit seam, synthetic
-TRILEGAL table).  ~80-100 s per run, hence few runs (6 of TOI-465.01, 16 of TOI-411.02); they are the sample tests/test_gpu_notebook_anchors.py
+TRILEGAL table).  ~80-100 s per run, hence few runs (16 of TOI-465.01, 16 of TOI-411.02); they are the sample tests/test_gpu_notebook_anchors.py
 compares the device path's distribution with (same code base as the device path mirrors, unlike the stored
 notebook outputs, which an older release produced).
 
     python profiles/reference_fpp_cpu.py toi465_nocc 6 >  profiles/r04_reference_fpp_cpu.txt
     python profiles/reference_fpp_cpu.py toi411 4      >> profiles/r04_reference_fpp_cpu.txt      (round 3: seeds 1000-1003)
     python profiles/reference_fpp_cpu.py toi411 12 1000000 1004 >> profiles/r04_reference_fpp_cpu.txt   (round 4: 1004-1015)
+    python profiles/reference_fpp_cpu.py toi465_nocc 10 1000000 1006 >> profiles/r04_reference_fpp_cpu.txt   (round 4: 1006-1015)
     python tests/golden/make_reference_runs.py profiles/r04_reference_fpp_cpu.txt
 """
 import os

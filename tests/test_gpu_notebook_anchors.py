@@ -11,7 +11,7 @@ the runs were looked at) and is held against
 
  * the CURRENT reference code: tests/golden/reference_runs.npz, the reference's own calc_probs run on the CPU of
    the build container at N = 1e6 with the oracle at pytransit's seam (profiles/reference_fpp_cpu.py, ~90 s a
-   run: 6 runs of TOI-465.01, 16 of TOI-411.02).  This is where agreement is REQUIRED: lnZ of TP / PTP / STP, FPP
+   run: 16 runs of each of TOI-465.01 and TOI-411.02).  This is where agreement is REQUIRED: lnZ of TP / PTP / STP, FPP
    and the TP radius by rank (Mann-Whitney), the log-shares ln(PTP/TP), ln(STP/TP) of TOI-411.02 -- the one
    tight anchor, 0.07 and 0.11 of scatter per run -- within 3 standard errors of the difference of the means;
  * the notebook's single run: the shares of TP : PTP : STP among themselves (the three scenarios whose evidence
@@ -116,7 +116,7 @@ def test_fpp_with_contrast_curve_against_the_notebooks_20_runs():
 @pytest.mark.parametrize("case", ["toi465_nocc", "toi411"])
 def test_device_path_against_runs_of_the_current_reference_code(case):
     """lnZ of TP / PTP / STP, FPP and the TP radius: this implementation's runs against the reference's own
-    (reference_runs.npz; 6 and 16 runs).  The evidences of a run are skewed (a lucky draw lifts lnZ), so the
+    (reference_runs.npz; 16 runs each).  The evidences of a run are skewed (a lucky draw lifts lnZ), so the
     comparison is by rank: Mann-Whitney's two-sided p-value above 0.002 for each quantity.  The notebook's FPP
     of the same input is printed beside it (cell 14 / cell 25): reported, not gated (module docstring)."""
     from scipy.stats import mannwhitneyu

@@ -1829,12 +1829,14 @@ std::atomic<int> g_cells_below{320};
 thread_local const double* t_last_rowc = nullptr;
 thread_local bool t_last_pruned = false;
 
-// After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 60 %
+// After the pilot launch: does probing pay?  One workgroup over the pilot rows' chi^2/2: if fewer than 90 %
 // of the finite ones lie more than 150 above the smallest, the main launch evaluates its rows in one pass
 // (a scenario no draw of which comes near the data -- a faint neighbour that would need a 50 % deep eclipse --
 // has all its rows within a few tens of each other: nothing to abandon; and measured per call in round 4,
 // profiles/r04_bounded_short.txt: with 37 % of the rows abandoned -- TOI-411.02, a 166 ppm signal -- the probe pass
-// costs more than it saves (0.54 -> 0.73 ms), with 76 % it pays (0.59 -> 0.50), with 93 % it halves the call).
+// costs more than it saves (0.54 -> 0.73 ms), with 76 % it pays (0.59 -> 0.50), with 93 % it halves the call.  The share
+// of pilot rows 150 above the best overstates what the probe cells can prove: 0.8 for TOI-411.02, 0.995 and more for
+// the cases that gain -- hence 90 %).
 __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
                                                           double* __restrict__ rowc, unsigned long long* __restrict__ surv_count)
 {
@@ -1866,7 +1868,7 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
     if (threadIdx.x == 0) {
         far = sfar[0] + sfar[1] + sfar[2] + sfar[3];
         fin = sfin[0] + sfin[1] + sfin[2] + sfin[3];
-        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 60L * fin) ? 1.0 : 0.0;
+        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 90L * fin) ? 1.0 : 0.0;
     }
 }
 
