@@ -246,3 +246,27 @@ def test_eccentric_supersampled_row_end_to_end_in_arbitrary_precision():
     got = O.evaluate_pv(times, [[k, t0, per, a, inc, e, w]], [[u1, u2]], ex, S)[0]
     assert min(want) < 0.99 and max(want) == 1.0        # the row covers ingress, mid-transit and baseline
     assert np.max(np.abs(got - np.array(want))) < 2e-13, np.abs(got - np.array(want))
+
+
+def test_depth_bound_of_the_bounded_evaluation_holds_for_the_disc_model():
+    """cells_kernel<PRUNE>'s depth screen (csrc/trx_kernels.hip, depth_bound) settles a row from its constants: a body
+    of radius ratio k cannot take more than k^2 Imax / Imean of the flux, Imax the largest intensity of the
+    quadratic law on the disc, Imean = 1 - u1/3 - u2/6.  The same expression here against the oracle's
+    Mandel-Agol flux over all separations, for limb-darkening pairs inside and outside the physical range."""
+    rng = np.random.default_rng(5)
+    worst = -np.inf
+    for _ in range(400):
+        k = float(10 ** rng.uniform(-2.5, 0.3))
+        u1, u2 = float(rng.uniform(-0.3, 1.0)), float(rng.uniform(-0.3, 0.6))
+        if 1 - u1 / 3 - u2 / 6 <= 0.2:
+            continue
+        imax = max(1.0, 1.0 - u1 - u2)
+        if u2 > 0 and u1 < 0:
+            imax += u1 * u1 / (4 * u2)
+        bound = k * k * imax / (1 - u1 / 3 - u2 / 6)       # (no cap at 1: negative limb intensities can exceed it)
+        z = np.concatenate([np.linspace(0, 1 + k, 400), [abs(1 - k), k, 1.0]])
+        deficit = max(1.0 - O.ma_flux(float(zz), k, u1, u2) for zz in z if zz < 1 + k)
+        worst = max(worst, deficit - bound)
+        assert deficit <= bound * (1 + 1e-12) + 1e-15, (k, u1, u2, deficit, bound)
+    assert worst <= 1e-15
+    # ... and the screen is only consulted below 1 (csrc: depth_screen returns 0 from there on)

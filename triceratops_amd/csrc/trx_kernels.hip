@@ -635,16 +635,16 @@ __device__ __forceinline__ double depth_bound(const RowC& c)
     const double u2 = c.ced * om4, u1 = c.cld * om4 - 2.0 * u2;
     double imax = fmax(1.0, 1.0 - u1 - u2);                 // 1 - u1 x - u2 x^2 on [0, 1]: the ends ...
     if (u2 > 0.0 && u1 < 0.0) imax += u1 * u1 / (4.0 * u2); // ... and no more than the vertex adds
-    double d = c.k * c.k * imax * (c.cle + c.cld);
-    d = (d < 1.0) ? d : 1.0;                                // (false for NaN: the bound is then 1, i.e. no bound)
-    if (!(d >= 0.0)) d = 1.0;
-    d *= c.rdil * (1.0 + 1e-12);
-    return (d <= 1.0) ? d : 1.0;                            // (NaN dilution: 1)
+    // (no cap at 1: a law whose intensity turns negative at the limb -- u1 + u2 > 1 -- lets a large body hide MORE than
+    // the whole flux; depth_screen has nothing to say from 1 on)
+    const double d = c.k * c.k * imax * (c.cle + c.cld) * c.rdil * (1.0 + 1e-12);
+    return (d >= 0.0) ? d : INFINITY;                       // (NaN anywhere: no bound)
 }
 
 // chi^2 / 2 that a row whose deficit never exceeds `d` cannot go below (0 when the table has nothing to say)
 __device__ __forceinline__ double depth_screen(const double* hdr, double d)
 {
+    if (!(d < 1.0)) return 0.0;
     // first grid depth >= d (the grid is log-spaced: an fp32 logarithm finds the neighbourhood, two steps settle it)
     int i = (int)ceilf((log10f((float)fmax(d, 1e-30)) + 5.0f) * (63.0f / 5.0f));
     i = i < 0 ? 0 : (i > 63 ? 63 : i);
