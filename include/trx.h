@@ -178,15 +178,18 @@ int trx_set_rows_per_wave(int rows);
  *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
  *    for each cell instead of the flux. */
 /*  - trx_set_bounded_evaluation(mode): 0 = trx_scenario_evidence / trx_scenario_enqueue evaluate every masked
- *    draw to the end; 1 (default) = bounded evaluation for light curves of trx_set_cell_packing_below's
- *    threshold and more (one row per wave), 2 = for every light curve.  Bounded: a draw is abandoned once its
- *    chi^2 over the cells done so far shows that it can neither be the best draw (it exceeds the smallest
- *    finished chi^2) nor carry weight in the evidence (its log-weight lies 90 below the largest finished one;
- *    the reduction drops everything 80 below the largest).  lnZ agrees to rounding (the ~16 probe cells of a
- *    row are summed first), the best draw is the same, results repeat bit for bit from run to run; the first
- *    4096 rows are evaluated to the end (they seed the bounds and decide whether probing pays).
- *    trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the device).  The per-row entry
- *    points (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
+ *    draw to the end; 1 = bounded evaluation for light curves of trx_set_cell_packing_below's threshold and more
+ *    (one row per wave), 2 (default since round 4) = for every light curve.  Bounded: a draw is abandoned once it is
+ *    shown that it can neither be the best draw (its chi^2 exceeds the smallest finished chi^2) nor carry weight in
+ *    the evidence (its log-weight lies 90 below the largest finished one; the reduction drops everything 80 below
+ *    the largest) -- from its constants alone when the model can never be as deep as the data (a lower bound of
+ *    chi^2 that depends on the light curve and the model's largest possible flux deficit only), else from its
+ *    chi^2 over ~16 probe cells and every cell outside its transit window.  Short light curves (batches of rows per
+ *    wave) take it in passes: the first 4096 rows to the end (they seed the bounds and decide whether probing pays:
+ *    it does when >= 90 % of them lie 150 above the best), a probe pass over the rest, and the rows it leaves alive
+ *    -- compacted across workgroups -- to the end.  lnZ agrees to rounding, the best draw is the same, results
+ *    repeat bit for bit from run to run.  trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the
+ *    device).  The per-row entry points (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
 int trx_set_bounded_evaluation(int mode);
 /*    trx_set_debug_bounded_lnl(1) (tests): trx_lnl_batch / trx_lnz_scenario treat their rows the same way, as
  *    for an evidence without prior: a row then holds its chi^2/2 or, if abandoned, a lower bound of it that

@@ -53,4 +53,4 @@ for name, base, plx in cases():
             r = res[0] if isinstance(res, tuple) else res
             line += "   bounded %d: %.3f ms, %d rows, %d abandoned, lnZ %.6f" % (mode, best, _lib.STATS["rows"], cnt.value, r["lnZ"])
         print(line, flush=True)
-L.trx_set_bounded_evaluation(1)
+L.trx_set_bounded_evaluation(2)

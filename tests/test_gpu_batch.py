@@ -150,9 +150,8 @@ def test_native_scenario_call_equals_the_torch_operator_path():
     """trx_scenario_enqueue (draws -> compaction -> likelihood -> evidence -> best draw in one library
     call, no host sync) against the chain of torch operators around trx_draw_scenario / trx_lnz_scenario on
     the same Philox keys, on all 18 scenarios of several TOIs, with a contrast curve, in fp64 and in the
-    mixed-precision mode.  With every row evaluated to the end (trx_set_bounded_evaluation(0), and the default
-    for these 200-point light curves): every lnZ, every best-fit column and FPP / NFPP bit for bit.  With the
-    bounded evaluation forced (mode 2): the same best draws, lnZ to 1e-12 (the probe cells of a row are summed
+    mixed-precision mode.  With every row evaluated to the end (trx_set_bounded_evaluation(0)): every lnZ, every best-fit column and FPP / NFPP bit for bit.  With the
+    bounded evaluation (mode 2, the default): the same best draws, lnZ to 1e-12 (the probe cells of a row are summed
     first: another order of the same terms)."""
     import triceratops_amd
     from triceratops_amd import fused, sharding
@@ -190,7 +189,40 @@ def test_native_scenario_call_equals_the_torch_operator_path():
             assert got["native"][1]["cells"] == got["torch"][1]["cells"]
     finally:
         fused.NATIVE = True
-        L.trx_set_bounded_evaluation(1)
+        L.trx_set_bounded_evaluation(2)          # (the library's default)
         sharding.per_unit_seed = False
         triceratops_amd.set_precision("fp64")
+        triceratops_amd.set_sampling("numpy")
+
+
+def test_bounded_evaluation_leaves_no_row_unwritten_whatever_the_row_count():
+    """The bounded evaluation of short light curves is three passes (pilot rows, probe pass, the rows left alive)
+    whose grids are sized for an upper bound of a row count that only the device knows; a workgroup beyond the
+    batches leaves at once, by a rule that must use the SAME rows-per-wave as the pass itself (round 4's first
+    version did not for 30 000-34 000 masked draws: tests/test_toi465.py::test_blend_bounded_evaluation_equals_the_
+    full_one_on_one_and_six_streams is the run that showed it).  Here: N swept so that the masked counts of the 18
+    scenarios of two synthetic TOIs cross the thresholds of the rows-per-wave rule; bounded against unbounded: same
+    best draws, lnZ to 1e-12."""
+    import triceratops_amd
+    from triceratops_amd import sharding
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    L = _lib.lib()
+    try:
+        for N in (60_000, 250_000, 290_000, 330_000, 370_000, 420_000, 480_000, 560_000):
+            got = {}
+            for mode in (0, 2):
+                L.trx_set_bounded_evaluation(mode)
+                np.random.seed(9)
+                torch.manual_seed(9)
+                got[mode] = triceratops_amd.calc_probs_many(_jobs(2, N))
+            for x, z in zip(got[0], got[2]):
+                fin = np.isfinite(x.lnZ)
+                assert np.array_equal(fin, np.isfinite(z.lnZ)), N
+                assert np.allclose(z.lnZ[fin], x.lnZ[fin], rtol=1e-12, atol=0), (N, np.abs(z.lnZ[fin] - x.lnZ[fin]).max())
+                for c in ("P_orb", "inc", "R_p", "ecc", "w", "M_EB", "R_EB"):
+                    assert np.array_equal(x.probs[c].values, z.probs[c].values, equal_nan=True), (N, c)
+    finally:
+        L.trx_set_bounded_evaluation(2)
+        sharding.per_unit_seed = False
         triceratops_amd.set_sampling("numpy")

@@ -161,3 +161,37 @@ def test_config3_blend_at_full_size(sampling):
     import anchors
     many = anchors.run_many("toi465_cc", range(1000, 1064))[2]
     assert -1e-9 <= tg.FPP and abs(tg.FPP - many.mean()) < 4.0 * many.std(ddof=1), (tg.FPP, many.mean(), many.std(ddof=1))
+
+
+@pytest.mark.gpu
+def test_blend_bounded_evaluation_equals_the_full_one_on_one_and_six_streams():
+    """The 75-scenario blend, N = 1e6, device sampling: every lnZ with the bounded evaluation (the default: pilot
+    rows, probe pass, the rows left alive) against every row evaluated to the end, with the calls on one stream and
+    dealt to six.  This is the run on which round 4's first version of the three-pass scheme left rows unwritten
+    (the twin branches of the nearby stars' EB calls, 30 000-34 000 masked draws each: chi^2 of whatever call had
+    used the stream before; FPP = 1 with six streams, right with one)."""
+    import torch
+    import triceratops_amd
+    from triceratops_amd import _lib, sharding
+    triceratops_amd.set_sampling("device")
+    L = _lib.lib()
+    saved = sharding.streams
+    try:
+        runs = {}
+        for mode, streams in ((0, 1), (2, 1), (2, 6), (2, 3), (0, 6)):
+            L.trx_set_bounded_evaluation(mode)
+            sharding.streams = streams
+            torch.manual_seed(465)
+            runs[(mode, streams)] = _run("blend", 1_000_000, 465)
+        ref = runs[(0, 1)]
+        fin = np.isfinite(ref.lnZ)
+        assert fin.sum() >= 60
+        for key, tg in runs.items():
+            assert np.array_equal(fin, np.isfinite(tg.lnZ)), key
+            # (hopeless scenarios sit at lnZ ~ -1e6: relative)
+            assert np.allclose(tg.lnZ[fin], ref.lnZ[fin], rtol=1e-12, atol=0), (key, np.abs(tg.lnZ[fin] - ref.lnZ[fin]).max())
+            assert abs(tg.FPP - ref.FPP) < 1e-12 and abs(tg.NFPP - ref.NFPP) < 1e-12, key
+    finally:
+        L.trx_set_bounded_evaluation(2)
+        sharding.streams = saved
+        triceratops_amd.set_sampling("numpy")

@@ -869,6 +869,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (alive) a.surv_list[at + lanes_below(ma)] = (int)rowid;
             }
         };
+#ifndef TRX_NO_DEPTH_SCREEN
         if (PRUNE && probing) {
             // depth screen: a row too shallow (diluted) for the data is settled by its constants alone
             const double hmin_run = __hip_atomic_load(&hdr[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -898,6 +899,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         const int nphase = probing ? 2 : 1;
         TRX_TOCK(0, t_pro);
 
+#endif
         // (every row of the batch settled by the depth screen or the EB rule: no cell to look at)
         const unsigned long long rowsmask = (nb >= 64) ? ~0ull : ((1ull << nb) - 1ull);
         const bool all_settled = PRUNE && !LONG && (skipmask & rowsmask) == rowsmask;
@@ -1277,9 +1279,15 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS
             const long np = nd < kPilotRows ? nd : kPilotRows;
             rows_here = a.part == 1 ? np : nd - np;
             if (!LONG && a.part == 1 && a.split) B = 1;
-            if (a.part == 3 && a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) {
-                rows_here = (long)*a.surv_count;
+            if (a.part == 3) {
+                // (the rows of the third pass: the listed ones, or all behind the pilot; its rows per wave follow from
+                // THAT count, as in cells_body)
+                if (a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) rows_here = (long)*a.surv_count;
+#ifdef TRX_BUG_EXIT_RULE
+                if (!LONG && a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) {        // (A/B build: round 4's first version)
+#else
                 if (!LONG) {
+#endif
                     B = batch_rows(rows_here, a.n_time, a.forced_B);
                     B = B < a.B ? B : a.B;
                 }
@@ -1974,7 +1982,11 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list) | row blocks |
     // launch header]
     const size_t list_doubles = scan_list_doubles(a.n);
+#ifdef TRX_NO_SPLIT
+    const bool split = false;              // (A/B builds: batches probe and finish in one kernel, as in round 3)
+#else
     const bool split = prune && !long_rows;
+#endif
     const size_t surv_doubles = split ? scan_list_doubles(a.n) : 0;
     const size_t scratch_bytes = (list_doubles + surv_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
