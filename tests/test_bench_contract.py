@@ -142,7 +142,7 @@ def test_host_path_of_a_rank_shrinks_with_the_world_size():
     shrink with the number of ranks, or eight GPUs wait for eight Pythons (round 3: every rank prepared and
     finished all 64 targets, 0.042 s per step whatever the world size).  Eight gloo ranks on this box's one GPU
     (the GPU time is meaningless there; the host path is what is measured, at N = 2e4 so that the one GPU the eight
-    processes share never pushes back on their queues) against one rank: at most a quarter."""
+    processes share never pushes back on their queues) against one rank: a quarter (measured; asserted below 0.30)."""
     one = _batch_line(1)
     eight = _batch_line(8, ("--debug-single-device",))
     h1 = one["config"]["per_rank"]["host_path_s"][0]
@@ -150,4 +150,5 @@ def test_host_path_of_a_rank_shrinks_with_the_world_size():
     print("\nhost path per step: 1 rank %.4f s, 8 ranks (max) %.4f s; enqueue %s" %
           (h1, h8, ["%.4f" % v for v in eight["config"]["per_rank"]["enqueue_s"]]))
     assert eight["n_gpus"] == 8 and len(eight["config"]["per_rank"]["host_path_s"]) == 8
-    assert h8 <= 0.25 * h1, (h1, h8)
+    # (measured 0.024-0.025 s against 0.105 s: 0.24; the gate leaves room for a busy box)
+    assert h8 <= 0.30 * h1 and h8 <= 0.035, (h1, h8)

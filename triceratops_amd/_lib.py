@@ -175,8 +175,10 @@ def compute_device():
 _upload_streams = {}
 # events of uploads that may still be in flight: every stream about to read library inputs waits for them ON THE
 # DEVICE (wait_uploads), the host never blocks
-_pending_uploads = []
+_pending_uploads = {}          # device index -> [(sequence number, event)], oldest first
 _pending_lock = threading.Lock()
+_upload_seq = 0
+_stream_seen = {}              # stream handle -> sequence number of the last upload it already waits for
 
 
 def dev(x, device=None):
@@ -188,6 +190,7 @@ def dev(x, device=None):
     the host: the upload leaves an event, the stream that is current here waits for it on the device, and so does
     every stream a library call is enqueued on while the event is pending (wait_uploads; cached tables are read
     by calls on other streams a few microseconds later)."""
+    global _upload_seq
     if isinstance(x, torch.Tensor):
         return x.to(device=device or "cuda", dtype=torch.float64).contiguous()
     a = np.ascontiguousarray(x, dtype=np.float64)
@@ -204,22 +207,31 @@ def dev(x, device=None):
     ev = torch.cuda.Event()
     ev.record(up)
     cur = torch.cuda.current_stream(d)
-    cur.wait_event(ev)
     t.record_stream(cur)      # the allocator must not hand the block out early
     with _pending_lock:
-        _pending_uploads.append(ev)
+        _upload_seq += 1
+        _pending_uploads.setdefault(d.index, []).append((_upload_seq, ev))
+    wait_uploads(cur)
     return t
 
 
 def wait_uploads(stream):
-    """`stream` waits (on the device) for every upload that has not completed yet"""
-    if not _pending_uploads:
+    """`stream` waits (on the device) for every upload that has not completed yet -- each of them once: the uploads
+    go up on ONE stream, in order, so waiting for the newest pending one covers all before it"""
+    pend = _pending_uploads.get(stream.device.index)
+    if not pend:
         return
+    key = stream.cuda_stream
     with _pending_lock:
-        live = [ev for ev in _pending_uploads if not ev.query()]
-        _pending_uploads[:] = live
-    for ev in live:
-        stream.wait_event(ev)
+        while pend and pend[0][1].query():
+            pend.pop(0)                                 # (completed: nobody needs to wait any more)
+        if not pend:
+            return
+        seq, ev = pend[-1]
+        if _stream_seen.get(key, 0) >= seq:
+            return
+        _stream_seen[key] = seq
+    stream.wait_event(ev)
 
 
 class upload_stream:
