@@ -374,13 +374,24 @@ __device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
                                                      // same operation everywhere, so that flat rows tie exactly)
         }
         acc = wave_sum(acc);
-        {
-            // the depth screen's table: lane i takes depth i of the grid
+        if (a.prune) {
+            // the depth screen's table (bounded evaluation only): lane i takes depth i of the grid; the light curve goes
+            // through LDS 512 points at a time (a lane reading flux[j] from memory in a serial loop waited ~200 cycles
+            // per point: 190 us on a 2000-point curve, on the critical path of every launch)
+            __shared__ double gbuf[512];
             const double dpt = (lane == 63) ? 1.0 : depth_grid(lane);
+            const double lim = 1.0 - dpt;
             double g = 0.0;
-            for (int j = 0; j < a.n_time; ++j) {
-                const double d = (1.0 - dpt) - a.flux[j];
-                if (d > 0.0) g = fma(d * d, a.rs2, g);
+            for (int j0 = 0; j0 < a.n_time; j0 += 512) {
+                const int m = (a.n_time - j0 < 512) ? (a.n_time - j0) : 512;
+                __syncthreads();
+                for (int j = lane; j < m; j += 64) gbuf[j] = a.flux[j0 + j];
+                __syncthreads();
+#pragma unroll 8
+                for (int j = 0; j < m; ++j) {
+                    const double d = lim - gbuf[j];
+                    g = fma(d > 0.0 ? d * d : 0.0, a.rs2, g);
+                }
             }
             hdr[kHdrGrid + lane] = dpt;
             hdr[kHdrG + lane] = g;
