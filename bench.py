@@ -676,7 +676,8 @@ def run_batch(ctx):
 
     def clear_counters():
         _lib.reset_stats()
-        _lib.check(_lib.lib().trx_skipped_rows(None, 1))          # clears the device counter
+        _lib.check(_lib.lib().trx_skipped_rows(None, 1))          # clears the device counters
+        _lib.check(_lib.lib().trx_pruned_rows(None, 1))
 
     elapsed, out, jobs, timing = batch_leg(ctx, args.tois, args.batch_n, args.n_time, args.steps, args.warmup,
                                            before_timed=clear_counters)
@@ -690,7 +691,12 @@ def run_batch(ctx):
     # rows whose light curve was not evaluated: lnL_EB_p's secondary-eclipse rule gives them +inf anyway
     _lib.check(_lib.lib().trx_skipped_rows(ctypes.byref(skipped), 1))
     stats["skipped_rows"] = int(skipped.value)
-    stats["cells"] -= stats["skipped_rows"] * args.n_time
+    # ... and the rows the bounded evaluation abandoned (settled from their constants or after ~16 probe cells: they are
+    # NOT counted as evaluated)
+    _lib.check(_lib.lib().trx_pruned_rows(ctypes.byref(skipped), 1))
+    stats["abandoned_rows"] = int(skipped.value)
+    stats["settled_cells"] = stats["cells"] - stats["skipped_rows"] * args.n_time
+    stats["cells"] -= (stats["skipped_rows"] + stats["abandoned_rows"]) * args.n_time
     fpps = [float(tg.FPP) for tg in out]         # of the last timed step (the targets are updated in place)
     n_scen = sum(len(tg.lnZ) for tg in out)
     # Not timed: one more step with events around every likelihood launch and sampled parameter blocks
@@ -701,7 +707,8 @@ def run_batch(ctx):
     _sync(ctx)
     trace, _lib.TRACE = _lib.TRACE, None
     # cells evaluated over all ranks
-    cells = torch.tensor([float(stats["cells"]), float(stats["rows"]), float(stats["skipped_rows"])], dtype=torch.float64,
+    cells = torch.tensor([float(stats["cells"]), float(stats["rows"]), float(stats["skipped_rows"]),
+                          float(stats["abandoned_rows"]), float(stats["settled_cells"])], dtype=torch.float64,
                          device="cpu" if ctx["debug_one"] or world == 1 else device)
     if world > 1:
         import torch.distributed as dist
@@ -726,7 +733,7 @@ def run_batch(ctx):
         tot += float(c.numel())
     evals_per_cell = ev_cells / max(tot, 1.0)
     # the traced launches skip the excluded rows too: scale by the evaluated share of the timed steps
-    evaluated_share = float(stats["cells"]) / max(float(stats["cells"]) + float(stats["skipped_rows"]) * args.n_time, 1.0)
+    evaluated_share = float(stats["settled_cells"]) / max(float(stats["settled_cells"]) + float(stats["skipped_rows"]) * args.n_time, 1.0)
     achieved = evals_per_cell * (F_ORBIT + F_MA) * cells_rank0 * evaluated_share / max(kern_s, 1e-12) / 1e12
     return {
         "metric": "light-curve-point x sample evals/sec", "value": float(cells[0]) / elapsed,
@@ -736,12 +743,14 @@ def run_batch(ctx):
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[3]: %d synthetic TOIs x 18 scenarios x N=%d draws, %d-point "
                                "light curves, calc_probs_many with device-side sampling, %d host thread(s) per rank, every lnZ_* call enqueued without a host sync on one of %d streams; "
-                               "value counts the (draw, time) cells that pass the geometry mask and are evaluated (the draws that lnL_EB_p's secondary-eclipse rule excludes are not: rows_not_evaluated_per_step)"
+                               "value counts the (draw, time) cells of the masked draws that are evaluated TO THE END: not the draws that lnL_EB_p's secondary-eclipse rule excludes (rows_not_evaluated_per_step), not the draws the bounded evaluation abandons (abandoned_rows_per_step: settled from their constants or after ~16 probe cells; with them: settled_cells_per_s)"
                                % (args.tois, args.batch_n, args.n_time, args.threads, __import__("triceratops_amd.sharding", fromlist=["streams"]).streams),
                    "tois": args.tois, "n_scenarios": n_scen, "N": args.batch_n, "n_time": args.n_time,
                    "evaluated_cells_per_step": float(cells[0]) / args.steps,
-                   "evaluated_rows_per_step": (float(cells[1]) - float(cells[2])) / args.steps,
+                   "evaluated_rows_per_step": (float(cells[1]) - float(cells[2]) - float(cells[3])) / args.steps,
                    "rows_not_evaluated_per_step": float(cells[2]) / args.steps,
+                   "abandoned_rows_per_step": float(cells[3]) / args.steps,
+                   "settled_cells_per_s": float(cells[4]) / elapsed,
                    "nominal_evals_per_s": nominal / elapsed,
                    "calc_probs_per_s": args.tois * args.steps / elapsed,
                    # host seconds per step and rank: unit lists, argument blocks + library calls of the rank's own units,
