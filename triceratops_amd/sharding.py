@@ -183,8 +183,8 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             table[offs[k]:offs[k] + rows[k]] = _record(res)
 
     def resolve():
-        for k, p in pending:
-            table[offs[k]:offs[k] + rows[k]] = _record(p.result())
+        for k, rec in _fused.records_to_rows(pending).items():
+            table[offs[k]:offs[k] + rows[k]] = rec
 
     on_device = _fused.threadable()
     if on_device:
