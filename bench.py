@@ -452,10 +452,8 @@ def run_grid(ctx):
     if not args.no_batch_leg:
         try:
             batch = batch_object(ctx)
-        except Exception as exc:                  # the grid line stands on its own
-            if world > 1:
-                raise
-            batch = {"error": repr(exc)}
+        except Exception as exc:                  # the grid line stands on its own (a failure here is the same on
+            batch = {"error": repr(exc)}          # every rank: nobody is left waiting in a collective)
     if rank != 0:
         return None
 

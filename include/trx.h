@@ -195,6 +195,10 @@ int trx_set_bounded_evaluation(int mode);
  *    for an evidence without prior: a row then holds its chi^2/2 or, if abandoned, a lower bound of it that
  *    exceeds the smallest chi^2/2 of the call by more than 90. */
 int trx_set_debug_bounded_lnl(int on);
+/*    trx_set_debug_poison(1) (tests): trx_scenario_enqueue / trx_star_enqueue fill the chi^2 arrays of a call with zeros
+ *    before its likelihood kernels run, so that a row no kernel writes shows as a perfect fit (lnZ and the best draw
+ *    jump) instead of as whatever the previous call on the stream left there. */
+int trx_set_debug_poison(int on);
 int trx_pruned_rows(unsigned long long* out, int reset);
 int trx_set_supersample_tiers(int on);
 int trx_set_stencil(int on);

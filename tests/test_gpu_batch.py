@@ -201,28 +201,39 @@ def test_bounded_evaluation_leaves_no_row_unwritten_whatever_the_row_count():
     batches leaves at once, by a rule that must use the SAME rows-per-wave as the pass itself (round 4's first
     version did not for 30 000-34 000 masked draws: tests/test_toi465.py::test_blend_bounded_evaluation_equals_the_
     full_one_on_one_and_six_streams is the run that showed it).  Here: N swept so that the masked counts of the 18
-    scenarios of two synthetic TOIs cross the thresholds of the rows-per-wave rule; bounded against unbounded: same
-    best draws, lnZ to 1e-12."""
+    scenarios of two synthetic TOIs cross the thresholds of the rows-per-wave rule, with the chi^2 arrays poisoned
+    before every call (trx_set_debug_poison: an unwritten row reads as a perfect fit); bounded against unbounded:
+    same best draws, lnZ to 1e-12.  (Verified to fail on a build with the old rule.)"""
     import triceratops_amd
     from triceratops_amd import sharding
     triceratops_amd.set_sampling("device")
     sharding.per_unit_seed = True
     L = _lib.lib()
+    L.trx_set_debug_poison(1)
     try:
+        rng = np.random.default_rng(3)
         for N in (60_000, 250_000, 290_000, 330_000, 370_000, 420_000, 480_000, 560_000):
-            got = {}
-            for mode in (0, 2):
-                L.trx_set_bounded_evaluation(mode)
-                np.random.seed(9)
-                torch.manual_seed(9)
-                got[mode] = triceratops_amd.calc_probs_many(_jobs(2, N))
-            for x, z in zip(got[0], got[2]):
-                fin = np.isfinite(x.lnZ)
-                assert np.array_equal(fin, np.isfinite(z.lnZ)), N
-                assert np.allclose(z.lnZ[fin], x.lnZ[fin], rtol=1e-12, atol=0), (N, np.abs(z.lnZ[fin] - x.lnZ[fin]).max())
-                for c in ("P_orb", "inc", "R_p", "ecc", "w", "M_EB", "R_EB"):
-                    assert np.array_equal(x.probs[c].values, z.probs[c].values, equal_nan=True), (N, c)
+            # with the TOIs' transits, and with pure noise in their place (no draw stands out: the pilot finds
+            # nothing to abandon and the third pass takes every row behind it -- the case that went wrong)
+            for signal in (True, False):
+                got = {}
+                for mode in (0, 2):
+                    L.trx_set_bounded_evaluation(mode)
+                    np.random.seed(9)
+                    torch.manual_seed(9)
+                    jobs = _jobs(2, N)
+                    if not signal:
+                        for _, kw in jobs:
+                            kw["flux_0"] = 1.0 + np.random.default_rng(4).normal(0.0, kw["flux_err_0"], kw["time"].size)
+                    got[mode] = triceratops_amd.calc_probs_many(jobs)
+                for x, z in zip(got[0], got[2]):
+                    fin = np.isfinite(x.lnZ)
+                    assert np.array_equal(fin, np.isfinite(z.lnZ)), (N, signal)
+                    assert np.allclose(z.lnZ[fin], x.lnZ[fin], rtol=1e-12, atol=0), (N, signal, np.abs(z.lnZ[fin] - x.lnZ[fin]).max())
+                    for c in ("P_orb", "inc", "R_p", "ecc", "w", "M_EB", "R_EB"):
+                        assert np.array_equal(x.probs[c].values, z.probs[c].values, equal_nan=True), (N, signal, c)
     finally:
+        L.trx_set_debug_poison(0)
         L.trx_set_bounded_evaluation(2)
         sharding.per_unit_seed = False
         triceratops_amd.set_sampling("numpy")

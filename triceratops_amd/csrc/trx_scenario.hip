@@ -29,12 +29,15 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/trx.h"
 #include "trx_device.hpp"
 #include "trx_internal.hpp"
 
 namespace {
 
+std::atomic<int> g_poison{0};         // trx_set_debug_poison (tests)
 
 #define TRXS_HIP(call)                                   \
     do {                                                 \
@@ -108,6 +111,8 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         return rc;
     };
     if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, st)) return bail(rc);
+    if (g_poison.load(std::memory_order_relaxed))          // tests: an unwritten row must show (include/trx.h)
+        for (int b = 0; b < nbr; ++b) TRXS_HIP(hipMemsetAsync(h[b], 0, sizeof(double) * (size_t)N, st));
     for (int b = 0; b < nbr; ++b) {
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
         const double* bounds = nullptr;
@@ -172,3 +177,9 @@ extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
 }
 
 extern "C" size_t trx_scenario_args_size(void) { return sizeof(trx_scenario_args); }
+
+extern "C" int trx_set_debug_poison(int on)
+{
+    g_poison = on ? 1 : 0;
+    return TRX_OK;
+}
