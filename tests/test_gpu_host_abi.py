@@ -121,3 +121,67 @@ def test_log_mean_exp_host_reference_vectors():
         assert out[0] == want if not np.isfinite(want) else abs(out[0] - want) < 1e-12
     out = np.empty(1)
     assert _L.trx_log_mean_exp_host(np.zeros(5), 5, 6, out) == _lib.ERR_NTOTAL   # ValueError in the reference
+
+
+def test_star_enqueue_equals_the_calls_one_by_one():
+    """trx_star_enqueue as INTEGRATION.md section C binds it: the lnZ_* calls of one star -- here a planet and a
+    binary scenario with their argument blocks built by triceratops_amd.fused -- handed to the library in ONE call on
+    two streams, against the same blocks through trx_scenario_evidence (one call each, synchronous): the same records
+    bit for bit (the draws depend on the seed in the block only)."""
+    import triceratops_amd
+    from helpers import gold
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    G = gold("lnz_cases.npz")
+    base = (G["time"], G["flux"], float(G["sigma"][0]), 3.3, 0.82, 0.8, 5100.0, 0.0)
+    triceratops_amd.set_sampling("device")
+    saved = fused.TABLE_ROWS
+    fused.TABLE_ROWS = 1
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.trx_star_enqueue.restype = ctypes.c_int
+    L.trx_star_enqueue.argtypes = [ctypes.POINTER(fused.ScenarioArgs), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+    L.trx_scenario_evidence.restype = ctypes.c_int
+    L.trx_scenario_evidence.argtypes = [ctypes.POINTER(fused.ScenarioArgs), ctypes.c_void_p]
+    try:
+        fused.begin_deferred(4)
+        torch.manual_seed(3)
+        pend = [ml.lnZ_TTP(*base, 200_000, True), ml.lnZ_TEB(*base, 200_000, True)]
+        blocks = [b[0] for b in fused._tls.batch]            # the argument blocks fused collected (not yet enqueued)
+        fused._tls.batch = []
+        assert len(blocks) == 2 and all(isinstance(p, fused.Pending) for p in pend)
+        n = len(blocks)
+        calls = (fused.ScenarioArgs * n)(*blocks)
+        recs = torch.zeros((n, fused.RECORD), dtype=torch.float64).pin_memory()
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        for s_ in streams:
+            _lib.wait_uploads(s_)                            # (the light curve went up asynchronously)
+        outs = (ctypes.c_void_p * n)(*[recs[i].data_ptr() for i in range(n)])
+        sts = (ctypes.c_void_p * n)(*[s_.cuda_stream for s_ in streams])
+        done = ctypes.c_int(0)
+        assert L.trx_star_enqueue(calls, n, outs, sts, ctypes.byref(done)) == 0, _L.trx_last_error()
+        assert done.value == n
+        for s_ in streams:
+            s_.synchronize()
+        together = recs.numpy().copy()
+        # ... and one by one, synchronously
+        for i, sa in enumerate(blocks):
+            out = np.zeros(2 * fused.SCENARIO_OUT)
+            flag = ctypes.c_int(-1)
+            sa.out = out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            sa.out_flag = ctypes.pointer(flag)
+            torch.cuda.synchronize()
+            assert L.trx_scenario_evidence(ctypes.byref(sa), None) == 0, _L.trx_last_error()
+            nbr = 1 if sa.draw.contents.planet else 2
+            assert flag.value == 0 and together[i, 2 * fused.SCENARIO_OUT] == 0.0
+            assert np.array_equal(out[:nbr * fused.SCENARIO_OUT], together[i, :nbr * fused.SCENARIO_OUT], equal_nan=True)
+            ncol = 11 if nbr == 1 else 14
+            assert np.isfinite(out[ncol]) and out[ncol + 1] > 1000          # lnZ, masked draws
+        # argument checks: a null block list is refused, an empty one is a no-op
+        assert L.trx_star_enqueue(None, 1, outs, sts, None) != 0
+        assert L.trx_star_enqueue(calls, 0, outs, sts, ctypes.byref(done)) == 0 and done.value == 0
+    finally:
+        fused._tls.batch = []
+        fused.end_deferred()
+        fused.TABLE_ROWS = saved
+        triceratops_amd.set_sampling("numpy")
