@@ -185,7 +185,7 @@ int trx_set_rows_per_wave(int rows);
  *    the largest) -- from its constants alone when the model can never be as deep as the data (a lower bound of
  *    chi^2 that depends on the light curve and the model's largest possible flux deficit only), else from its
  *    chi^2 over ~16 probe cells and every cell outside its transit window.  Short light curves (batches of rows per
- *    wave) take it in passes: the first 4096 rows to the end (they seed the bounds and decide whether probing pays:
+ *    wave) take it in passes: the first 2048 rows to the end (they seed the bounds and decide whether probing pays:
  *    it does when >= 90 % of them lie 150 above the best), a probe pass over the rest, and the rows it leaves alive
  *    -- compacted across workgroups -- to the end.  lnZ agrees to rounding, the best draw is the same, results
  *    repeat bit for bit from run to run.  trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the

@@ -267,7 +267,10 @@ __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.
 // -- they give the launch's running bounds their first values, so that the bound bites from the first wave
 // of the main launch on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
 // (header slot kHdrProbe) when few pilot rows lie far above the pilot's best.
-constexpr long kPilotRows = 4096;
+#ifndef TRX_PILOT_ROWS
+#define TRX_PILOT_ROWS 2048
+#endif
+constexpr long kPilotRows = TRX_PILOT_ROWS;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
 // Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
@@ -784,8 +787,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             B = batch_rows(row1 - row0, n_time, a.forced_B);
             B = B < Bl ? B : Bl;
         }
-        // the pilot's 4096 rows one per wave: six per wave are 683 waves on 256 CUs, each a serial chain of a whole
-        // batch -- 108 us before the launch proper could start (TOI-465.01, 100 points); 4096 short waves fill the chip
+        // the pilot's rows one per wave: six per wave were 683 waves on 256 CUs for 4096 rows, each a serial chain of a
+        // whole batch -- 108 us before the launch proper could start (TOI-465.01, 100 points); short waves fill the chip
         if (!LONG && a.part == 1 && a.split) B = 1;
         nbatch = (row1 - row0 + B - 1) / B;
     }
