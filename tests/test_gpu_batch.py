@@ -237,3 +237,39 @@ def test_bounded_evaluation_leaves_no_row_unwritten_whatever_the_row_count():
         L.trx_set_bounded_evaluation(2)
         sharding.per_unit_seed = False
         triceratops_amd.set_sampling("numpy")
+
+
+@pytest.mark.parametrize("n_time", [20, 40, 47, 48, 63])
+def test_bounded_evaluation_on_very_short_light_curves(n_time):
+    """Below 48 stamps there is nothing to probe and the launch is evaluated in full.  Until profiles/fuzz_bounded.py
+    ran, such a launch still went through the passes: the probe pass declined (stride 1) while the third pass waited
+    for the probe pass's list, and the rows behind the pilot were never written when the pilot's verdict was
+    "probing pays" (every n_time < 48 with a clear signal).  Poisoned chi^2 arrays, bounded against full, both sides
+    of the threshold.  (Fails on the library of the commit before.)"""
+    import triceratops_amd
+    from triceratops_amd import sharding
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    L = _lib.lib()
+    L.trx_set_debug_poison(1)
+    try:
+        got = {}
+        for mode in (0, 2):
+            L.trx_set_bounded_evaluation(mode)
+            np.random.seed(5)
+            torch.manual_seed(5)
+            jobs = synth.toi_jobs(2, n_time=n_time, N=130_000, seed=synth.SEED + 9,
+                                  trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"),
+                                  contrast_curve_file=os.path.join(GOLD, "contrast_curve_synth.csv"))
+            got[mode] = triceratops_amd.calc_probs_many(jobs)
+        for x, z in zip(got[0], got[2]):
+            fin = np.isfinite(x.lnZ)
+            assert np.array_equal(fin, np.isfinite(z.lnZ))
+            assert np.allclose(z.lnZ[fin], x.lnZ[fin], rtol=1e-12, atol=0), np.abs(z.lnZ[fin] - x.lnZ[fin]).max()
+            for c in ("P_orb", "inc", "R_p", "ecc", "w", "M_EB", "R_EB"):
+                assert np.array_equal(x.probs[c].values, z.probs[c].values, equal_nan=True), c
+    finally:
+        L.trx_set_debug_poison(0)
+        L.trx_set_bounded_evaluation(2)
+        sharding.per_unit_seed = False
+        triceratops_amd.set_sampling("numpy")

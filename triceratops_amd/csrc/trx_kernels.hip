@@ -122,6 +122,13 @@ __device__ __forceinline__ double uniform(double v)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+__device__ __forceinline__ long uniform_long(long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long)(((unsigned long long)hi << 32) | lo);
+}
+
 // number of set bits of `m` below this lane
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
@@ -237,6 +244,72 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
     return B;
 }
 
+// The batches of a launch, dealt to the XCDs and tapered towards the end of the launch.  Workgroups are dispatched in
+// blockIdx order, round the 8 XCDs; an XCD's waves take consecutive positions of its share of the rows (whose blocks
+// then stay in that XCD's L2).  The chip holds 5120 waves of the batched variant (5 per SIMD), a launch of 10^5 rows
+// at six rows per wave is 3.3 rounds over those slots, and the slots that finish their last batch first idle until
+// the last wave of the launch is done: 12 % of the launch (300 000 rows run at 2.35e10 cells/s where 100 000 run
+// at 2.04e10, profiles/r04_f_cells_batch_sweep.txt).  So the last positions of every XCD take fewer rows: half a
+// slot's worth of positions at half the rows per wave, then as many at a quarter -- the work still out when the slots
+// start to drain comes in pieces a quarter the size (100 points, 10^5 rows: 2.04e10 -> 2.14e10 cells/s).
+// Positions 0 .. P-1 per XCD; one rule for the host (grid), the workgroup exit test and the batch loop.  Not for the
+// passes of the bounded evaluation (`taper` false): a probe pass has so little to do per row that more, smaller
+// waves cost more than the tail they fill (+10 % on a 200-point call, profiles/r04_ab_taper.txt).
+#ifndef TRX_TAPER_SLOTS
+#define TRX_TAPER_SLOTS 320
+#endif
+struct BatchPlan {
+    long R;            // rows per XCD (a multiple of B)
+    long ra, rb;       // rows of the XCD's share at B rows per wave, then at B2 (the rest at B3)
+    long pa, pb, P;    // positions: [0, pa) B rows, [pa, pa + pb) B2 rows, [pa + pb, P) B3 rows
+    int B, B2, B3;
+};
+__host__ __device__ inline BatchPlan batch_plan(long rows, int B, bool taper = true)
+{
+    BatchPlan p;
+    p.B = B;
+    p.B2 = (B + 1) / 2;
+    p.B3 = B / 4 > 0 ? B / 4 : 1;
+    const long nb = (rows + B - 1) / B;
+    p.R = ((nb + 7) / 8) * B;
+    long rb = 0, rc = 0;
+#ifndef TRX_NO_TAPER
+    if (B > 1 && taper) {
+        // an XCD holds 640 waves of this kernel (32 CUs x 4 SIMDs x 5); measured per 18 launches of 10^5 rows x 100
+        // points: no taper 8.86-8.96 ms, 2560 positions per tier 8.85-8.90, 1280 8.67-8.74, 640 8.51-8.55, 320 8.49-8.52
+        // (profiles/r04_ab_taper.txt)
+        constexpr long kSlotsPerXcd = TRX_TAPER_SLOTS;
+        rc = kSlotsPerXcd * p.B3;
+        if (rc > (3 * p.R) / 20) rc = (3 * p.R) / 20;
+        rb = kSlotsPerXcd * p.B2;
+        if (rb > (3 * p.R) / 10) rb = (3 * p.R) / 10;
+        rc -= rc % B;
+        rb -= rb % B;
+    }
+#endif
+    p.ra = p.R - rb - rc;
+    p.rb = rb;
+    p.pa = p.ra / B;
+    p.pb = (rb + p.B2 - 1) / p.B2;
+    p.P = p.pa + p.pb + (rc + p.B3 - 1) / p.B3;
+    return p;
+}
+// position `pos` of XCD `xcd`: first row (relative to the launch's first) and the rows of the batch there
+__host__ __device__ inline void batch_at(const BatchPlan& p, long xcd, long pos, long& off, int& rows)
+{
+    if (pos < p.pa) { off = pos * p.B; rows = p.B; }
+    else if (pos < p.pa + p.pb) {
+        off = p.ra + (pos - p.pa) * p.B2;
+        const long left = p.ra + p.rb - off;
+        rows = (int)(left < p.B2 ? left : p.B2);
+    } else {
+        off = p.ra + p.rb + (pos - p.pa - p.pb) * p.B3;
+        const long left = p.R - off;
+        rows = (int)(left < p.B3 ? left : p.B3);
+    }
+    off += xcd * p.R;
+}
+
 // Launch header behind the row blocks in scratch: [0] chi^2 of the flat model, [1] stencil radius
 // (0 = no stencil), [2 .. 2 + 2 kStM] stencil weights.
 //
@@ -271,6 +344,11 @@ __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.
 #define TRX_PILOT_ROWS 2048
 #endif
 constexpr long kPilotRows = TRX_PILOT_ROWS;
+// Light curves shorter than this are evaluated in full: with fewer than three stamps per probe cell there is nothing to
+// probe.  (Until the fuzz of profiles/fuzz_bounded.py such a launch still ran the passes with a probe stride of 1: the
+// probe pass then declined to probe while the third pass waited for its list -- rows behind the pilot were never
+// written whenever the pilot's verdict was "probing pays".  tests/test_gpu_bounded.py::test_very_short_light_curves...)
+constexpr int kProbeMinPoints = 48;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
 // Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
@@ -709,7 +787,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     static_assert(!PRUNE || (MODE == MODE_LNL && !ST), "bounded evaluation: likelihood mode, no stencil");
     extern __shared__ double lds_all[];
     constexpr int W = cells_waves(LONG);
-    const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // (scalar: so is all that follows from it)
     // shared by the workgroup's waves: node tables, atan constants, (short curves) the light curve
     double* tier_xw = lds_all;
     double* atab = tier_xw + 2 * kTiers * kTierMaxNodes;             // atan_pos_tab's range constants
@@ -746,7 +824,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const float inv_nt = 1.0f / (float)n_time;
     // the row count: known to the host, or left on the device by an earlier kernel of the stream (the
     // rows per wave and the batch count then follow here, by the host's rule)
-    long n = a.n, nbatch = a.nbatch;
+    long n = a.n, nbatch = a.nbatch;          // (nbatch: one row per wave only; batches follow batch_plan)
     int B = Bl;
     if (a.n_dev) {
         n = *a.n_dev;
@@ -796,16 +874,29 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // does the pass over the listed rows)
     const bool probing = PRUNE && a.pstride > 1 && (a.part == 0 || a.part == 2) && hdr[kHdrProbe] != 0.0;
     if (PRUNE && a.split && a.part == 2 && !probing) return;       // nothing to probe: part 3 takes the rows directly
-    const long per_xcd = (nbatch + 7) / 8;
+    // (one row per wave: nothing to taper -- an XCD's waves take consecutive rows of its eighth)
+    // (a row count read from the device is wave-uniform, which the compiler cannot know: the plan belongs in scalar
+    // registers)
+    const BatchPlan bp = LONG ? BatchPlan{} : batch_plan(uniform_long(row1 - row0), __builtin_amdgcn_readfirstlane(B), !PRUNE);
+    const long positions = LONG ? (nbatch + 7) / 8 : bp.P;
     // workgroups go round the 8 XCDs (blockIdx & 7) and an XCD's waves take consecutive batches of its share
     // of the rows, whose blocks then stay in that XCD's L2
     const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
     unsigned n_skipped = 0, n_pruned = 0;          // this wave's rows for trx_skipped_rows / trx_pruned_rows
-    for (long v = v0; v < 8 * per_xcd; v += (long)gridDim.x * W) {
-        const long batch = (v & 7) * per_xcd + (v >> 3);
-        if ((v >> 3) >= per_xcd || batch >= nbatch) continue;
-        const long base = row0 + batch * B;
-        const int nb = (int)((row1 - base < B) ? (row1 - base) : B);
+    for (long v = v0; v < 8 * positions; v += (long)gridDim.x * W) {
+        long base;
+        int nb;
+        if (LONG) {
+            const long batch = (v & 7) * positions + (v >> 3);
+            if ((v >> 3) >= positions || batch >= nbatch) continue;
+            base = row0 + batch * B;
+            nb = (int)((row1 - base < B) ? (row1 - base) : B);
+        } else {
+            batch_at(bp, v & 7, v >> 3, base, nb);
+            base += row0;
+            if (base >= row1) continue;
+            if (row1 - base < nb) nb = (int)(row1 - base);
+        }
         TRX_TICK(t_pro);
         // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
         long rowid = base + lane;          // the row of lane `lane` of the batch (lanes < nb)
@@ -1308,7 +1399,9 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS
             }
         }
         // (the first batch index of this workgroup's first wave, see cells_body)
-        if ((long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * cells_waves(LONG)) >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
+        if (LONG) {
+            if ((long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * cells_waves(LONG)) >= 8 * (((rows_here + B - 1) / B + 7) / 8)) return;
+        } else if ((long)(blockIdx.x >> 3) * cells_waves(LONG) >= batch_plan(rows_here, B, !PRUNE).P) return;
     }
     double st_radius = 0.0;
     if (LONG && (ST ? a.use_stencil != 0 : a.use_stencil == 1)) {
@@ -1860,7 +1953,8 @@ thread_local bool t_last_pruned = false;
 // of pilot rows 150 above the best overstates what the probe cells can prove: 0.8 for TOI-411.02, 0.995 and more for
 // the cases that gain -- hence 90 %).
 __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
-                                                          double* __restrict__ rowc, unsigned long long* __restrict__ surv_count)
+                                                          double* __restrict__ rowc, unsigned long long* __restrict__ surv_count,
+                                                          int pstride)
 {
     if (threadIdx.x == 0 && surv_count) *surv_count = 0ull;
     __shared__ double smin[4];
@@ -1890,7 +1984,8 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
     if (threadIdx.x == 0) {
         far = sfar[0] + sfar[1] + sfar[2] + sfar[3];
         fin = sfin[0] + sfin[1] + sfin[2] + sfin[3];
-        rowc[n * kRowDoubles + kHdrProbe] = (fin > 0 && 100L * far >= 90L * fin) ? 1.0 : 0.0;
+        // (the same condition as cells_body's `probing`: a stride of 1 leaves nothing to probe)
+        rowc[n * kRowDoubles + kHdrProbe] = (pstride > 1 && fin > 0 && 100L * far >= 90L * fin) ? 1.0 : 0.0;
     }
 }
 
@@ -1921,7 +2016,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.rs2 = 1.0 / a.s2;
     a.dS = (double)a.S;
     a.rS = 1.0 / a.dS;
-    a.nbatch = (a.n + a.B - 1) / a.B;
+    a.nbatch = 8 * batch_plan(a.n, a.B).P;          // wave positions of the launch (batch_plan)
     const long max_grid = 1L << 20;
     // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
     // keeps 2-11 % of them, so the grid takes a quarter of the bound -- blocks
@@ -1948,9 +2043,10 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // a forced rows-per-wave or a raised trx_set_cell_packing_below can exceed it: those launches evaluate in full)
     const bool prune = MODE == MODE_LNL && a.prune && g_step.load(std::memory_order_relaxed) &&
                        (prune_mode == 2 || (prune_mode == 1 && long_rows)) &&
-                       (long_rows || (long)a.B * a.n_time <= (long)kCellsWindowBatch);
+                       (long_rows || (long)a.B * a.n_time <= (long)kCellsWindowBatch) &&
+                       a.n_time >= kProbeMinPoints;
     a.prune = prune ? 1 : 0;
-    a.pstride = prune ? (a.n_time >= 48 ? a.n_time / 16 : 1) : 1;
+    a.pstride = prune ? a.n_time / 16 : 1;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
@@ -2044,7 +2140,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
         launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
-            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count);
+            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count, a.pstride);
             ap.part = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
             if (split) {
