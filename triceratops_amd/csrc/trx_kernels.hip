@@ -233,14 +233,17 @@ constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pas
 // (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 -- larger
 // batches fill the chunks better, but the batches of a launch differ in work (rows with long transits),
 // and with fewer, longer waves the last round over the chip's wave slots leaves more of them idle.
-// Few rows: fill the chip's 4096 wave slots first.  `n` < 0: the largest value any n gives (LDS layout).
+// Few rows: fewer per wave, down to ~3200 waves a launch (with the tapered plan below the best rows per wave at 100
+// points are 3 for 10 000 rows and 6 from 20 000 on, profiles/r04_few_rows_sweep.txt; until then the rule asked for
+// 10 000 waves and 30 000 rows ran 6 % slower at 3 per wave than at 4-6).  `n` < 0: the largest value any n gives
+// (LDS layout).
 __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
 {
     int B = (640 + n_time / 2) / (n_time > 0 ? n_time : 1);
     B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
     if (forced > 0) return forced > kCellsMaxRows ? kCellsMaxRows : forced;
     if (n >= 0)
-        while (B > 1 && n / B < 10000) B = (B + 1) / 2;
+        while (B > 1 && n / B < 3200) B = (B + 1) / 2;
     return B;
 }
 
