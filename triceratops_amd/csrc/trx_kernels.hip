@@ -2025,16 +2025,16 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // keeps 2-11 % of them, so the grid takes a quarter of the bound -- blocks
     // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
     // (a workgroup is cells_waves() waves, each with its own batches; a multiple of 8 workgroups: one per XCD)
-    auto grid_for = [&](long batches, bool long_variant) -> unsigned {
+    auto grid_for = [&](long batches, bool long_variant, long cap) -> unsigned {
         if (a.n_dev) {
             batches = (batches + 3) / 4;
             batches = batches < 4096 ? 4096 : batches;
         }
         const long groups = (batches + cells_waves(long_variant) - 1) / cells_waves(long_variant);
-        const long want = 8 * ((groups + 7) / 8);
+        long want = 8 * ((groups + 7) / 8);
+        if (cap > 0 && want > cap) want = cap;
         return (unsigned)(want < max_grid ? want : max_grid);
     };
-    const unsigned grid = grid_for(a.nbatch, long_rows);
     a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
     // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
@@ -2131,7 +2131,21 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
     const bool step = g_step.load(std::memory_order_relaxed) != 0;
-    const unsigned g2 = long_rows ? grid_for(a.n, true) : grid;
+    // Workgroups beyond the batches are not free: ~2.4 ns each to dispatch and leave, and while they are dealt out they
+    // hold back the workgroups of the other streams' kernels.  A grid sized for the upper bound of a row count that
+    // only the device knows is mostly such workgroups (a quarter of the bound: 10 000 of them per launch at N = 10^6,
+    // three launches per call; 250 000 one-wave workgroups with one row per wave).  So the grid is capped and the waves
+    // stride over the positions beyond it: one workgroup per slot of the chip (1280) for the passes of the bounded
+    // evaluation, four per slot for a full evaluation -- which loses nothing against one workgroup per four batches
+    // when a launch runs alone (static striding below that does: +6 % at two per slot, +18 % at one) --, four waves
+    // per slot with one row per wave.  Measured in one job each (profiles/r04_ab_cap.txt): 64 TOIs on three streams
+    // 0.265 -> 0.185 s per step (four streams 0.175), the 75-scenario calc_probs 22.0 -> 20.4 ms, 15 scenarios
+    // 3.8 -> 3.1 ms, Kepler-10b 12.0 -> 10.6 ms.  (Environment: experiments only.)
+    static const long cap_probe = getenv("TRX_GRID_CAP") ? atol(getenv("TRX_GRID_CAP")) : 1280;
+    static const long cap_plain = getenv("TRX_GRID_CAP_PLAIN") ? atol(getenv("TRX_GRID_CAP_PLAIN")) : 5120;
+    static const long cap_long = getenv("TRX_GRID_CAP_LONG") ? atol(getenv("TRX_GRID_CAP_LONG")) : 16384;
+    const long cap = (a.n_dev || prune) ? (long_rows ? cap_long : (prune ? cap_probe : cap_plain)) : 0;
+    const unsigned g2 = grid_for(long_rows ? a.n : a.nbatch, long_rows, cap);
     t_last_rowc = a.rowc;
     t_last_pruned = prune;
     if (prune) {

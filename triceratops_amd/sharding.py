@@ -38,11 +38,11 @@ threads = 1
 # is enqueued without any host synchronisation (trx_scenario_enqueue), so the thread enqueues every
 # unit, the streams overlap the small kernels of one call with the large ones of another, and the
 # results are read after one wait.  The library keeps ~0.3 GB of scratch per stream at N = 1e6.
-# Six: a call is a chain of dependent launches, most of them small, so a stream keeps the chip busy only while its
+# Four: a call is a chain of dependent launches, most of them small, so a stream keeps the chip busy only while its
 # likelihood kernel runs, and the other streams fill those gaps.  64 TOIs x 18 scenarios, the stream counts visited in
-# turn over seven rounds (profiles/batch_timing.py, profiles/r04_f_batch_timing.txt): 0.40 s a step on one stream, 0.31
-# on two, 0.34 on three, 0.32 on four, 0.30 on six and on eight.
-streams = int(os.environ.get("TRX_STREAMS", "6"))
+# turn over seven rounds (profiles/batch_timing.py, profiles/r04_g_batch_timing.txt): 0.185 s a step on three streams,
+# 0.175 on four, 0.192 on six.
+streams = int(os.environ.get("TRX_STREAMS", "4"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
 # (+ the collective, and -- calc_probs_many -- the unit lists and the result tables of all targets)
 timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "finish_s": 0.0}
