@@ -3,7 +3,7 @@ against the full evaluation (mode 0) on the same seeds, with the chi^2 arrays po
 (trx_set_debug_poison: a row no pass wrote reads as a perfect fit).  Random light-curve length (batched and
 one-row-per-wave variants, both sides of every threshold), time span, noise, signal strength (none / weak / strong /
 a signal deeper than any model can be), N (so that the masked counts cross the rows-per-wave rules), stream count.
-Same best draws, lnZ to 1e-12 of each other, FPP / NFPP to 1e-12 absolute.
+Same best draws, |lnZ difference| <= 1e-12 max(1, |lnZ|), FPP / NFPP to 1e-12 + 4 x the largest lnZ difference.
     python profiles/fuzz_bounded.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,7 +61,7 @@ while time.time() - t_start < budget:
         for x, z in zip(got[0], got[2]):
             fin = np.isfinite(x.lnZ)
             ok = np.array_equal(fin, np.isfinite(z.lnZ))
-            d = float(np.abs(z.lnZ[fin] / x.lnZ[fin] - 1.0).max()) if ok and fin.any() else 0.0
+            d = float((np.abs(z.lnZ[fin] - x.lnZ[fin]) / np.maximum(1.0, np.abs(x.lnZ[fin]))).max()) if ok and fin.any() else 0.0
             dabs = float(np.abs(z.lnZ[fin] - x.lnZ[fin]).max()) if ok and fin.any() else 0.0
             worst = max(worst, d)
             why = "" if ok else "finite pattern "
@@ -82,7 +82,7 @@ while time.time() - t_start < budget:
     stats[kind] = stats.get(kind, 0) + 1
 L.trx_set_debug_poison(0)
 L.trx_set_bounded_evaluation(2)
-print("fuzz_bounded seed %d: %d configurations in %.0f s (%s), worst relative lnZ difference %.2e, %d failures"
+print("fuzz_bounded seed %d: %d configurations in %.0f s (%s), worst lnZ difference relative to max(1, |lnZ|) %.2e, %d failures"
       % (seed, n_cfg, time.time() - t_start, ", ".join("%s %d" % kv for kv in sorted(stats.items())), worst, len(fails)))
 import collections
 by = collections.Counter((f[0], f[2], "exception" if f[7].startswith("EXC") else f[7].split("(")[0]) for f in fails)

@@ -37,3 +37,5 @@ for mode in (0, 2, 2):
 for x, z in zip(got[0], got[2]):
     print(x.probs.assign(lnZ0=x.lnZ, lnZ2=z.lnZ)[["scenario", "lnZ0", "lnZ2"]].to_string())
     print("FPP", x.FPP, z.FPP)
+for x, z in zip(got[0], got[2]):
+    print("lnZ differences:", np.array2string(z.lnZ - x.lnZ, precision=3))
