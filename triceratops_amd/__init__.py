@@ -6,6 +6,15 @@ Compute runs in hand-written HIP kernels behind the C ABI of include/trx.h (libt
 """
 __version__ = "0.2.0"
 
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise, and two streams that
+# share a queue serialise: calc_probs on three streams then runs slower than on two (64 TOIs: 0.223 s a step on two
+# streams, 0.263 on three, 0.226 on four, 0.190 on six; with 8 queues 0.224 / 0.185 / 0.172 / 0.180 --
+# profiles/r04_hw_queues.txt).  Read by the runtime when it initialises (the first HIP call of the process), so it
+# has to be in the environment before that; a value the user has set is left alone.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def set_sampling(mode):
     """'device' (default): the whole scenario on the GPU, the draw kernel's own Philox numbers (seeded through
