@@ -188,8 +188,9 @@ int trx_set_rows_per_wave(int rows);
  *    wave) take it in passes: the first 2048 rows to the end (they seed the bounds and decide whether probing pays:
  *    it does when >= 90 % of them lie 150 above the best), a probe pass over the rest, and the rows it leaves alive
  *    -- compacted across workgroups -- to the end.  lnZ agrees to rounding, the best draw is the same, results
- *    repeat bit for bit from run to run.  trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the
- *    device).  The per-row entry points (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
+ *    repeat bit for bit from run to run.  Light curves of fewer than 48 points are always evaluated in full.
+ *    trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the device).  The per-row entry points
+ *    (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
 int trx_set_bounded_evaluation(int mode);
 /*    trx_set_debug_bounded_lnl(1) (tests): trx_lnl_batch / trx_lnz_scenario treat their rows the same way, as
  *    for an evidence without prior: a row then holds its chi^2/2 or, if abandoned, a lower bound of it that

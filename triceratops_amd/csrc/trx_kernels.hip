@@ -252,7 +252,7 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced)
 // then stay in that XCD's L2).  The chip holds 5120 waves of the batched variant (5 per SIMD), a launch of 10^5 rows
 // at six rows per wave is 3.3 rounds over those slots, and the slots that finish their last batch first idle until
 // the last wave of the launch is done: 12 % of the launch (300 000 rows run at 2.35e10 cells/s where 100 000 run
-// at 2.04e10, profiles/r04_f_cells_batch_sweep.txt).  So the last positions of every XCD take fewer rows: half a
+// at 2.04e10: the untapered sweeps of profiles/r04_ab_taper.txt).  So the last positions of every XCD take fewer rows: half a
 // slot's worth of positions at half the rows per wave, then as many at a quarter -- the work still out when the slots
 // start to drain comes in pieces a quarter the size (100 points, 10^5 rows: 2.04e10 -> 2.14e10 cells/s).
 // Positions 0 .. P-1 per XCD; one rule for the host (grid), the workgroup exit test and the batch loop.  Not for the
