@@ -273,3 +273,42 @@ def test_bounded_evaluation_on_very_short_light_curves(n_time):
         L.trx_set_bounded_evaluation(2)
         sharding.per_unit_seed = False
         triceratops_amd.set_sampling("numpy")
+
+
+def test_launches_whose_batches_exceed_the_grid_caps():
+    """cells_kernel's grids are capped when the row count lives on the device (1280 workgroups for the passes of the
+    bounded evaluation, 5120 for a full evaluation: launch_cells) and the waves stride over the batches beyond the
+    cap.  N = 3e6 draws on a 100-point light curve leaves ~3e5 masked rows = 12 000 workgroups' worth of batches,
+    beyond both caps: the native call without the bounded evaluation against the torch-operator chain (whose
+    launches know their row count on the host: exact grids, no cap) bit for bit, the bounded one to 1e-12 with the
+    same best draws."""
+    import triceratops_amd
+    from triceratops_amd import fused, sharding
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    L = _lib.lib()
+    L.trx_set_debug_poison(1)
+    try:
+        got = {}
+        for mode in ("native", "native-unbounded", "torch"):
+            fused.NATIVE = mode != "torch"
+            L.trx_set_bounded_evaluation(0 if mode == "native-unbounded" else 2)
+            np.random.seed(6)
+            torch.manual_seed(6)
+            jobs = synth.toi_jobs(1, n_time=100, N=3_000_000, seed=synth.SEED + 5,
+                                  trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"), contrast_curve_file=None)
+            got[mode] = triceratops_amd.calc_probs_many(jobs)[0]
+        x, y, z = got["native-unbounded"], got["torch"], got["native"]
+        assert np.array_equal(x.lnZ, y.lnZ, equal_nan=True) and x.FPP == y.FPP
+        fin = np.isfinite(y.lnZ)
+        assert np.array_equal(fin, np.isfinite(z.lnZ))
+        assert np.allclose(z.lnZ[fin], y.lnZ[fin], rtol=1e-12, atol=0)
+        for c in ("P_orb", "inc", "R_p", "ecc", "w", "M_EB", "R_EB"):
+            assert np.array_equal(x.probs[c].values, y.probs[c].values, equal_nan=True), c
+            assert np.array_equal(z.probs[c].values, y.probs[c].values, equal_nan=True), c
+    finally:
+        fused.NATIVE = True
+        L.trx_set_debug_poison(0)
+        L.trx_set_bounded_evaluation(2)
+        sharding.per_unit_seed = False
+        triceratops_amd.set_sampling("numpy")
