@@ -115,7 +115,10 @@ __device__ __forceinline__ double random_ecc_beta(unsigned long long seed, long 
 }
 
 // ---- tables staged in LDS ------------------------------------------------------------------
-constexpr int kDrawChunk = 1024;        // draws a workgroup pre-tests before it regroups the candidates
+#ifndef TRX_DRAW_CHUNK
+#define TRX_DRAW_CHUNK 1024
+#endif
+constexpr int kDrawChunk = TRX_DRAW_CHUNK;        // draws a workgroup pre-tests before it regroups the candidates
 
 struct Tables {
     double spl[TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES];

@@ -59,7 +59,14 @@ int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, lon
 
 // trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
 // [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)
-constexpr int kDrawMaxGroups = 2048;
+// (1024 workgroups of 256 threads for N = 1e6, ~1000 draws each: of a chunk of 1024 pre-tested draws ~100 go on to the
+// fp64 mask, on 256 lanes; with 2048 workgroups of ~500 draws the fp64 pass ran on a fifth of its lanes -- draw_kernel<2>
+// 43.5 -> 39.8 us per call, compact_fill_kernel 33.6 -> 38.8 (half as many one-wave workgroups), 64-TOI step 0.173 ->
+// 0.166 s, 75 scenarios 19.0 -> 18.3 ms: profiles/r04_ab_draw.txt; 512 workgroups lose)
+#ifndef TRX_DRAW_GROUPS
+#define TRX_DRAW_GROUPS 1024
+#endif
+constexpr int kDrawMaxGroups = TRX_DRAW_GROUPS;
 int draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* groups_out, hipStream_t st);
 // behind it: the ordered lists of the draws that passed a mask (idx0 / idx1, their lengths in n_dev[0 / 1]) and the
 // columns and the prior of those draws (and of draw 0)
