@@ -107,6 +107,8 @@ struct RowsArgs {
     int split;
     int* surv_list;                      // split: the rows the probe pass left alive (any order) ...
     unsigned long long* surv_count;      // ... and their number (zeroed by pilot_stats_kernel)
+    int* probe_list;                     // split: the rows behind the pilot that the depth screen did not settle
+    unsigned long long* probe_count;     // (depth_screen_kernel; zeroed by pilot_stats_kernel)
     TierTable tiers;
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
@@ -860,10 +862,14 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     if (PRUNE && a.part) {
         const long np = n < kPilotRows ? n : kPilotRows;
         if (a.part == 1) row1 = np;
-        else if (a.part == 2) row0 = np;
+        else if (a.part == 2) {
+            // (split: the probe pass takes the rows depth_screen_kernel listed; when nothing is probed it leaves below)
+            if (a.split && hdr[kHdrProbe] != 0.0) { rlist = a.probe_list; row1 = (long)*a.probe_count; }
+            else row0 = np;
+        }
         else if (hdr[kHdrProbe] != 0.0) { rlist = a.surv_list; row1 = (long)*a.surv_count; }
         else row0 = np;                // (no probe pass was run: every row behind the pilot, as they come)
-        if (!LONG && a.part == 3) {
+        if (!LONG && (a.part == 3 || (a.part == 2 && rlist))) {
             // few rows left: fewer per wave, by the host's rule for a launch of that many rows
             B = batch_rows(row1 - row0, n_time, a.forced_B);
             B = B < Bl ? B : Bl;
@@ -978,8 +984,9 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             }
         };
 #ifndef TRX_NO_DEPTH_SCREEN
-        if (PRUNE && probing) {
+        if (PRUNE && probing && !a.split) {
             // depth screen: a row too shallow (diluted) for the data is settled by its constants alone
+            // (batches of short light curves: depth_screen_kernel did it before this launch and listed the rest)
             const double hmin_run = __hip_atomic_load(&hdr[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double xmax_run = __hip_atomic_load(&hdr[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool shallow = false;
@@ -1387,6 +1394,12 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS
             const long np = nd < kPilotRows ? nd : kPilotRows;
             rows_here = a.part == 1 ? np : nd - np;
             if (!LONG && a.part == 1 && a.split) B = 1;
+            if (!LONG && a.part == 2 && a.split) {
+                // (the probe pass: the rows depth_screen_kernel listed -- none when nothing is probed)
+                rows_here = a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0 ? (long)*a.probe_count : 0;
+                B = batch_rows(rows_here, a.n_time, a.forced_B);
+                B = B < a.B ? B : a.B;
+            }
             if (a.part == 3) {
                 // (the rows of the third pass: the listed ones, or all behind the pilot; its rows per wave follow from
                 // THAT count, as in cells_body)
@@ -1957,9 +1970,10 @@ thread_local bool t_last_pruned = false;
 // the cases that gain -- hence 90 %).
 __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
                                                           double* __restrict__ rowc, unsigned long long* __restrict__ surv_count,
-                                                          int pstride)
+                                                          int pstride, unsigned long long* __restrict__ probe_count)
 {
     if (threadIdx.x == 0 && surv_count) *surv_count = 0ull;
+    if (threadIdx.x == 0 && probe_count) *probe_count = 0ull;
     __shared__ double smin[4];
     __shared__ int sfar[4], sfin[4];
     if (n_dev) n = *n_dev;
@@ -1990,6 +2004,53 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
         // (the same condition as cells_body's `probing`: a stride of 1 leaves nothing to probe)
         rowc[n * kRowDoubles + kHdrProbe] = (pstride > 1 && fin > 0 && 100L * far >= 90L * fin) ? 1.0 : 0.0;
     }
+}
+
+// Depth screen of the rows behind the pilot (bounded evaluation of batches; after pilot_stats_kernel, before the probe
+// pass): lanes = rows.  A row too shallow (diluted) for the data is settled by its constants alone and reports the
+// bound; the others go on the probe pass's list, one atomic per wave.  Until round 4's last day the probe pass screened
+// its own rows: with four rows in five settled (TOI-465.01's lnZ_TTP: 82 %) its batches held one live row of six, and
+// the window pass -- 64 cells at a time over ALL cells of a batch -- ran on a fifth of its lanes.
+__global__ __launch_bounds__(64) void depth_screen_kernel(RowsArgs a)
+{
+    const long n = a.n_dev ? *a.n_dev : a.n;
+    const double* hdr = a.rowc + n * kRowDoubles;
+    if (hdr[kHdrProbe] == 0.0) return;                 // nothing is probed: the third pass takes the rows as they come
+    const long np = n < kPilotRows ? n : kPilotRows;
+    const int lane = (int)threadIdx.x;
+    const double hmin = hdr[kHdrHmin], xmax = hdr[kHdrXmax];
+    const bool excl_rule = a.skip_excl && a.model == TRX_MODEL_EB;
+    unsigned n_pruned = 0;
+    for (long r0 = np + (long)blockIdx.x * 64; r0 < n; r0 += (long)gridDim.x * 64) {
+        const long row = r0 + lane;
+        bool alive = row < n, shallow = false;
+        double lb = 0.0;
+        if (alive) {
+            const RowC& c = *reinterpret_cast<const RowC*>(a.rowc + row * kRowDoubles);
+            // (a row the EB secondary rule excludes stays on the list: the probe pass reports its +inf and counts it)
+            if (!(excl_rule && c.excl != 0.0)) {
+                lb = depth_screen(hdr, depth_bound(c));
+                const double lp = a.prune_lp ? a.prune_lp[a.src_idx ? (long)a.src_idx[row] : row] : 0.0;
+                // (an unocculted cell must read exactly 1: a degenerate flux ratio makes it NaN, and so the row's chi^2)
+                const double m1 = fma(-(1.0 - 1.0), c.rdil, 1.0);
+                shallow = m1 == 1.0 && lb > hmin && (a.prune_c0 - lb + lp) < xmax - 90.0;
+#ifdef TRX_PRUNE_NEVER_DEAD
+                shallow = false;
+#endif
+            }
+            if (shallow) a.out[row] = lb;
+            alive = !shallow;
+        }
+        n_pruned += (unsigned)__popcll(__ballot(shallow));
+        const unsigned long long ma = __ballot(alive);
+        if (ma) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(a.probe_count, (unsigned long long)__popcll(ma));
+            at = __shfl(at, 0, 64);
+            if (alive) a.probe_list[at + lanes_below(ma)] = (int)row;
+        }
+    }
+    if (lane == 0 && n_pruned) add_row_stat(1, n_pruned);
 }
 
 // the PRUNE instantiations exist for the likelihood mode only
@@ -2092,15 +2153,15 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
     // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
-    // [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list) | row blocks |
-    // launch header]
+    // [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list, probe counter, probe
+    // list) | row blocks | launch header]
     const size_t list_doubles = scan_list_doubles(a.n);
 #ifdef TRX_NO_SPLIT
     const bool split = false;              // (A/B builds: batches probe and finish in one kernel, as in round 3)
 #else
     const bool split = prune && !long_rows;
 #endif
-    const size_t surv_doubles = split ? scan_list_doubles(a.n) : 0;
+    const size_t surv_doubles = split ? 2 * scan_list_doubles(a.n) : 0;
     const size_t scratch_bytes = (list_doubles + surv_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
@@ -2109,6 +2170,8 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.split = split ? 1 : 0;
     a.surv_count = split ? reinterpret_cast<unsigned long long*>(static_cast<double*>(scratch) + list_doubles) : nullptr;
     a.surv_list = split ? reinterpret_cast<int*>(static_cast<double*>(scratch) + list_doubles + 2) : nullptr;
+    a.probe_count = split ? reinterpret_cast<unsigned long long*>(static_cast<double*>(scratch) + 2 * list_doubles) : nullptr;
+    a.probe_list = split ? reinterpret_cast<int*>(static_cast<double*>(scratch) + 2 * list_doubles + 2) : nullptr;
     a.rowc = static_cast<double*>(scratch) + list_doubles + surv_doubles;
     {
         long rb = (a.n + 63) / 64;
@@ -2157,7 +2220,15 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
         launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
         if (a.n_dev || a.n > kPilotRows) {
-            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count, a.pstride);
+            hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count, a.pstride,
+                               a.probe_count);
+            if (split) {
+                // the depth screen of the rows behind the pilot, lanes = rows; what it leaves goes to the probe pass
+                long sg = (a.n + 63) / 64;
+                if (a.n_dev) sg = (sg + 3) / 4;
+                sg = sg < 8 ? 8 : (sg > 1024 ? 1024 : sg);
+                hipLaunchKernelGGL(depth_screen_kernel, dim3((unsigned)sg), dim3(64), 0, st, a);
+            }
             ap.part = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
             if (split) {
