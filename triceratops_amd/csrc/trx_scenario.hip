@@ -19,6 +19,8 @@
 //                        equals, NaN first: numpy's / torch's argmin), its columns, the masked count and the
 //                        limb-darkening flag (scenario_final, trx_device.hpp), written straight into the caller's
 //                        pinned record
+// (with the bounded evaluation cells_kernel is up to five launches: pilot rows, pilot_stats_kernel, depth_screen_kernel,
+// probe pass, the rows left alive -- trx_kernels.hip)
 // 5 launches for a planet scenario (7 in round 3), 9 for a binary one (two branches; 10), no memset, no copy, NO
 // sync: a caller can enqueue every lnZ_* call of a calc_probs on a few streams and wait once (trx_scenario_enqueue);
 // trx_scenario_evidence is the same followed by one hipStreamSynchronize.  Every buffer lives in the stream's scratch
