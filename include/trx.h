@@ -155,6 +155,10 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
  * wavefront of the batched variant (light curves below trx_set_cell_packing_below's threshold), 1..22;
  * 0 = automatic. */
 int trx_set_rows_per_wave(int rows);
+/* (tests; host only, touches no device) checks the plan by which the batched likelihood kernel deals `rows` rows to its
+ * waves at `rows_per_wave` rows each -- tapered towards the end of the launch when `taper` is set -- : every row in
+ * exactly one batch.  *positions: wave positions per XCD; *rows_min: the smallest batch. */
+int trx_debug_batch_plan(long rows, int rows_per_wave, int taper, long* positions, int* rows_min);
 
 /* Diagnostics (process-wide switches, default 1 / 1 / 1 / 1 / 0; no reference counterpart):
  *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of

@@ -2537,6 +2537,38 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
     return TRX_OK;
 }
 
+// (tests, host only: no device is touched) the plan the batched cells_kernel deals its rows by -- walks every position
+// of the eight XCDs exactly as cells_body does and checks that the batches tile [0, rows) once, in order within an
+// XCD, none larger than rows_per_wave; *positions = positions per XCD, *waves_min = the smallest batch met
+int trx_debug_batch_plan(long rows, int rows_per_wave, int taper, long* positions, int* rows_min)
+{
+    if (rows < 0 || rows_per_wave < 1 || rows_per_wave > kCellsMaxRows) return fail(TRX_ERR_ARG, "bad plan request%s (%ld rows)", "", rows);
+    const BatchPlan p = batch_plan(rows, rows_per_wave, taper != 0);
+    long covered = 0;
+    int smallest = rows_per_wave;
+    for (long xcd = 0; xcd < 8; ++xcd) {
+        long expect = xcd * p.R;                         // an XCD's batches follow one another in its share
+        for (long pos = 0; pos < p.P; ++pos) {
+            long base;
+            int nb;
+            batch_at(p, xcd, pos, base, nb);
+            if (base >= rows) continue;
+            if (rows - base < nb) nb = (int)(rows - base);
+            if (nb < 1 || nb > rows_per_wave || base != expect)
+                return fail(TRX_ERR_ARG, "batch plan broken%s (at row %ld)", "", base);
+            expect = base + nb;
+            covered += nb;
+            if (nb < smallest) smallest = nb;
+        }
+        const long share_end = (xcd + 1) * p.R < rows ? (xcd + 1) * p.R : rows;
+        if (xcd * p.R < rows && expect != share_end) return fail(TRX_ERR_ARG, "batch plan leaves rows out%s (after row %ld)", "", expect);
+    }
+    if (covered != rows) return fail(TRX_ERR_ARG, "batch plan covers the wrong number of rows%s (%ld)", "", covered);
+    if (positions) *positions = p.P;
+    if (rows_min) *rows_min = smallest;
+    return TRX_OK;
+}
+
 int trx_set_rows_per_wave(int rows)
 {
     if (rows < 0 || rows > kCellsMaxRows)
