@@ -1375,8 +1375,11 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // launches enqueue only the instantiation it predicts.  A stale memo (the address now holds another
 // light curve) is harmless -- the stencil instantiation falls back to the Gauss nodes when the
 // device finds no uniform grid, the other one never uses the stencil.
+// (Batches: five waves per SIMD for the bounded instantiation too -- until round 4's last day it was compiled for four and
+// took 97 VGPRs, one more than five waves allow on 512 registers in granules of 8; for five it takes 95, no scratch:
+// the unprobed full evaluations of its third pass gain 8 %, profiles/r04_ab_waves5.txt.)
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
-__global__ __launch_bounds__(64 * cells_waves(LONG), (LONG || PRUNE) ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
+__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
 {
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
     // back to zero for the next call on this stream
