@@ -227,7 +227,13 @@ constexpr int kCellsMaxRows = 22;
 // cells per window pass (in-window list in LDS): 1024 with one row per wave; 768 for batches, whose
 // ~640 cells fit one window -- the smaller list lets one more wave onto a CU at 200-300 points
 // (18.5 -> 17.5 ms per 18 launches at 200 points; 1000-point rows lose 2 % with it)
-constexpr int kCellsWindowLong = TRX_CELLS_WINDOW, kCellsWindowBatch = 768;
+#ifndef TRX_CELLS_WINDOW_BATCH
+#define TRX_CELLS_WINDOW_BATCH 768
+#endif
+#ifndef TRX_BATCH_WAVES_PER_EU
+#define TRX_BATCH_WAVES_PER_EU 5
+#endif
+constexpr int kCellsWindowLong = TRX_CELLS_WINDOW, kCellsWindowBatch = TRX_CELLS_WINDOW_BATCH;
 __host__ __device__ constexpr int cells_window(bool long_rows) { return long_rows ? kCellsWindowLong : kCellsWindowBatch; }
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
@@ -1379,7 +1385,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // took 97 VGPRs, one more than five waves allow on 512 registers in granules of 8; for five it takes 95, no scratch:
 // the unprobed full evaluations of its third pass gain 8 %, profiles/r04_ab_waves5.txt.)
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
-__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : 5) void cells_kernel(RowsArgs a)
+__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel(RowsArgs a)
 {
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
     // back to zero for the next call on this stream
