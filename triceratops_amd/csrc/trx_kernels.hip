@@ -1017,10 +1017,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 }
             }
         }
+#endif
         const int nphase = probing ? 2 : 1;
         TRX_TOCK(0, t_pro);
 
-#endif
         // (every row of the batch settled by the depth screen or the EB rule: no cell to look at)
         const unsigned long long rowsmask = (nb >= 64) ? ~0ull : ((1ull << nb) - 1ull);
         const bool all_settled = PRUNE && !LONG && (skipmask & rowsmask) == rowsmask;
@@ -2043,7 +2043,7 @@ __global__ __launch_bounds__(64) void depth_screen_kernel(RowsArgs a)
                 // (an unocculted cell must read exactly 1: a degenerate flux ratio makes it NaN, and so the row's chi^2)
                 const double m1 = fma(-(1.0 - 1.0), c.rdil, 1.0);
                 shallow = m1 == 1.0 && lb > hmin && (a.prune_c0 - lb + lp) < xmax - 90.0;
-#ifdef TRX_PRUNE_NEVER_DEAD
+#if defined(TRX_PRUNE_NEVER_DEAD) || defined(TRX_NO_DEPTH_SCREEN)
                 shallow = false;
 #endif
             }
