@@ -15,7 +15,7 @@
 // One body, draw_one<PHASE>, three uses: trx_draw_scenario evaluates every draw in full (draw_kernel<0>);
 // trx_scenario_enqueue first takes the geometry mask(s) of all draws (draw_kernel<1>, or <2> behind an fp32
 // pre-test of the geometry that leaves the fp64 mask to the draws near it) and, once the survivors are listed,
-// the columns and the prior of those alone (fill_kernel) -- nine draws in ten fail the geometry.
+// the columns and the prior of those alone (compact_fill_kernel) -- nine draws in ten fail the geometry.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -413,7 +413,7 @@ __device__ __forceinline__ bool may_transit(const trx_draw_args& a, const Tables
 //   PHASE 0  everything (trx_draw_scenario: the torch-operator chain reads whole columns)
 //   PHASE 1  the mask(s) only -- what does not feed them (flux ratios, the prior) is not computed and no
 //            column is written: 90-95 % of the draws fail the geometry and are never looked at again
-//   PHASE 2  the columns and the prior of a draw that passed (fill_kernel, after the compaction): the same
+//   PHASE 2  the columns and the prior of a draw that passed (compact_fill_kernel): the same
 //            code on the same counter-based random numbers, hence the same values
 template <int PHASE>
 __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T, const long i, const bool parallel,
@@ -613,8 +613,8 @@ __device__ __forceinline__ void stage_tables(const trx_draw_args& a, Tables& T)
 // KIND 0 (trx_draw_scenario): every draw in full, grid-stride.
 // KIND 1, 2 (trx_scenario_evidence; 2 = with the fp32 pre-test): workgroup b takes the `per` consecutive draws from b * per, writes
 // their mask(s) only and leaves the number of its draws that passed in blk_cnt[b] (and blk_cnt[gridDim.x + b]
-// for the twin branch) -- the first half of the ordered compaction (compact_kernel, trx_scenario.hip); the
-// columns of the draws that passed follow in fill_kernel.  A draw's numbers depend on its index only, so the
+// for the twin branch) -- the first half of the ordered compaction; its second half and the columns of the draws
+// that passed follow in compact_fill_kernel.  A draw's numbers depend on its index only, so the
 // mapping of draws to threads changes no result.  (Three kernels, not one with branches: with two inlined
 // copies of the draw in one kernel the compiler moved the 1.2 KB argument block into scratch memory.)
 template <int KIND>
@@ -809,9 +809,9 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
 }
 
 // Ordered compaction of the mask(s) + the columns and the prior of the draws that passed: see compact_fill_kernel.
-// One workgroup of one wave per workgroup of draw_kernel (2048 at N = 1e6: 512 draws each, ~50 of which pass at the
-// reference's priors -- one wave of fills): 23-31 us for the planet scenarios against 29-39 with two of draw_kernel's
-// workgroups each (a full wave of fills and a partial one in a row).
+// One workgroup of one wave per workgroup of draw_kernel (1024 at N = 1e6: ~1000 draws each, ~100 of which pass at the
+// reference's priors -- two waves of fills): 27-39 us for the planet scenarios (profiles/r04_i_draw_kernel.txt; with
+// 2048 draw workgroups of 512 draws it was 23-31, and the draw kernel 4 us slower: trx_internal.hpp).
 int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
                       hipStream_t st)
 {

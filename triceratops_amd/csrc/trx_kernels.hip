@@ -347,9 +347,9 @@ constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXm
 // scenario are too small for a detected signal: this settles them.
 constexpr int kHdrGrid = 18, kHdrG = kHdrGrid + 64, kHdrDoubles = kHdrG + 64;
 __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.0 * (double)i / 63.0); }
-// Bounded evaluation, two launches (see cells_body, PRUNE): the first kPilotRows rows are evaluated to the end
-// -- they give the launch's running bounds their first values, so that the bound bites from the first wave
-// of the main launch on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
+// Bounded evaluation, several launches (see cells_body, PRUNE, and launch_cells): the first kPilotRows rows are
+// evaluated to the end -- they give the launch's running bounds their first values, so that the bound bites from the
+// first wave of the later passes on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
 // (header slot kHdrProbe) when few pilot rows lie far above the pilot's best.
 #ifndef TRX_PILOT_ROWS
 #define TRX_PILOT_ROWS 2048
