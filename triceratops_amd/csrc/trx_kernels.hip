@@ -829,6 +829,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     }
     if (threadIdx.x < kAtanRanges * kAtanCols) atab[threadIdx.x] = kAtanTable[threadIdx.x];
     const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    // Probe pass of a batched launch: the rows its waves leave alive are gathered per WORKGROUP and reserved in the
+    // launch's list with one device-scope atomic (one per wave -- several thousand on one address, ~23 ns each at the
+    // memory side -- was what the pass's 65 us were made of)
+    constexpr int kWgKeep = (PRUNE && !LONG) ? 8 * kCellsMaxRows : 1;
+    __shared__ int wg_keep[kWgKeep];
+    __shared__ int wg_nkeep, wg_valid;
+    if (PRUNE && !LONG && threadIdx.x == 0) { wg_nkeep = 0; wg_valid = 0x7fffffff; }     // (before the workgroup's only barrier below)
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const double rs2 = a.rs2;
     const int n_time = a.n_time;
@@ -983,10 +990,23 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             if (in_batch && !alive) a.out[rowid] = is_excl ? INFINITY : hrem[lane];
             const unsigned long long ma = __ballot(alive);
             if (ma) {
-                unsigned long long at = 0;
-                if (lane == 0) at = atomicAdd(a.surv_count, (unsigned long long)__popcll(ma));
-                at = __shfl(at, 0, 64);
-                if (alive) a.surv_list[at + lanes_below(ma)] = (int)rowid;
+                const int cnt = __popcll(ma);
+                int slot = 0;
+                if (!LONG) {
+                    if (lane == 0) slot = atomicAdd(&wg_nkeep, cnt);
+                    slot = __shfl(slot, 0, 64);
+                }
+                if (!LONG && slot + cnt <= kWgKeep) {
+                    if (alive) wg_keep[slot + lanes_below(ma)] = (int)rowid;
+                } else {
+                    // (the workgroup's buffer is full -- a launch far beyond the grid cap: straight to the list.  Every
+                    // later reservation is refused as well: the buffer's entries end where the first refused one began)
+                    if (!LONG && lane == 0) atomicMin(&wg_valid, slot);
+                    unsigned long long at = 0;
+                    if (lane == 0) at = atomicAdd(a.surv_count, (unsigned long long)cnt);
+                    at = __shfl(at, 0, 64);
+                    if (alive) a.surv_list[at + lanes_below(ma)] = (int)rowid;
+                }
             }
         };
 #ifndef TRX_NO_DEPTH_SCREEN
@@ -1361,6 +1381,14 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             }
         }
         wave_sync();
+    }
+    if (PRUNE && !LONG && a.split && a.part == 2) {
+        __shared__ unsigned long long wg_at;
+        __syncthreads();                    // every wave of the workgroup is through its batches
+        const int nk = wg_nkeep < wg_valid ? wg_nkeep : wg_valid;
+        if (threadIdx.x == 0 && nk > 0) wg_at = atomicAdd(a.surv_count, (unsigned long long)nk);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nk; i += 64 * W) a.surv_list[wg_at + i] = wg_keep[i];
     }
     if (lane == 0) {
         add_row_stat(0, n_skipped);
@@ -2020,44 +2048,63 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
 // bound; the others go on the probe pass's list, one atomic per wave.  Until round 4's last day the probe pass screened
 // its own rows: with four rows in five settled (TOI-465.01's lnZ_TTP: 82 %) its batches held one live row of six, and
 // the window pass -- 64 cells at a time over ALL cells of a batch -- ran on a fifth of its lanes.
-__global__ __launch_bounds__(64) void depth_screen_kernel(RowsArgs a)
+constexpr int kScreenRows = 512;           // rows per workgroup of depth_screen_kernel (two trips per wave)
+__global__ __launch_bounds__(256) void depth_screen_kernel(RowsArgs a)
 {
+    // One reservation in the probe pass's list per WORKGROUP (512 rows): a device-scope atomic on one address costs
+    // ~23 ns at the memory side whoever issues it, and one per wave of 64 rows -- 1600 of them for 10^5 rows -- made
+    // this kernel 25 us long.  The depth table goes through LDS (depth_screen reads it three times in a row).
+    __shared__ double tab[2 * 64];
+    __shared__ int keep[kScreenRows];
+    __shared__ int nkeep;
+    __shared__ unsigned long long base_at;
     const long n = a.n_dev ? *a.n_dev : a.n;
     const double* hdr = a.rowc + n * kRowDoubles;
     if (hdr[kHdrProbe] == 0.0) return;                 // nothing is probed: the third pass takes the rows as they come
     const long np = n < kPilotRows ? n : kPilotRows;
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    if (threadIdx.x < 128) tab[threadIdx.x] = hdr[kHdrGrid + threadIdx.x];
     const double hmin = hdr[kHdrHmin], xmax = hdr[kHdrXmax];
     const bool excl_rule = a.skip_excl && a.model == TRX_MODEL_EB;
     unsigned n_pruned = 0;
-    for (long r0 = np + (long)blockIdx.x * 64; r0 < n; r0 += (long)gridDim.x * 64) {
-        const long row = r0 + lane;
-        bool alive = row < n, shallow = false;
-        double lb = 0.0;
-        if (alive) {
-            const RowC& c = *reinterpret_cast<const RowC*>(a.rowc + row * kRowDoubles);
-            // (a row the EB secondary rule excludes stays on the list: the probe pass reports its +inf and counts it)
-            if (!(excl_rule && c.excl != 0.0)) {
-                lb = depth_screen(hdr, depth_bound(c));
-                const double lp = a.prune_lp ? a.prune_lp[a.src_idx ? (long)a.src_idx[row] : row] : 0.0;
-                // (an unocculted cell must read exactly 1: a degenerate flux ratio makes it NaN, and so the row's chi^2)
-                const double m1 = fma(-(1.0 - 1.0), c.rdil, 1.0);
-                shallow = m1 == 1.0 && lb > hmin && (a.prune_c0 - lb + lp) < xmax - 90.0;
+    for (long w0 = np + (long)blockIdx.x * kScreenRows; w0 < n; w0 += (long)gridDim.x * kScreenRows) {
+        if (threadIdx.x == 0) nkeep = 0;
+        __syncthreads();
+        for (long r0 = w0 + (threadIdx.x & ~63); r0 < w0 + kScreenRows && r0 < n; r0 += 256) {
+            const long row = r0 + lane;
+            bool alive = row < n, shallow = false;
+            double lb = 0.0;
+            if (alive) {
+                const RowC& c = *reinterpret_cast<const RowC*>(a.rowc + row * kRowDoubles);
+                // (a row the EB secondary rule excludes stays on the list: the probe pass reports its +inf and counts it)
+                if (!(excl_rule && c.excl != 0.0)) {
+                    lb = depth_screen(tab - kHdrGrid, depth_bound(c));
+                    const double lp = a.prune_lp ? a.prune_lp[a.src_idx ? (long)a.src_idx[row] : row] : 0.0;
+                    // (an unocculted cell must read exactly 1: a degenerate flux ratio makes it NaN, and so the row's chi^2)
+                    const double m1 = fma(-(1.0 - 1.0), c.rdil, 1.0);
+                    shallow = m1 == 1.0 && lb > hmin && (a.prune_c0 - lb + lp) < xmax - 90.0;
 #if defined(TRX_PRUNE_NEVER_DEAD) || defined(TRX_NO_DEPTH_SCREEN)
-                shallow = false;
+                    shallow = false;
 #endif
+                }
+                if (shallow) a.out[row] = lb;
+                alive = !shallow;
             }
-            if (shallow) a.out[row] = lb;
-            alive = !shallow;
+            n_pruned += (unsigned)__popcll(__ballot(shallow));
+            const unsigned long long ma = __ballot(alive);
+            if (ma) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&nkeep, __popcll(ma));
+                at = __shfl(at, 0, 64);
+                if (alive) keep[at + lanes_below(ma)] = (int)row;
+            }
         }
-        n_pruned += (unsigned)__popcll(__ballot(shallow));
-        const unsigned long long ma = __ballot(alive);
-        if (ma) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(a.probe_count, (unsigned long long)__popcll(ma));
-            at = __shfl(at, 0, 64);
-            if (alive) a.probe_list[at + lanes_below(ma)] = (int)row;
-        }
+        __syncthreads();
+        const int nk = nkeep;
+        if (threadIdx.x == 0 && nk) base_at = atomicAdd(a.probe_count, (unsigned long long)nk);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nk; i += 256) a.probe_list[base_at + i] = keep[i];
+        __syncthreads();
     }
     if (lane == 0 && n_pruned) add_row_stat(1, n_pruned);
 }
@@ -2233,10 +2280,10 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
                                a.probe_count);
             if (split) {
                 // the depth screen of the rows behind the pilot, lanes = rows; what it leaves goes to the probe pass
-                long sg = (a.n + 63) / 64;
+                long sg = (a.n + kScreenRows - 1) / kScreenRows;
                 if (a.n_dev) sg = (sg + 3) / 4;
-                sg = sg < 8 ? 8 : (sg > 1024 ? 1024 : sg);
-                hipLaunchKernelGGL(depth_screen_kernel, dim3((unsigned)sg), dim3(64), 0, st, a);
+                sg = sg < 8 ? 8 : (sg > 512 ? 512 : sg);
+                hipLaunchKernelGGL(depth_screen_kernel, dim3((unsigned)sg), dim3(256), 0, st, a);
             }
             ap.part = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
