@@ -30,5 +30,5 @@ M_s, R_s, Teff = (float(stars[c][0]) for c in ("mass", "rad", "Teff"))
 for mode in (0, 2, 0, 2, 0, 2):
     L.trx_set_bounded_evaluation(mode)
     torch.manual_seed(11)
-    ml.lnZ_TTP(t, f, sigma, P, M_s, R_s, Teff, 0.0, 1_000_000, True)
+    (ml.lnZ_TEB if os.environ.get("TRACE_EB") else ml.lnZ_TTP)(t, f, sigma, P, M_s, R_s, Teff, 0.0, 1_000_000, True)
     torch.cuda.synchronize()
