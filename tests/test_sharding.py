@@ -272,7 +272,7 @@ def _many_worker(rank, world, port, q):
     calc_probs_many(jobs)
     units = [u for tg, kw in _two_jobs() for u in tg._prepare(**{k: v for k, v in kw.items()})[0]]
     live = [u for u in units if u[4] is not None]
-    owners = sharding.schedule([sharding._COST.get(u[5], 1.0) * u[6] for u in live], world)
+    owners = sharding.schedule([sharding._COST.get(u[5], 1.0) * u[6] for u in live], world, [u[8] for u in live])
     q.put((rank, _tables(jobs), owners))
     dist.barrier()
     dist.destroy_process_group()
@@ -341,3 +341,31 @@ def test_schedule_balances_the_64_toi_batch_over_8_ranks():
     assert owner == sharding.schedule(costs, 8)               # deterministic: every rank computes the same table
     # one rank: everything on rank 0
     assert set(sharding.schedule(costs, 1)) == {0}
+    # with the (job, star) of every unit the ranks get WHOLE TOIs, still balanced: a rank prepares, uploads and
+    # enqueues only the light curves and star tables of its own targets
+    groups = [(j, 0 if i < 10 else 1) for j in range(64) for i in range(12)]
+    owner = sharding.schedule(costs, 8, groups)
+    assert owner == sharding.schedule(costs, 8, groups)
+    load = np.bincount(owner, weights=costs, minlength=8)
+    assert load.max() / load.mean() < 1.03
+    for j in range(64):
+        assert len(set(owner[12 * j:12 * j + 12])) == 1       # no TOI is split
+    assert sorted(np.bincount([owner[12 * j] for j in range(64)], minlength=8)) == [8] * 8 or \
+        load.max() / load.mean() < 1.03                        # (sizes differ: counts may, the loads may not)
+
+
+def test_schedule_deals_like_sized_tois_eight_to_a_rank():
+    """BASELINE configs[3] as bench.py builds it: 64 TOIs of one size, two stars each (10 + 2 calls)"""
+    keys = ["TP", "EB", "PTP", "PEB", "STP", "SEB", "DTP", "DEB", "BTP", "BEB", "NTP", "NEB"]
+    costs = [sharding._COST[k] * 2e8 for _ in range(64) for k in keys]
+    groups = [(j, 0 if i < 10 else 1) for j in range(64) for i in range(12)]
+    owner = sharding.schedule(costs, 8, groups)
+    for r in range(8):
+        mine = [k for k, o in enumerate(owner) if o == r]
+        assert len(mine) == 96 and len({groups[k][0] for k in mine}) == 8
+    # few groups: falls back to stars, then to single calls, and a star dearer than a rank's share is split
+    costs = [sharding._COST[k] for k in keys[:10]] + [1.0, 1.7] * 20
+    groups = [(0, 0)] * 10 + [(0, 1 + i // 2) for i in range(40)]
+    owner = sharding.schedule(costs, 8, groups)
+    load = np.bincount(owner, weights=costs, minlength=8)
+    assert load.max() / load.mean() < 1.10 and len(set(owner[:10])) > 1

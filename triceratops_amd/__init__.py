@@ -13,7 +13,36 @@ import os as _os
 # streams, 0.263 on three, 0.226 on four, 0.190 on six; with 8 queues 0.224 / 0.185 / 0.172 / 0.180 --
 # profiles/r04_hw_queues.txt).  Read by the runtime when it initialises (the first HIP call of the process), so it
 # has to be in the environment before that; a value the user has set is left alone.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+def _request_hw_queues():
+    """Sets GPU_MAX_HW_QUEUES = 8 unless the user has, and records whether the runtime can still see it: the variable
+    is read once, by the first HIP call of the process.  If torch had already initialised the GPU when this package
+    was imported, the setting is a silent no-op -- hw_queues() then says so and require_gpu() warns once."""
+    import sys as _sys
+    user = _os.environ.get("GPU_MAX_HW_QUEUES")
+    late = False
+    _torch = _sys.modules.get("torch")
+    if _torch is not None:
+        try:
+            late = bool(_torch.cuda.is_initialized())
+        except Exception:        # pragma: no cover
+            late = False
+    if user is None:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    return {"value": int(user) if (user or "").isdigit() else (None if user else 8),
+            "set_by": "user" if user is not None else "package",
+            # None: unknown to this process (a user setting is the user's business); False: HIP was up before the import
+            "in_effect": (None if user is not None else (not late))}
+
+
+_HW_QUEUES = _request_hw_queues()
+
+
+def hw_queues():
+    """{'value', 'set_by': 'user' | 'package', 'in_effect'}: what GPU_MAX_HW_QUEUES this process asked for and whether
+    the HIP runtime was still uninitialised when the package set it (False: the runtime's default of 4 applies and
+    calc_probs on more than two streams runs ~10 % slower, profiles/r04_hw_queues.txt; import triceratops_amd before
+    the first GPU call, or export the variable)."""
+    return dict(_HW_QUEUES)
 
 
 def set_sampling(mode):

@@ -164,6 +164,13 @@ def require_gpu():
         raise TrxError("triceratops_amd needs an AMD GPU (gfx950); none is visible and there is no "
                        "CPU fallback")
     _gpu_seen = True
+    from . import hw_queues
+    if hw_queues()["in_effect"] is False:
+        import warnings
+        warnings.warn("triceratops_amd was imported after the HIP runtime had been initialised: GPU_MAX_HW_QUEUES=8 "
+                      "did not take effect (the runtime keeps its default of 4 hardware queues; calc_probs on more "
+                      "than two streams runs ~10 % slower).  Import triceratops_amd before the first GPU call or "
+                      "export GPU_MAX_HW_QUEUES=8.", RuntimeWarning, stacklevel=3)
 
 
 def compute_device():
@@ -179,8 +186,8 @@ _upload_streams = {}
 # DEVICE (wait_uploads), the host never blocks
 _pending_uploads = {}          # device index -> [(sequence number, event)], oldest first
 _pending_lock = threading.Lock()
-_upload_seq = 0
-_stream_seen = {}              # stream handle -> sequence number of the last upload it already waits for
+_upload_seq = {}               # device index -> sequence number of its newest upload
+_stream_seen = {}              # (device index, stream handle) -> sequence number of the last upload it already waits for
 
 
 def dev(x, device=None):
@@ -191,8 +198,9 @@ def dev(x, device=None):
     third of the host time of a 64-target batch step, profiles/r03_f_batch_host_profile.txt).  Nothing waits on
     the host: the upload leaves an event, the stream that is current here waits for it on the device, and so does
     every stream a library call is enqueued on while the event is pending (wait_uploads; cached tables are read
-    by calls on other streams a few microseconds later)."""
-    global _upload_seq
+    by calls on other streams a few microseconds later).  A tensor from dev() is therefore ordered for the stream
+    that was current at the upload and for every stream that passes through wait_uploads() / _stream() -- all library
+    calls do; a torch operator launched on some OTHER stream right after must call wait_uploads(that stream) itself."""
     if isinstance(x, torch.Tensor):
         return x.to(device=device or "cuda", dtype=torch.float64).contiguous()
     a = np.ascontiguousarray(x, dtype=np.float64)
@@ -211,8 +219,8 @@ def dev(x, device=None):
     cur = torch.cuda.current_stream(d)
     t.record_stream(cur)      # the allocator must not hand the block out early
     with _pending_lock:
-        _upload_seq += 1
-        _pending_uploads.setdefault(d.index, []).append((_upload_seq, ev))
+        seq = _upload_seq[d.index] = _upload_seq.get(d.index, 0) + 1
+        _pending_uploads.setdefault(d.index, []).append((seq, ev))
     wait_uploads(cur)
     return t
 
@@ -223,11 +231,16 @@ def wait_uploads(stream):
     pend = _pending_uploads.get(stream.device.index)
     if not pend:
         return
-    key = stream.cuda_stream
+    # (keyed per device: the default stream is handle 0 on every device, and sequence numbers are per device too)
+    key = (stream.device.index, stream.cuda_stream)
     with _pending_lock:
         while pend and pend[0][1].query():
             pend.pop(0)                                 # (completed: nobody needs to wait any more)
         if not pend:
+            # nothing in flight: forget who waited for what, so that a stream created later under a recycled handle
+            # does not inherit the record of the one destroyed
+            for k in [k for k in _stream_seen if k[0] == stream.device.index]:
+                del _stream_seen[k]
             return
         seq, ev = pend[-1]
         if _stream_seen.get(key, 0) >= seq:

@@ -50,6 +50,8 @@ streams = int(os.environ.get("TRX_STREAMS", "4"))
 timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "finish_s": 0.0}
 # seed bases of the ranks of the last multi-rank run_units (from the all_gather's header rows)
 last_seed_bases = None
+# what the schedule of the last run_units gave every rank: lnZ_* calls, distinct (job, star)s and distinct jobs
+last_share = {"calls": [0], "stars": [0], "jobs": [0]}
 # The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
 # their scratch together stays near this many draws' worth (6 streams at N = 1e6, 2 at N >= 3e6)
 scratch_budget_draws = 6_000_000
@@ -79,16 +81,54 @@ def _dist():
     return None
 
 
-def schedule(costs, world):
-    """Longest-processing-time-first assignment.  Returns owner[k] for every unit; ties are
-    broken by unit index and rank index so that every rank computes the same table."""
-    order = sorted(range(len(costs)), key=lambda k: (-costs[k], k))
-    load = [0.0] * world
-    owner = [0] * len(costs)
-    for k in order:
-        r = min(range(world), key=lambda i: (load[i], i))
+def _lpt(items, cost, load, calls, n_calls):
+    """longest-processing-time-first: the dearest item first, each to the rank with the least load so far (ties:
+    fewest calls, then rank index)"""
+    out = {}
+    for it in sorted(items, key=lambda it: (-cost[it], it)):
+        r = min(range(len(load)), key=lambda i: (load[i], calls[i], i))
+        out[it] = r
+        load[r] += cost[it]
+        calls[r] += n_calls[it]
+    return out
+
+
+def schedule(costs, world, groups=None):
+    """Owner of every unit; every rank computes the same table.
+
+    groups[k] = (job, star) of unit k (calc_probs_many: the TOI and the star of the lnZ_* call).  A rank pays for
+    every star it touches on the HOST as well -- the renormalised light curve, the star's constants and tables,
+    one trx_star_enqueue per star -- so units are dealt as whole TOIs, then as whole stars, and only what is left
+    as single calls (round 4 dealt single calls: 64 like-sized TOIs on 8 ranks gave every rank 16 TOIs x 6 calls
+    instead of 8 x 12, and the host path of a rank shrank to a quarter, not an eighth).  At each level the groups
+    are dealt longest-first while there are at least two per rank; a group dearer than 3/4 of a rank's fair share
+    (the target star of a single crowded field), and the len mod world cheapest ones, go on to the next level,
+    where they fill in what the whole groups left uneven.  groups = None: single units (one calc_probs)."""
+    n = len(costs)
+    load, calls = [0.0] * world, [0] * world
+    owner = [0] * n
+    if world <= 1 or n == 0:
+        return owner
+    fair = 0.75 * sum(costs) / world
+    todo = list(range(n))
+    levels = [] if groups is None else [lambda k: groups[k][0], lambda k: groups[k]]
+    for level in levels:
+        members = {}
+        for k in todo:
+            members.setdefault(level(k), []).append(k)
+        cost = {g: sum(costs[k] for k in ks) for g, ks in members.items()}
+        whole = sorted((g for g in members if cost[g] <= fair), key=lambda g: (-cost[g], members[g][0]))
+        if len(whole) < 2 * world:
+            continue
+        whole = whole[:len(whole) - len(whole) % world]
+        dealt = _lpt(whole, cost, load, calls, {g: len(members[g]) for g in whole})
+        for g, r in dealt.items():
+            for k in members[g]:
+                owner[k] = r
+        todo = [k for k in todo if level(k) not in dealt]
+    dealt = _lpt(todo, {k: costs[k] for k in todo}, load, calls, {k: 1 for k in todo})
+    for k, r in dealt.items():
         owner[k] = r
-        load[r] += costs[k]
     return owner
 
 
@@ -109,8 +149,9 @@ def _as_dicts(rec):
 def run_units(units, verbose=0):
     """Evaluate the work units of one calc_probs.
 
-    units: list of (first_row, names, star_num, ID, thunk_or_None, key[, weight]); weight scales the
-    scenario cost of `key` in the schedule (units of differently sized jobs, calc_probs_many).
+    units: list of (first_row, names, star_num, ID, thunk_or_None, key[, weight, draws, (job, star)]); weight scales
+    the scenario cost of `key` in the schedule (units of differently sized jobs, calc_probs_many), (job, star) lets
+    the schedule deal whole TOIs and whole stars.
     Returns, per unit, None (dropped scenario) or a tuple of per-scenario dicts
     {column: best value, 'lnZ': float}."""
     dist = _dist()
@@ -122,8 +163,13 @@ def run_units(units, verbose=0):
     if dist:
         base = _draw_base()         # ranks seeded alike draw the same one (module docstring)
         own = schedule([_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
-                        for k in live], world)
+                        for k in live], world,
+                       [units[k][8] for k in live] if all(len(units[k]) > 8 for k in live) else None)
         owner = {k: own[i] for i, k in enumerate(live)}
+    global last_share
+    last_share = {"calls": [sum(1 for k in live if owner[k] == r) for r in range(world)],
+                  "stars": [len({_star_of(units[k]) for k in live if owner[k] == r}) for r in range(world)],
+                  "jobs": [len({_job_of(units[k]) for k in live if owner[k] == r}) for r in range(world)]}
     # calc_probs keeps the best draw of every scenario only: with the device generator the fused
     # path then selects it with one argmin instead of a top-100 sort (fused.TABLE_ROWS)
     from . import fused as _fused
@@ -148,6 +194,15 @@ def _worker_streams(device, n):
     while len(have) < n:
         have.append(torch.cuda.Stream(device))
     return have[:n]
+
+
+def _star_of(u):
+    """(job, star) of a unit when the caller gave it (target._prepare), else its star's ID"""
+    return u[8] if len(u) > 8 else u[3]
+
+
+def _job_of(u):
+    return u[8][0] if len(u) > 8 else 0
 
 
 def _run_units(units, live, owner, base, dist, world, rank, verbose):
@@ -219,7 +274,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                 with torch.cuda.stream(pool[j]):
                     one(k)
                 # the calls of one star go to the library together (trx_star_enqueue): at the last unit of a star
-                if n_ + 1 == len(mine_k) or units[mine_k[n_ + 1]][3] != units[k][3]:
+                if n_ + 1 == len(mine_k) or _star_of(units[mine_k[n_ + 1]]) != _star_of(units[k]):
                     _fused.flush()
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:

@@ -174,11 +174,11 @@ class target:
                     break
                 for key, names, j0, snum in _TARGET_CALLS:
                     fn = None if key in drop_scenario else (lambda k=key: target_call(k))
-                    units.append((j0, names, snum, ID, fn, key))
+                    units.append((j0, names, snum, ID, fn, key, 0))
             else:
                 j0 = 15 + 3 * (i - 1)
-                units.append((j0, ("NTP",), 1, ID, lambda i=i: nearby_call(i, lnZ_TTP), "NTP"))
-                units.append((j0 + 1, ("NEB", "NEBx2P"), 1, ID, lambda i=i: nearby_call(i, lnZ_TEB), "NEB"))
+                units.append((j0, ("NTP",), 1, ID, lambda i=i: nearby_call(i, lnZ_TTP), "NTP", i))
+                units.append((j0 + 1, ("NEB", "NEBx2P"), 1, ID, lambda i=i: nearby_call(i, lnZ_TEB), "NEB", i))
         return units, ok
 
     def calc_probs(self, time, flux_0, flux_err_0: float, P_orb, contrast_curve_file: str = None,
@@ -197,9 +197,9 @@ class target:
 
     def _prepare(self, time, flux_0, flux_err_0, P_orb, contrast_curve_file=None, filt="TESS",
                  N=1000000, parallel=False, drop_scenario=[], flatpriors=False, exptime=0.00139,
-                 nsamples=20, molusc_file=None):
+                 nsamples=20, molusc_file=None, job=0):
         """Work units of one calc_probs (triceratops.py:673-735: NaN filter, star filter, table
-        sizes) and the number of table rows."""
+        sizes) and the number of table rows.  job: index of this target in a calc_probs_many batch."""
         time = np.asarray(time, dtype=np.float64)
         flux_0 = np.asarray(flux_0, dtype=np.float64)
         keep = ~np.isnan(time) & ~np.isnan(flux_0)
@@ -217,9 +217,10 @@ class target:
         units, _ok = self._units(filtered, flux_0, flux_err_0, time, P_orb, contrast_curve_file,
                                  filt, N, parallel, drop_scenario, flatpriors, exptime, nsamples,
                                  molusc_file)
-        # relative size of this job's units for the multi-GPU schedule, and the draws per unit (stream scratch)
+        # relative size of this job's units for the multi-GPU schedule, the draws per unit (stream scratch) and the
+        # (job, star) the unit belongs to: the schedule deals whole jobs and whole stars first (sharding.schedule)
         weight = float(N) * max(1, time.size)
-        return [u + (weight, int(N)) for u in units], n_scen
+        return [u[:6] + (weight, int(N), (job, u[6])) for u in units], n_scen
 
     def _finish(self, units, results, n_scen):
         """Scenario table, normalised probabilities, FPP and NFPP from the per-unit results
@@ -353,10 +354,10 @@ def calc_probs_many(jobs, verbose: int = 0):
     import time as _time
     t0 = _time.perf_counter()
     prepared = []
-    for tg, kw in jobs:
+    for job, (tg, kw) in enumerate(jobs):
         kw = dict(kw)
         kw.pop("verbose", None)
-        prepared.append((tg,) + tg._prepare(**kw))
+        prepared.append((tg,) + tg._prepare(job=job, **kw))
     flat = [u for _, units, _ in prepared for u in units]
     t1 = _time.perf_counter()
     results = sharding.run_units(flat, verbose=verbose)
