@@ -1,0 +1,124 @@
+"""The PRODUCTION chain against reference-generated fixtures, value for value.
+
+calc_probs in its default mode is trx_star_enqueue -> draw_kernel, compact_fill_kernel, rowc_kernel (sec_scan_kernel),
+the passes of the bounded evaluation (pilot, pilot_stats_kernel, depth_screen_kernel, probe pass, survivors),
+lme_partial_kernel + scenario_final, on a few streams, records read after one wait.  Until round 4 the fixtures made
+from the imported reference pinned only the torch-operator chain with the FULL evaluation (the seeded numpy modes were
+refused by the native path) and production hung on a chain of equivalences.  Here set_sampling("numpy-device")
+feeds numpy's seeded uniforms -- the reference's draws, in its order -- into that very chain (trx_draw_args.uP ... uW,
+use_philox = 0), bounded evaluation at its default, and the results are compared with
+
+ * tests/golden/lnz_cases.npz: 38 seeded lnZ_* calls of the imported reference (N = 2000; lnZ 1e-8, best draw equal);
+ * tests/golden/reference_full.npz (make_reference_full.py): the reference's own calc_probs at N = 1e6 and 1e5 on the
+   notebook inputs -- the sizes at which the depth screen, the probe pass and the survivor pass really run --
+   every scenario's lnZ (1e-8 + 1e-12 |lnZ|), FPP / NFPP (1e-9), the best draw of every scenario;
+ * the calc_probs fixtures of tests/test_calc_probs_golden.py / test_toi465.py / test_toi1228.py, which take this
+   chain too since set_sampling("numpy-device") does.
+Reference: marginal_likelihoods.py:39-172 (TTP) ... 2038-2362 (BEB); triceratops.py:797-823.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+import anchors
+from helpers import GOLD, gold
+from test_gpu_golden import CASES, G, _call
+
+pytestmark = pytest.mark.gpu
+
+
+def _native_calls():
+    """(library calls through trx_star_enqueue / trx_scenario_enqueue so far)"""
+    from triceratops_amd import _lib
+    return int(_lib.STATS["native_calls"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lnz_calls_through_the_library_chain_on_the_reference_draws(case):
+    import triceratops_amd
+    from triceratops_amd import fused
+    from triceratops_amd import marginal_likelihoods as ml
+    name, variant = case.split("_")
+    if variant == "serial":
+        pytest.skip("N = 300 per-draw-loop fixture: covered by the operator chain (same kernels, parallel = 0)")
+    P = [2.5, 4.0] if variant == "range" else 3.3
+    cc = os.path.join(GOLD, "contrast_curve_synth.csv") if variant == "ccJ" else None
+    triceratops_amd.set_sampling("numpy-device")
+    fused.TABLE_ROWS = 1
+    before = _native_calls()
+    try:
+        assert fused.staged_native()
+        np.random.seed(int(G[case + "_seed"][0]))
+        res = _call(ml, name, P, int(G["N"][0]), True, cc, "J" if cc else "TESS")
+    finally:
+        fused.TABLE_ROWS = fused.N_BEST
+        triceratops_amd.set_sampling("numpy")
+    dicts = res if isinstance(res, tuple) else (res,)
+    assert _native_calls() == before + 1                    # the library's chain ran, not the operator chain
+    for i, d in enumerate(dicts):
+        want = G["%s_lnZ%d" % (case, i)][0]
+        assert (d["lnZ"] == want) if not np.isfinite(want) else abs(d["lnZ"] - want) < 1e-8 + 1e-12 * abs(want), (case, i)
+        logw = G["%s_logw%d" % (case, i)]
+        if not np.isfinite(logw).any():
+            continue
+        # the best draw: equal unless the reference's own best is an exact tie (its argsort is not stable)
+        top = np.sort(logw[np.isfinite(logw)])[::-1]
+        if top.size > 1 and top[0] == top[1]:
+            continue
+        for k in ("P_orb", "inc", "b", "R_p", "ecc", "argp", "M_EB", "R_EB"):
+            assert np.allclose(d[k][0], G["%s_res%d_%s" % (case, i, k)][0], rtol=1e-9, atol=1e-12), (case, i, k)
+
+
+FULL = gold("reference_full.npz") if os.path.exists(os.path.join(GOLD, "reference_full.npz")) else None
+RUNS = [str(r) for r in FULL["runs"]] if FULL is not None else []
+
+
+@pytest.mark.parametrize("run", RUNS)
+def test_calc_probs_production_chain_replays_the_reference_run(run):
+    """one seeded calc_probs of the reference (N = 1e6 / 1e5, imported reference on the CPU) against the same seed through
+    set_sampling("numpy-device"): trx_star_enqueue on sharding.streams streams, bounded evaluation on"""
+    import ctypes
+    from triceratops_amd import _lib, sharding
+    case, seed, N = run.rsplit("_", 2)
+    pruned = ctypes.c_ulonglong(0)
+    _lib.check(_lib.lib().trx_pruned_rows(ctypes.byref(pruned), 1))
+    before = _native_calls()
+    lnZ, prob, fpp, rp = anchors.run(case, int(seed), N=int(N), sampling="numpy-device")
+    assert _native_calls() - before == 10                    # the ten lnZ_* calls of the target star
+    _lib.check(_lib.lib().trx_pruned_rows(ctypes.byref(pruned), 1))
+    want = FULL[run + "_lnZ"]
+    fin = np.isfinite(want)
+    err = np.abs(lnZ[fin] - want[fin])
+    print("\n%s: %d rows abandoned by the bounded evaluation on %d streams; max |lnZ - reference| %.2e, "
+          "|FPP - reference| %.2e" % (run, pruned.value, sharding.streams, err.max(), abs(fpp - FULL[run + "_FPP"][0])))
+    assert np.array_equal(fin, np.isfinite(lnZ)) and np.array_equal(lnZ[~fin], want[~fin])
+    assert np.all(err < 1e-8 + 1e-12 * np.abs(want[fin])), err
+    assert abs(fpp - FULL[run + "_FPP"][0]) < 1e-9
+    assert np.abs(prob - FULL[run + "_prob"]).max() < 1e-9
+    if int(N) >= 1_000_000:
+        assert pruned.value > 100_000                        # the bounded evaluation did abandon rows in this run
+
+
+@pytest.mark.parametrize("run", RUNS[:2])
+def test_best_draws_of_the_production_chain_equal_the_reference_run(run):
+    import pandas as pd
+    import triceratops_amd
+    from triceratops_amd.triceratops import target
+    case, seed, N = run.rsplit("_", 2)
+    c = anchors.CASES[case]
+    stars, t, f, sigma, P = anchors.inputs(case)
+    tg = target(c["ID"], np.array([1]), mission=c["mission"], stars=stars, trilegal_fname=anchors.TRILEGAL)
+    triceratops_amd.set_sampling("numpy-device")
+    try:
+        np.random.seed(int(seed))
+        tg.calc_probs(t, f, sigma, P, contrast_curve_file=c["cc"], N=int(N), parallel=True, verbose=0)
+    finally:
+        triceratops_amd.set_sampling("numpy")
+    live = np.isfinite(FULL[run + "_lnZ"])
+    for col in ("M_s", "R_s", "P_orb", "inc", "b", "ecc", "w", "R_p", "M_EB", "R_EB"):
+        assert np.allclose(tg.probs[col].values[live], FULL[run + "_" + col][live], rtol=1e-9, atol=1e-12), col
+    for a in ("u1", "u2", "fluxratio_EB", "fluxratio_comp"):
+        assert np.allclose(np.asarray(getattr(tg, a))[live], FULL[run + "_" + a][live], rtol=1e-9, atol=1e-12), a

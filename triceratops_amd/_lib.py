@@ -40,7 +40,8 @@ EXTRA_FLAGS = 0
 CELL_PACKING_BELOW = 320
 # work counters of the scenario layer (bench.py reads them): rows and (row, time) cells that
 # went through trx_lnz_scenario since the last reset
-STATS = {"rows": 0, "cells": 0, "launches": 0}
+# native_calls: lnZ_* calls that went through the library's own chain (trx_scenario_enqueue / trx_star_enqueue)
+STATS = {"rows": 0, "cells": 0, "launches": 0, "native_calls": 0}
 _stats_lock = threading.Lock()
 
 

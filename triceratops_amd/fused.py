@@ -50,6 +50,13 @@ def threadable():
     return ml._sampling["mode"] == "device" and PHILOX and isinstance(dp.RNG, dp.TorchRng)
 
 
+def staged_native():
+    """True when lnZ_* calls under calc_probs go to the library's chain with STAGED random numbers: numpy's global
+    stream consumed on the calling thread in the reference's order (set_sampling("numpy-device")).  One host thread
+    only; the calls can still be deferred and dealt to streams like the device generator's."""
+    return ml._sampling["mode"] == "numpy-device" and NATIVE and isinstance(dp.RNG, dp.NumpyStreamRng)
+
+
 def _mix(seed, count):
     """splitmix64 of (seed, count): a 62-bit Philox key"""
     z = (seed * 0x9E3779B97F4A7C15 + count * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
@@ -161,6 +168,8 @@ class Pending:
             with _stats_lock:
                 _lib.count_launch(n, self.n_time)
             res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
+        with _stats_lock:
+            _lib.STATS["native_calls"] += 1
         return res[0] if planet else (res[0], res[1])
 
 
@@ -215,6 +224,7 @@ def records_to_rows(pending):
         _lib.STATS["rows"] += rows_total
         _lib.STATS["cells"] += cells_total
         _lib.STATS["launches"] += launches
+        _lib.STATS["native_calls"] += len(pending)
     for _, p in pending:
         p.keep = None
     return out
@@ -639,8 +649,12 @@ class _Scenario:
         tab = _spline_table(dev, self.band)
         a.splines = tab.data_ptr()
         ncol = 11 if a.planet else 14
-        if (NATIVE and TABLE_ROWS == 1 and DUMP is None and _lib.TRACE is None
-                and not isinstance(dp.RNG, dp.NumpyStreamRng)):
+        # calc_probs (TABLE_ROWS == 1) takes the library's own chain in BOTH device modes: with numpy's stream the staged
+        # uniforms go in through trx_draw_args.uP ... uW (use_philox = 0), so a seeded "numpy-device" run is the
+        # production chain -- trx_star_enqueue, bounded evaluation -- on the reference's draws
+        # (tests/test_gpu_production_pin.py).  The best draw is the FIRST of equal minima (numpy's argmin); the
+        # reference's argsort may order exact ties differently (the operator chain below reproduces that too).
+        if NATIVE and TABLE_ROWS == 1 and DUMP is None and _lib.TRACE is None:
             return self._run_native(is_host, ncol)
         cols = torch.empty((ncol, N), dtype=F64, device=dev)
         mask = torch.empty(N, dtype=torch.uint8, device=dev)

@@ -243,11 +243,12 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         for k, rec in _fused.records_to_rows(pending).items():
             table[offs[k]:offs[k] + rows[k]] = rec
 
-    on_device = _fused.threadable()
+    on_device = _fused.threadable() or _fused.staged_native()
     if on_device:
         import torch
         on_device = torch.cuda.is_available()          # (without a GPU the thunks fail loudly themselves)
-    n_threads = min(threads, len(mine_k)) if (base is not None and on_device) else 1
+    # (numpy's stream is consumed on this thread, call after call, in the reference's order: one host thread)
+    n_threads = min(threads, len(mine_k)) if (base is not None and on_device and _fused.threadable()) else 1
     if n_threads <= 1 and not (on_device and mine_k):
         for k in mine_k:
             one(k)
