@@ -204,6 +204,9 @@ int trx_set_debug_bounded_lnl(int on);
  *    before its likelihood kernels run, so that a row no kernel writes shows as a perfect fit (lnZ and the best draw
  *    jump) instead of as whatever the previous call on the stream left there. */
 int trx_set_debug_poison(int on);
+/*    trx_set_debug_bug(1) (tests): re-enables a bug of round 4 (the third pass of the bounded evaluation skipped its last
+ *    batches when nothing was probed), so that a test can show the "never written" status of the record catching it. */
+int trx_set_debug_bug(int on);
 int trx_pruned_rows(unsigned long long* out, int reset);
 int trx_set_supersample_tiers(int on);
 int trx_set_stencil(int on);
@@ -325,12 +328,16 @@ size_t trx_draw_args_size(void);   /* sizeof(trx_draw_args): lets a foreign bind
  *             dump) are ignored: the buffers are stream-ordered scratch of the call
  *   out       HOST, [branches][TRX_SCENARIO_OUT]: the best draw's columns (11 or 14, the layout
  *             of trx_draw_args.cols; draw 0 when no draw passes the mask), then lnZ, then the
- *             number of draws that passed the mask
+ *             number of draws that passed the mask; [16] the number of masked draws that hold the smallest
+ *             chi^2 (> 1: the best draw is the FIRST of an exact tie -- numpy's argmin; the reference's
+ *             argsort, marginal_likelihoods.py:152, may pick another of them); [17] status: 0, or 1 when a
+ *             masked draw's chi^2 was never written by any pass of the likelihood (an internal error:
+ *             lnZ is NaN then and the caller must not use the record)
  *   out_flag  HOST, [1]: trx_draw_args.flag
  * Nothing inside the call waits for the device: the masked counts stay there (the likelihood kernels
  * read them from device memory and their grids are sized for a guess), so trx_scenario_evidence is the
  * enqueue below followed by ONE hipStreamSynchronize, after which `out` is filled. */
-#define TRX_SCENARIO_OUT 16
+#define TRX_SCENARIO_OUT 18
 typedef struct {
     const trx_draw_args* draw;
     const double* time;          /* [n_time] device */
@@ -365,6 +372,13 @@ size_t trx_scenario_args_size(void);
  * the number of calls that were). */
 int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, double* const* out, void* const* streams,
                      int* n_done);
+/* Consecutive calls of a trx_star_enqueue that sit on ONE stream and share N, the time stamps (pointer and length),
+ * exptime, nsupersample and the precision flag are enqueued as one LAUNCH CHAIN: every kernel of the path once, with
+ * the call / branch as a further grid dimension (up to 16 calls or 24 branches per chain; ~11 launches instead of
+ * 9-17 per call).  Same records, bit for bit.  The calls of a chain run side by side: `out` of all of them is valid
+ * once the stream has passed the call.  trx_set_star_chain(0) enqueues call by call as before (tests, A/B runs;
+ * TRX_STAR_CHAIN=0 in the environment sets the initial value). */
+int trx_set_star_chain(int on);
 
 /* Frees the per-stream scratch described above (every device); all streams must be idle. */
 int trx_release_scratch(void);

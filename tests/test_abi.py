@@ -44,7 +44,7 @@ def test_struct_bindings_match_the_library_layout():
     L.trx_scenario_args_size.restype = ctypes.c_size_t
     assert L.trx_draw_args_size() == ctypes.sizeof(fused.DrawArgs)
     assert L.trx_scenario_args_size() == ctypes.sizeof(fused.ScenarioArgs)
-    assert fused.SCENARIO_OUT == 16
+    assert fused.SCENARIO_OUT == 18
     # bad arguments are rejected before anything touches a device
     assert L.trx_scenario_evidence(None, None) != 0
 

@@ -701,6 +701,14 @@ struct TierTable {
     double x[kTiers * kTierMaxNodes];      // node offsets / exptime, ascending in time
     double w[kTiers * kTierMaxNodes];      // weights of the flux deficits 1 - f
 };
+// What of the table rides in a kernel's argument block: the node counts and radii (read with constant indices only,
+// so a kernel that patches a local copy of its arguments keeps them in scalar registers).  The nodes and weights --
+// indexed by a lane -- live in device memory, [kTiers * kTierMaxNodes] (offset, weight) pairs, staged in LDS by
+// cells_kernel.
+struct TierHead {
+    int n[kTiers];
+    double radius[kTiers];
+};
 
 // What one (row, time) cell has to evaluate: n nodes of tier `tier` (-1 = all S sub-exposures),
 // or nothing (n = 0: the exposure is unocculted and its mean flux is exactly 1).
@@ -713,7 +721,7 @@ struct CellPlan {
 
 template <bool CHECK_WINDOW = true, bool FREEZE = false>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
-                                              const TierTable& tt, bool use_tiers, double st_radius = 0.0)
+                                              const TierHead& tt, bool use_tiers, double st_radius = 0.0)
 {
     CellPlan p;
     const double phase = c.nmot * (t - c.t0);
@@ -766,23 +774,29 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
         return G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
     };
     static_assert(kTiers == 7, "bisection over seven tiers");
-    if (tt.n[kTiers - 1] > 0) {
-        const bool ok3 = admissible(tt.radius[3]);
-        const bool ok1 = admissible(ok3 ? tt.radius[1] : tt.radius[5]);
-        const bool ok2 = admissible(ok3 ? (ok1 ? tt.radius[0] : tt.radius[2]) : (ok1 ? tt.radius[4] : tt.radius[6]));
+    // (the table's entries as VALUES, read with literal indices before any choice is made: `c ? tt.radius[1] : tt.radius[5]`
+    // is a choice between two ADDRESSES to the compiler, and a loop over q an indexed one -- either keeps a kernel's
+    // patched local copy of its argument block (star_args, trx_kernels.hip) from being split into registers, and the
+    // whole block then lives in scratch memory)
+    const int n0 = tt.n[0], n1 = tt.n[1], n2 = tt.n[2], n3 = tt.n[3], n4 = tt.n[4], n5 = tt.n[5], n6 = tt.n[6];
+    const double r0 = tt.radius[0], r1 = tt.radius[1], r2 = tt.radius[2], r3 = tt.radius[3], r4 = tt.radius[4],
+                 r5 = tt.radius[5], r6 = tt.radius[6];
+    if (n6 > 0) {
+        const bool ok3 = admissible(r3);
+        const bool ok1 = admissible(ok3 ? r1 : r5);
+        const bool ok2 = admissible(ok3 ? (ok1 ? r0 : r2) : (ok1 ? r4 : r6));
         const int q = (ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)) + (ok2 ? 0 : 1);      // first admissible tier, 7 = none
         if (q < kTiers) {
             p.tier = q;
-            p.n = (q < 4) ? ((q < 2) ? (q == 0 ? tt.n[0] : tt.n[1]) : (q == 2 ? tt.n[2] : tt.n[3]))
-                          : ((q < 6) ? (q == 4 ? tt.n[4] : tt.n[5]) : tt.n[6]);
+            p.n = (q < 4) ? ((q < 2) ? (q == 0 ? n0 : n1) : (q == 2 ? n2 : n3))
+                          : ((q < 6) ? (q == 4 ? n4 : n5) : n6);
         }
     } else {
-#pragma unroll
-        for (int q = kTiers - 1; q >= 0; --q) {
-            // scanned from the largest node count down
-            const bool ok = tt.n[q] > 0 && admissible(tt.radius[q]);
-            if (ok) { p.tier = q; p.n = tt.n[q]; }
-        }
+        // scanned from the largest node count down
+#define TRX_TIER_TRY(q, nq, rq) { const bool ok = nq > 0 && admissible(rq); if (ok) { p.tier = q; p.n = nq; } }
+        TRX_TIER_TRY(6, n6, r6) TRX_TIER_TRY(5, n5, r5) TRX_TIER_TRY(4, n4, r4) TRX_TIER_TRY(3, n3, r3)
+        TRX_TIER_TRY(2, n2, r2) TRX_TIER_TRY(1, n1, r1) TRX_TIER_TRY(0, n0, r0)
+#undef TRX_TIER_TRY
     }
     // the same test at the radius the centre-value stencil of a dense uniform time grid needs
     if (st_radius > 0.0) p.st_ok = admissible(st_radius);
@@ -846,7 +860,7 @@ __device__ __forceinline__ double disc_flux(double z, double k, const Limb& L, c
 // the time axis of the light curve goes through the packed path of rows_kernel.
 __device__ __forceinline__ double exposure_flux(const RowC& c, const Limb& L, double t,
                                                 double exptime, int S, double dS, double rS, bool stepping,
-                                                const TierTable& tt)
+                                                const TierHead& tt)
 {
     CellPlan p = plan_cell(c, t, exptime, S, tt, false);
     if (p.n == 0) return 1.0;
@@ -910,35 +924,42 @@ __device__ __forceinline__ bool argmin_before(double a, long ia, double b, long 
 //   the first minimum of chi^2 (NaN first, ties to the lowest index: numpy's / torch's argmin), and the record
 //     res[0 .. ncol)  the best draw's columns (draw 0 when no draw passed the mask)
 //     res[ncol]       lnZ          res[ncol + 1]  the masked count
+//     res[16]         rows that hold the smallest chi^2 (> 1: the best draw is the first of an exact tie)
+//     res[17]         status: 1 = a row of the branch was never written by any likelihood pass (lnZ is NaN then)
 //     flag_out[0]     the limb-darkening flag of the draw kernel (branch 0 writes it)
 // `res` may be pinned host memory (the record then needs no copy).  `state` is the persistent block at the head of
 // the stream's scenario scratch: [0] the counter of finished blocks, [1] the draw kernel's flag -- both are left at
 // zero for the next call (the last branch of a call clears the flag).
-constexpr int kScenRecord = 16;       // TRX_SCENARIO_OUT
+constexpr int kScenRecord = 18;       // TRX_SCENARIO_OUT
+constexpr int kScenTies = 16, kScenStatus = 17;
 struct ScenFinal {
     const int* idx;                   // the branch's list of masked draws
     const double* cols;               // [ncol][N]
     long N, n_total;
     int ncol, branch, last_branch;
     double* res;                      // this branch's record
-    double* flag_out;                 // where the flag goes (as a double), or null
-    unsigned* state;                  // persistent: [0] finished blocks, [1] flag
+    double* flag_out;                 // where the flag goes (as a double), or null: branch 0 reads it and clears it
+    unsigned* state;                  // persistent: [0] finished blocks of THIS branch, [1] the call's flag (branch 0's block)
 };
 
 __device__ __forceinline__ void scenario_final(const ScenFinal& f, const double* __restrict__ w,
                                                const double* __restrict__ pv, const long* __restrict__ pi,
-                                               const long n, const int lane)
+                                               const long* __restrict__ pc, const long n, const int lane)
 {
     const int nparts = lme_blocks(n);
     Lme t{-INFINITY, 0.0, 0};
     double bv = INFINITY;
-    long bi = -1;
+    long bi = -1, bc = 0;
     if (n > 0) {
         for (int i = lane; i < nparts; i += 64) {
-            Lme o{w[3 * i], w[3 * i + 1], w[3 * i + 2] != 0.0};
+            Lme o{w[3 * i], w[3 * i + 1], (int)w[3 * i + 2]};
             lme_merge(t, o);
             const long oi = pi[i];
-            if (oi >= 0 && (bi < 0 || argmin_before(pv[i], oi, bv, bi))) { bv = pv[i]; bi = oi; }
+            if (oi >= 0) {
+                if (bi < 0) { bv = pv[i]; bi = oi; bc = pc[i]; }
+                else if (pv[i] == bv || (pv[i] != pv[i] && bv != bv)) { bc += pc[i]; bi = oi < bi ? oi : bi; }
+                else if (argmin_before(pv[i], oi, bv, bi)) { bv = pv[i]; bi = oi; bc = pc[i]; }
+            }
         }
     }
 #pragma unroll
@@ -950,19 +971,31 @@ __device__ __forceinline__ void scenario_final(const ScenFinal& f, const double*
         lme_merge(t, other);
         const double ov = __shfl_xor(bv, o, 64);
         const long oi = __shfl_xor(bi, o, 64);
-        if (oi >= 0 && (bi < 0 || argmin_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+        const long oc = __shfl_xor(bc, o, 64);
+        if (oi >= 0) {
+            if (bi < 0) { bv = ov; bi = oi; bc = oc; }
+            else if (ov == bv || (ov != ov && bv != bv)) { bc += oc; bi = oi < bi ? oi : bi; }
+            else if (argmin_before(ov, oi, bv, bi)) { bv = ov; bi = oi; bc = oc; }
+        }
     }
     double lnz;
-    if (t.pinf) lnz = INFINITY;                                   // _numerics.py:46-47
+    const bool unwritten = (t.pinf & 2) != 0;                     // a row no likelihood pass wrote (rowc_kernel's mark)
+    if (unwritten) lnz = NAN;
+    else if (t.pinf & 1) lnz = INFINITY;                          // _numerics.py:46-47
     else if (t.m == -INFINITY) lnz = -INFINITY;                   // :49-50
     else lnz = log(t.s) + t.m - log((double)f.n_total);           // :51
     const long best = (bi >= 0) ? (long)f.idx[bi] : 0;
     if (lane < f.ncol) f.res[lane] = f.cols[(long)lane * f.N + best];
     if (lane == f.ncol) f.res[f.ncol] = lnz;
     if (lane == f.ncol + 1) f.res[f.ncol + 1] = (double)n;
+    if (lane == 62) {
+        f.res[kScenTies] = (double)bc;
+        f.res[kScenStatus] = unwritten ? 1.0 : 0.0;
+    }
     if (lane == 63) {
-        if (f.flag_out) f.flag_out[0] = (double)f.state[1];
-        if (f.last_branch) f.state[1] = 0u;
+        // (the flag belongs to the call: the branch that reports it -- branch 0 -- also clears it; with the branches of a
+        // call reduced side by side in one launch the other branch must not touch it)
+        if (f.flag_out) { f.flag_out[0] = (double)f.state[1]; f.state[1] = 0u; }
         f.state[0] = 0u;
     }
 }

@@ -618,7 +618,7 @@ __device__ __forceinline__ void stage_tables(const trx_draw_args& a, Tables& T)
 // mapping of draws to threads changes no result.  (Three kernels, not one with branches: with two inlined
 // copies of the draw in one kernel the compiler moved the 1.2 KB argument block into scratch memory.)
 template <int KIND>
-__global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restrict__ blk_cnt, long per)
+__device__ __forceinline__ void draw_body(const trx_draw_args& a, int* __restrict__ blk_cnt, long per)
 {
     __shared__ Tables T;
     __shared__ int wave_cnt[2][4];
@@ -679,6 +679,21 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restr
     }
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restrict__ blk_cnt, long per)
+{
+    draw_body<KIND>(a, blk_cnt, per);
+}
+
+// One launch chain for several lnZ_* calls (trx_star_enqueue): the call is the grid's second dimension and its
+// argument block -- 1.2 KB, too large for several to ride in one kernel's argument buffer -- is read from a table in
+// DEVICE memory (uniform addresses: scalar loads, and none of the block is held in registers across the draw).
+template <int KIND>
+__global__ __launch_bounds__(256) void draw_kernel_star(const trx_draw_args* __restrict__ tab, int* __restrict__ blk_cnt_all, long per)
+{
+    draw_body<KIND>(tab[blockIdx.y], blk_cnt_all + (long)blockIdx.y * 2 * trx::kDrawMaxGroups, per);
+}
+
 // Ordered compaction of the geometry mask(s) AND the columns / prior of the draws that passed, in one kernel
 // (compact_kernel + fill_kernel until round 3: two launches, two tails).  grid = (chunks, branches), one wave per
 // workgroup.  Workgroup (c, br) owns `gper` consecutive workgroups' worth of draw_kernel's draws, [c gper per,
@@ -690,9 +705,9 @@ __global__ __launch_bounds__(256) void draw_kernel(trx_draw_args a, int* __restr
 // writing the columns and the prior.  A draw passes at most one of the two masks of a binary scenario.  Draw 0 is
 // always filled: it stands in for the best draw of a branch no draw passed.
 constexpr int kFillList = 128;
-__global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long per, int groups, int gper,
-                                                          const int* __restrict__ blk_cnt, int* __restrict__ idx0,
-                                                          int* __restrict__ idx1, long* __restrict__ n_out)
+__device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long per, int groups, int gper,
+                                                  const int* __restrict__ blk_cnt, int* __restrict__ idx0,
+                                                  int* __restrict__ idx1, long* __restrict__ n_out)
 {
     __shared__ Tables T;
     __shared__ int hits[kFillList];
@@ -755,6 +770,28 @@ __global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long 
         nh -= take;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long per, int groups, int gper,
+                                                          const int* __restrict__ blk_cnt, int* __restrict__ idx0,
+                                                          int* __restrict__ idx1, long* __restrict__ n_out)
+{
+    compact_fill_body(a, per, groups, gper, blk_cnt, idx0, idx1, n_out);
+}
+
+// chain: grid = (draw workgroups, 2 branches, calls); a planet call has one branch and one draw workgroup per wave
+struct FillTab {
+    trx::ChainFill f[trx::kChainMaxCalls];
+};
+__global__ __launch_bounds__(64) void compact_fill_kernel_star(const trx_draw_args* __restrict__ tab, FillTab ft, long per, int groups,
+                                                               const int* __restrict__ blk_cnt_all)
+{
+    const trx_draw_args& a = tab[blockIdx.z];
+    const int gper = a.planet ? 1 : 2;
+    if (a.planet && blockIdx.y) return;
+    if ((int)blockIdx.x * gper >= groups) return;
+    const trx::ChainFill& f = ft.f[blockIdx.z];
+    compact_fill_body(a, per, groups, gper, blk_cnt_all + (long)blockIdx.z * 2 * trx::kDrawMaxGroups, f.idx0, f.idx1, f.n_dev);
 }
 
 }  // namespace
@@ -821,5 +858,34 @@ int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* b
     const int chunks = (groups + gper - 1) / gper;
     hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks, a.planet ? 1u : 2u), dim3(64), 0, st, a, per, groups, gper,
                        blk_cnt, idx0, idx1, n_dev);
+    return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
+}
+
+// The draw kernels of a chain (trx_internal.hpp): masks of every draw of every call, then the ordered lists and the
+// columns of the draws that passed -- two launches for all the calls.
+int trx::draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab, int n_calls, int* blk_cnt,
+                    const ChainFill* fills, long* per_out, int* groups_out, hipStream_t st)
+{
+    if (!host_args || !dev_tab || !blk_cnt || !fills || n_calls < 1 || n_calls > kChainMaxCalls) return TRX_ERR_ARG;
+    const long N = host_args[0].N;
+    if (N < 1) return TRX_ERR_ARG;
+    bool pretest = true;
+    FillTab ft{};
+    for (int i = 0; i < n_calls; ++i) {
+        if (host_args[i].N != N) return TRX_ERR_ARG;
+        if (int rc = check_draw_args(host_args[i])) return rc;
+        if (!fills[i].idx0 || !fills[i].n_dev || (!host_args[i].planet && !fills[i].idx1)) return TRX_ERR_ARG;
+        pretest = pretest && host_args[i].pretest;
+        ft.f[i] = fills[i];
+    }
+    long per = (N + kDrawMaxGroups - 1) / kDrawMaxGroups;
+    per = ((per + 255) / 256) * 256;
+    const int groups = (int)((N + per - 1) / per);
+    if (pretest) hipLaunchKernelGGL(draw_kernel_star<2>, dim3((unsigned)groups, (unsigned)n_calls), dim3(256), 0, st, dev_tab, blk_cnt, per);
+    else         hipLaunchKernelGGL(draw_kernel_star<1>, dim3((unsigned)groups, (unsigned)n_calls), dim3(256), 0, st, dev_tab, blk_cnt, per);
+    hipLaunchKernelGGL(compact_fill_kernel_star, dim3((unsigned)groups, 2u, (unsigned)n_calls), dim3(64), 0, st, dev_tab, ft, per, groups,
+                       (const int*)blk_cnt);
+    *per_out = per;
+    *groups_out = groups;
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }

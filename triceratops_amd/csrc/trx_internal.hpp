@@ -7,17 +7,19 @@
 
 namespace trx {
 
+struct ScenFinal;      // trx_device.hpp
+
 // Per-(device, stream) scratch owned by the library.  Work on one stream is ordered, so a buffer can
 // serve call after call on that stream without any allocator traffic; it only grows (the stream is
 // synchronised first, then hipFree + hipMalloc), and it is released by trx_release_scratch().
 //   slot 0  row-constant blocks of a likelihood call (rowc_kernel -> cells_kernel)
 //   slot 1  trx_scenario_evidence: buffers sized by the number of draws
-//   slot 2  (unused since round 3: the masked draws are read in place)
+//   slot 2  trx_star_enqueue: the arena of a launch chain (several calls' buffers side by side)
 //   slot 3  (host, pinned) small results on their way back
 constexpr int kScratchSlots = 4;
 // The first kScratchZeroed bytes of a device slot are zero when the buffer is handed out for the first time and
 // after every growth (cleared on the stream): persistent counters that the kernels themselves leave at zero.
-constexpr size_t kScratchZeroed = 256;
+constexpr size_t kScratchZeroed = 4096;
 hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out);
 
 // Held while a call enqueues its kernels on `st`: two host threads that share a stream take turns, so
@@ -52,10 +54,51 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
 // amin_pv / amin_pi [2048]; lme_blocks(*n_dev) of them are valid.
 // fin.state != null: the block that finishes last also folds the partials into the branch's record
 // (scenario_final, trx_device.hpp).
-struct ScenFinal;
 int lme_draws(const double* halfchi2, const double* lnprior, double lnsigma, long n_upper, const long* n_dev,
               const int* src_idx, double* ws, double* amin_pv, long* amin_pi, const double* bounds_base,
               const ScenFinal& fin, hipStream_t st);
+
+// ---- one launch chain for several lnZ_* calls (trx_star_enqueue) -------------------------------------------------
+// A branch of a chain: what lnl_draws + lme_draws take for one branch of one call, with the branch's own scratch
+// (chain_branch_scratch_bytes(N) bytes; `scan_count` = 8 bytes that are zero before the chain's first use of them and
+// at a place nothing else ever occupies) and reduction buffers (ws [3 * 2048], amin_pv [2048], amin_pi [2 * 2048]).
+struct ChainBranch {
+    int model, flags, twin;
+    const double* flux;
+    double sigma, lnsigma;
+    const double* cols;            // the call's [ncol][N] column block
+    const long* n_dev;
+    const int* src_idx;
+    double* h;
+    const double* lnprior;         // per draw, or null
+    double* scratch;
+    unsigned long long* scan_count;
+    double* ws;
+    double* amin_pv;
+    long* amin_pi;
+    const ScenFinal* fin;
+};
+constexpr int kChainNotApplicable = -1;
+constexpr int kChainMaxCalls = 16, kChainMaxBranchesHost = 24;
+size_t chain_branch_scratch_bytes(long n_upper);
+// would lnl_lme_chain take these rows?  (the bounded evaluation's passes apply: see lnl_lme_chain)
+bool lnl_chain_applicable(int flags, int n_time, long N, int S);
+// A block of pinned host memory for a small upload enqueued on `st` right away: begin -> fill the block ->
+// hipMemcpyAsync(..., st) -> end (records an event: the block is handed out again only after the copy has run).
+// A ring of blocks per (device, stream); begin waits for the oldest copy when all are in flight.
+hipError_t pinned_stage_begin(hipStream_t st, size_t bytes, void** block, void** ticket);
+void pinned_stage_end(hipStream_t st, void* ticket);
+int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time, long N, double exptime, int S,
+                  hipStream_t st);
+// the draw kernels of a chain's calls, the call as the grid's second (draw) / third (fill) dimension: `tab` = the calls'
+// argument blocks in DEVICE memory (output pointers set), blk_cnt [n_calls][2 * kDrawMaxGroups]
+struct ChainFill {
+    int* idx0;
+    int* idx1;
+    long* n_dev;
+};
+int draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab, int n_calls, int* blk_cnt, const ChainFill* fills,
+               long* per_out, int* groups_out, hipStream_t st);
 
 // trx_draw_scenario with the first half of the ordered compaction: workgroup b takes the draws
 // [b * per, (b + 1) * per) and leaves its mask counts in blk_cnt[b] / blk_cnt[groups + b] (twin branch)

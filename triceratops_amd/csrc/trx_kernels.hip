@@ -74,7 +74,9 @@ struct RowsArgs {
     int B;
     long nbatch;
     int use_tiers, debug_nodes;
+    int debug_bug;     // trx_set_debug_bug (tests): see cells_entry
     int need_sec;      // rowc_kernel: run the secondary-eclipse scan (EB rows whose depth is used)
+    int mark_unwritten;   // rowc_kernel (likelihood launches): fill out[] with the "never written" mark (kUnwrittenBits)
     int use_stencil;   // 0: no stencil.  rowc_kernel looks for a dense uniform time grid (centre-value stencil,
                        // cells_kernel<LONG>); 1: both instantiations of cells_kernel are enqueued and the one
                        // that does not apply returns; 2: only the instantiation the memo predicts is enqueued
@@ -109,11 +111,38 @@ struct RowsArgs {
     unsigned long long* surv_count;      // ... and their number (zeroed by pilot_stats_kernel)
     int* probe_list;                     // split: the rows behind the pilot that the depth screen did not settle
     unsigned long long* probe_count;     // (depth_screen_kernel; zeroed by pilot_stats_kernel)
-    TierTable tiers;
+    TierHead tiers;                      // node counts and radii of the Gauss tiers ...
+    const double* tier_xw;               // ... and their (node offset, weight) pairs in device memory (tier_device)
     // wave-uniform fp64 values precomputed on the host: fp64 arithmetic has no scalar unit, so
     // computing them in the kernel parks them in long-lived vector registers
     double s2, rs2, dS, rS;      // sigma^2, 1 / sigma^2, S, 1 / S
 };
+
+// One launch chain for several lnZ_* branches (trx_star_enqueue, trx_scenario.hip): the kernels of the likelihood path
+// take the branch as the grid's SECOND dimension.  What the branches of a chain share -- the time stamps, the launch
+// geometry, the LDS layout, the node tables -- rides in one RowsArgs; what differs sits in a table of small blocks in
+// the SAME argument buffer (scalar loads at a dynamic offset: still scalar registers, pointers still known to be global
+// memory, no upload), and a kernel patches a local copy of the common block with the entry of its blockIdx.y.
+#ifndef TRX_CHAIN_MAX_BRANCHES
+#define TRX_CHAIN_MAX_BRANCHES 24
+#endif
+struct BranchArgs {
+    int model, flags, twin_cols, need_sec;
+    const double* flux;
+    double sigma, s2, rs2, prune_c0;
+    const double* params;
+    double* out;
+    const long* n_dev;
+    const int* src_idx;
+    const double* prune_lp;
+    double* scratch;           // [lists | row blocks | launch header] of this branch (set_scratch)
+    unsigned long long* scan_count;   // the scan's persistent counter, at a place that no other layout ever uses
+};
+constexpr int kChainMaxBranches = TRX_CHAIN_MAX_BRANCHES;
+struct BranchTab {
+    BranchArgs b[kChainMaxBranches];
+};
+static_assert(sizeof(RowsArgs) + sizeof(BranchTab) + 16 <= 4096, "kernel argument buffer");
 
 // a wave-uniform double moved to a scalar register pair
 __device__ __forceinline__ double uniform(double v)
@@ -160,7 +189,7 @@ constexpr int kStatShards = 256, kStatPad = 16;
 __device__ unsigned long long g_row_stats[2][kStatShards][kStatPad];       // [0] skipped, [1] abandoned
 __device__ __forceinline__ void add_row_stat(int which, unsigned count)
 {
-    if (count) atomicAdd(&g_row_stats[which][blockIdx.x & (kStatShards - 1)][0], (unsigned long long)count);
+    if (count) atomicAdd(&g_row_stats[which][(blockIdx.x + 41u * blockIdx.y) & (kStatShards - 1)][0], (unsigned long long)count);
 }
 
 // radius-ratio rule of the reference (likelihoods.py:122-123 scalar, :406/:418 vector)
@@ -212,6 +241,7 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 #ifndef TRX_BATCH_WAVES
 #define TRX_BATCH_WAVES 4
 #endif
+
 constexpr int kBatchWaves = TRX_BATCH_WAVES;
 __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows ? 1 : kBatchWaves; }
 #ifndef TRX_CELLS_WAVES_PER_EU
@@ -365,6 +395,37 @@ static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 // Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
 // depend on the row count, which may only be known on the device): one 64-bit counter, then one int per row.
 __host__ __device__ inline size_t scan_list_doubles(long n_upper) { return 2 + (size_t)(n_upper + 1) / 2; }
+// A likelihood launch's scratch: [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list,
+// probe counter, probe list) | row blocks | launch header], for a.n rows at most (a.split set).
+__host__ __device__ inline size_t launch_scratch_doubles(long n_upper, bool split)
+{
+    return scan_list_doubles(n_upper) * (split ? 3 : 1) + (size_t)n_upper * kRowDoubles + kHdrDoubles;
+}
+__host__ __device__ inline void set_scratch(RowsArgs& a, double* scratch)
+{
+    const size_t list_doubles = scan_list_doubles(a.n);
+    const bool split = a.split != 0;
+    a.scan_count = reinterpret_cast<unsigned long long*>(scratch);
+    a.scan_list = reinterpret_cast<int*>(scratch + 2);
+    a.surv_count = split ? reinterpret_cast<unsigned long long*>(scratch + list_doubles) : nullptr;
+    a.surv_list = split ? reinterpret_cast<int*>(scratch + list_doubles + 2) : nullptr;
+    a.probe_count = split ? reinterpret_cast<unsigned long long*>(scratch + 2 * list_doubles) : nullptr;
+    a.probe_list = split ? reinterpret_cast<int*>(scratch + 2 * list_doubles + 2) : nullptr;
+    a.rowc = scratch + list_doubles * (split ? 3 : 1);
+}
+// the arguments of branch blockIdx.y of a chain (see BranchArgs): the common block patched with the branch's own
+__device__ __forceinline__ RowsArgs star_args(const RowsArgs& common, const BranchTab& bt, int part)
+{
+    RowsArgs a = common;
+    const BranchArgs& b = bt.b[blockIdx.y];
+    a.model = b.model; a.flags = b.flags; a.twin_cols = b.twin_cols; a.need_sec = b.need_sec;
+    a.flux = b.flux; a.sigma = b.sigma; a.s2 = b.s2; a.rs2 = b.rs2; a.prune_c0 = b.prune_c0;
+    a.params = b.params; a.out = b.out; a.n_dev = b.n_dev; a.src_idx = b.src_idx; a.prune_lp = b.prune_lp;
+    a.part = part;
+    set_scratch(a, b.scratch);
+    a.scan_count = b.scan_count;
+    return a;
+}
 
 // The constants of one row (lanes = rows): unit conversion (likelihoods.py:337-347, 399-411), the radius-ratio rule,
 // orbit constants and transit window, dilution, limb weights -> c.  EB rows whose secondary depth is used (need_sec)
@@ -573,8 +634,14 @@ __device__ __forceinline__ void launch_header(const RowsArgs& a, const long n)
 // chain of ~2000 fp64 instructions at a quarter of the wave slots -- 232 us per call of a 75-scenario calc_probs).
 // When the depth itself is asked for (trx_flux_grid's out_secdepth) every row is scanned: no list, no quick test, and
 // the secondary orbit is derived by the scan kernel.
+// The mark of a row no likelihood pass has written yet (a quiet NaN with a payload no arithmetic produces): rowc_kernel
+// fills a likelihood launch's chi^2 array with it, every pass overwrites its rows, and the reduction of a scenario
+// (lme_partial_kernel<SCEN>) reports a row that still carries it -- a row "never written" would otherwise read as
+// whatever the stream's previous call left there (two such bugs shipped in round 4).
+constexpr unsigned long long kUnwrittenBits = 0x7ff8dead0badc0deull;
+
 template <bool SEC>
-__global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
+__device__ __forceinline__ void rowc_body(const RowsArgs& a)
 {
     __shared__ RowC rows_out[64];
     const int lane = threadIdx.x;
@@ -624,9 +691,13 @@ __global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
                 unsigned long long at = 0;
                 if (lane == 0) at = atomicAdd(count, (unsigned long long)__popcll(mo));
                 at = __shfl(at, 0, 64);
-                if (open) list[at + lanes_below(mo)] = (int)(base + lane);
+                // (bounded: a counter left non-zero by a call that failed between this kernel and the cells_kernel that
+                // resets it must not push the list past its n_upper + 1 entries)
+                const unsigned long long slot = at + (unsigned long long)lanes_below(mo);
+                if (open && slot <= (unsigned long long)a.n) list[slot] = (int)(base + lane);
             }
         }
+        if (a.mark_unwritten && lane < nb) a.out[base + lane] = __longlong_as_double((long long)kUnwrittenBits);
         __syncthreads();
         {
             const double* src = reinterpret_cast<const double*>(rows_out);
@@ -635,6 +706,20 @@ __global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
         }
         __syncthreads();
     }
+}
+
+template <bool SEC>
+__global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
+{
+    rowc_body<SEC>(a);
+}
+
+// chain: branch = blockIdx.y; the branches that need the secondary-eclipse verdict take the SEC body
+__global__ __launch_bounds__(64) void rowc_kernel_star(RowsArgs common, BranchTab bt)
+{
+    const RowsArgs a = star_args(common, bt, 0);
+    if (a.need_sec) rowc_body<true>(a);
+    else rowc_body<false>(a);
 }
 
 // The 25-point scan of the rows rowc_kernel<true> left open (or of every row when the depth itself is asked for):
@@ -646,7 +731,7 @@ __global__ __launch_bounds__(64) void rowc_kernel(RowsArgs a)
 // the 1e5 masked draws of a lnZ_*EB call -- and a wave's work is one serial chain (orbit constants, then E x 25 / 64
 // model evaluations of ~1000 fp64 instructions each): E = 8 spreads them over eight times the waves (117 -> 30 us).
 template <int E>
-__global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
+__device__ __forceinline__ void sec_scan_body(const RowsArgs& a)
 {
     __shared__ RowC srows[E];
     __shared__ double secmin[E];
@@ -690,6 +775,19 @@ __global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
         }
         __syncthreads();
     }
+}
+
+template <int E>
+__global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
+{
+    sec_scan_body<E>(a);
+}
+
+__global__ __launch_bounds__(64) void sec_scan_kernel_star(RowsArgs common, BranchTab bt)
+{
+    const RowsArgs a = star_args(common, bt, 0);
+    if (!a.need_sec) return;
+    sec_scan_body<8>(a);
 }
 static_assert(offsetof(RowC, excl) == (kRowDoubles - 1) * sizeof(double), "excl is the last field of RowC");
 
@@ -822,10 +920,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // the node tables into LDS as (node offset, weight) pairs (one 16-byte read per pair), an entry per lane: a
     // loop on one lane was 420 wave instructions per workgroup -- 3 % of a batch at 100 points
     if (a.use_tiers) {
-        for (int i = threadIdx.x; i < kTiers * kTierMaxNodes; i += 64 * W) {
-            tier_xw[2 * i] = a.tiers.x[i];
-            tier_xw[2 * i + 1] = a.tiers.w[i];
-        }
+        for (int i = threadIdx.x; i < 2 * kTiers * kTierMaxNodes; i += 64 * W) tier_xw[i] = a.tier_xw[i];
     }
     if (threadIdx.x < kAtanRanges * kAtanCols) atab[threadIdx.x] = kAtanTable[threadIdx.x];
     const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -874,13 +969,19 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const int* rlist = nullptr;        // split, part 3: the rows of this launch are rlist[row0 .. row1)
     if (PRUNE && a.part) {
         const long np = n < kPilotRows ? n : kPilotRows;
+        // (the argument block's pointers as values first: a choice between a.probe_list and a.surv_list made on the
+        // fields themselves is a choice between two addresses INSIDE the block -- see plan_cell)
+        const int* const probe_list = a.probe_list;
+        const int* const surv_list = a.surv_list;
+        const unsigned long long* const probe_count = a.probe_count;
+        const unsigned long long* const surv_count = a.surv_count;
         if (a.part == 1) row1 = np;
         else if (a.part == 2) {
             // (split: the probe pass takes the rows depth_screen_kernel listed; when nothing is probed it leaves below)
-            if (a.split && hdr[kHdrProbe] != 0.0) { rlist = a.probe_list; row1 = (long)*a.probe_count; }
+            if (a.split && hdr[kHdrProbe] != 0.0) { rlist = probe_list; row1 = (long)*probe_count; }
             else row0 = np;
         }
-        else if (hdr[kHdrProbe] != 0.0) { rlist = a.surv_list; row1 = (long)*a.surv_count; }
+        else if (hdr[kHdrProbe] != 0.0) { rlist = surv_list; row1 = (long)*surv_count; }
         else row0 = np;                // (no probe pass was run: every row behind the pilot, as they come)
         if (!LONG && (a.part == 3 || (a.part == 2 && rlist))) {
             // few rows left: fewer per wave, by the host's rule for a launch of that many rows
@@ -983,7 +1084,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         // them to the end on full chunks (part 3).  Until round 3 a batch went on with its survivors alone: one or two
         // rows' cells in chunks made for six, behind a second window pass; with nine rows in ten abandoned a call got
         // 15 % faster where the arithmetic allows 2.5 x.
-        auto finish_probe = [&]() {
+        auto finish_probe = [&]() __attribute__((always_inline)) {
             const bool in_batch = lane < nb;
             const bool is_dead = (deadmask >> lane) & 1ull, is_excl = (exclmask >> lane) & 1ull;
             const bool alive = in_batch && !is_dead && !is_excl;
@@ -1413,7 +1514,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // took 97 VGPRs, one more than five waves allow on 512 registers in granules of 8; for five it takes 95, no scratch:
 // the unprobed full evaluations of its third pass gain 8 %, profiles/r04_ab_waves5.txt.)
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
-__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+__device__ __forceinline__ void cells_entry(const RowsArgs& a)
 {
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
     // back to zero for the next call on this stream
@@ -1441,11 +1542,10 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_
                 // (the rows of the third pass: the listed ones, or all behind the pilot; its rows per wave follow from
                 // THAT count, as in cells_body)
                 if (a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) rows_here = (long)*a.surv_count;
-#ifdef TRX_BUG_EXIT_RULE
-                if (!LONG && a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0) {        // (A/B build: round 4's first version)
-#else
-                if (!LONG) {
-#endif
+                // (a.debug_bug, trx_set_debug_bug(1): round 4's first version of this rule, which took the rows per wave from
+                // the whole row count when nothing was probed -- the last batches of the third pass were then never
+                // written; kept as a switch so that a test can show the "never written" guard catching it)
+                if (!LONG && (!a.debug_bug || a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0)) {
                     B = batch_rows(rows_here, a.n_time, a.forced_B);
                     B = B < a.B ? B : a.B;
                 }
@@ -1464,6 +1564,20 @@ __global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_
         if (!ST) st_radius = 0.0;
     }
     cells_body<MODE, STEP, FP32, LONG, ST, PRUNE>(a, st_radius);
+}
+
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
+__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel(RowsArgs a)
+{
+    cells_entry<MODE, STEP, FP32, LONG, ST, PRUNE>(a);
+}
+
+// chain (bounded evaluation only): branch = blockIdx.y, `part` = the pass (1 pilot, 2 probe pass / the rest, 3 survivors)
+template <bool FP32, bool LONG>
+__global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel_star(RowsArgs common, BranchTab bt, int part)
+{
+    const RowsArgs a = star_args(common, bt, part);
+    cells_entry<MODE_LNL, true, FP32, LONG, false, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1564,16 +1678,29 @@ __device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double 
 // its upper bound and the blocks beyond lme_blocks(n) leave at once), lnprior is indexed by the draw
 // (src_idx: the masked draws are not gathered), and the pass also finds the first minimum of h
 // (argmin partials behind the 3 * 2048 sums of the workspace).
+constexpr int kLmeMaxBlocks = 2048;
+// same value for the search of the smallest chi^2 (NaN equals NaN there: torch.argmin's order)
+__device__ __forceinline__ bool argmin_same(double a, double b) { return a == b || (a != a && b != b); }
+
+// merge of two (value, first position, number of rows holding that value) states of the search
+__device__ __forceinline__ void argmin_merge(double& v, long& i, long& c, double ov, long oi, long oc)
+{
+    if (oi < 0) return;
+    if (i < 0) { v = ov; i = oi; c = oc; return; }
+    if (argmin_same(v, ov)) { c += oc; i = oi < i ? oi : i; return; }
+    if (argmin_before(ov, oi, v, i)) { v = ov; i = oi; c = oc; }
+}
+
 template <bool SCEN>
-__global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
-                                                          const double* __restrict__ h,
-                                                          const double* __restrict__ lnprior,
-                                                          double c0, long n, int vec_ok,
-                                                          double* __restrict__ ws,
-                                                          const long* __restrict__ n_dev,
-                                                          const int* __restrict__ src_idx,
-                                                          double* __restrict__ amin_pv, long* __restrict__ amin_pi,
-                                                          const double* __restrict__ bounds_base, const ScenFinal fin)
+__device__ __forceinline__ void lme_partial_body(const double* __restrict__ logw,
+                                                 const double* __restrict__ h,
+                                                 const double* __restrict__ lnprior,
+                                                 double c0, long n, int vec_ok,
+                                                 double* __restrict__ ws,
+                                                 const long* __restrict__ n_dev,
+                                                 const int* __restrict__ src_idx,
+                                                 double* __restrict__ amin_pv, long* __restrict__ amin_pi,
+                                                 const double* __restrict__ bounds_base, const ScenFinal& fin)
 {
     typedef double dvec2 __attribute__((ext_vector_type(2)));
     Lme st{-INFINITY, 0.0, 0};
@@ -1590,8 +1717,9 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         if (blockIdx.x >= nblocks) return;
         if (bounds_base) floor_x = bounds_base[n * kRowDoubles + kHdrXmax] - 90.0;
     }
-    double amin_v = INFINITY;          // SCEN: this thread's first minimum of h
-    long amin_i = -1;
+    double amin_v = INFINITY;          // SCEN: this thread's first minimum of h ...
+    long amin_i = -1, amin_c = 0;      // ... and the number of its rows that hold that value
+    bool unwritten = false;            // SCEN: a row still carries rowc_kernel's "never written" mark
     long stride = (long)nblocks * blockDim.x;
     long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {
@@ -1654,9 +1782,14 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
                 dvec2 a = cur[u];
                 const bool ok = v + u * stride < nv;
                 if (SCEN && ok) {
+                    // (a thread meets its elements in ascending order: a later one wins only when strictly before)
                     const long e = 2 * (v + u * stride);
-                    if (amin_i < 0 || argmin_before(a.x, e, amin_v, amin_i)) { amin_v = a.x; amin_i = e; }
-                    if (argmin_before(a.y, e + 1, amin_v, amin_i)) { amin_v = a.y; amin_i = e + 1; }
+                    if (amin_i < 0 || argmin_before(a.x, e, amin_v, amin_i)) { amin_v = a.x; amin_i = e; amin_c = 1; }
+                    else if (argmin_same(a.x, amin_v)) ++amin_c;
+                    if (argmin_before(a.y, e + 1, amin_v, amin_i)) { amin_v = a.y; amin_i = e + 1; amin_c = 1; }
+                    else if (argmin_same(a.y, amin_v)) ++amin_c;
+                    unwritten = unwritten || (unsigned long long)__double_as_longlong(a.x) == kUnwrittenBits ||
+                                (unsigned long long)__double_as_longlong(a.y) == kUnwrittenBits;
                 }
                 if (h) {
                     a = c0 - a;
@@ -1713,7 +1846,8 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         if ((n & 1) && tid == 0) {
             if (SCEN) {
                 const double hv = h[n - 1];
-                if (amin_i < 0 || argmin_before(hv, n - 1, amin_v, amin_i)) { amin_v = hv; amin_i = n - 1; }
+                argmin_merge(amin_v, amin_i, amin_c, hv, n - 1, 1);
+                unwritten = unwritten || (unsigned long long)__double_as_longlong(hv) == kUnwrittenBits;
                 double x = c0 - hv;
                 if (lnprior) x += lnprior[src_idx[n - 1]];
                 if (x < floor_x) x = -INFINITY;
@@ -1731,6 +1865,7 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
             lme_fold4(st, x[0], x[1], x[2], x[3]);
         }
     }
+    if (SCEN && unwritten) st.pinf |= 2;           // (bit 1 of the flag word travels with the partials: lme_merge ORs it)
     // wave combine (fixed butterfly order => deterministic)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1743,19 +1878,20 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
     __shared__ double sm[4], ss[4];
     __shared__ int sp[4];
     __shared__ double av[4];
-    __shared__ long ai[4];
+    __shared__ long ai[4], ac[4];
     const int wave = threadIdx.x >> 6;
     if (SCEN) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ov = __shfl_xor(amin_v, o, 64);
             const long oi = __shfl_xor(amin_i, o, 64);
-            if (oi >= 0 && (amin_i < 0 || argmin_before(ov, oi, amin_v, amin_i))) { amin_v = ov; amin_i = oi; }
+            const long oc = __shfl_xor(amin_c, o, 64);
+            argmin_merge(amin_v, amin_i, amin_c, ov, oi, oc);
         }
     }
     if ((threadIdx.x & 63) == 0) {
         sm[wave] = st.m; ss[wave] = st.s; sp[wave] = st.pinf;
-        if (SCEN) { av[wave] = amin_v; ai[wave] = amin_i; }
+        if (SCEN) { av[wave] = amin_v; ai[wave] = amin_i; ac[wave] = amin_c; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1766,11 +1902,11 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         ws[3 * blockIdx.x + 2] = (double)t.pinf;
         if (SCEN) {
             double bv = av[0];
-            long bi = ai[0];
-            for (int w = 1; w < 4; ++w)
-                if (ai[w] >= 0 && (bi < 0 || argmin_before(av[w], ai[w], bv, bi))) { bv = av[w]; bi = ai[w]; }
+            long bi = ai[0], bc = ac[0];
+            for (int w = 1; w < 4; ++w) argmin_merge(bv, bi, bc, av[w], ai[w], ac[w]);
             amin_pv[blockIdx.x] = bv;
             amin_pi[blockIdx.x] = bi;
+            amin_pi[kLmeMaxBlocks + blockIdx.x] = bc;        // (the counts ride behind the positions)
         }
     }
     if (SCEN && fin.state) {
@@ -1785,9 +1921,47 @@ __global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restri
         __syncthreads();
         if (is_last && threadIdx.x < 64) {
             __threadfence();                                   // the other blocks' partials after their tickets
-            scenario_final(fin, ws, amin_pv, amin_pi, n, (int)threadIdx.x);
+            scenario_final(fin, ws, amin_pv, amin_pi, amin_pi + kLmeMaxBlocks, n, (int)threadIdx.x);
         }
     }
+}
+
+template <bool SCEN>
+__global__ __launch_bounds__(256) void lme_partial_kernel(const double* __restrict__ logw,
+                                                          const double* __restrict__ h,
+                                                          const double* __restrict__ lnprior,
+                                                          double c0, long n, int vec_ok,
+                                                          double* __restrict__ ws,
+                                                          const long* __restrict__ n_dev,
+                                                          const int* __restrict__ src_idx,
+                                                          double* __restrict__ amin_pv, long* __restrict__ amin_pi,
+                                                          const double* __restrict__ bounds_base, const ScenFinal fin)
+{
+    lme_partial_body<SCEN>(logw, h, lnprior, c0, n, vec_ok, ws, n_dev, src_idx, amin_pv, amin_pi, bounds_base, fin);
+}
+
+// chain: the reductions of all branches in one launch, branch = blockIdx.y
+struct LmeBranch {
+    const double* h;
+    const double* lnprior;
+    double c0;
+    double* ws;
+    const long* n_dev;
+    double* amin_pv;
+    long* amin_pi;
+    const double* bounds_base;
+    ScenFinal fin;             // (fin.idx is the branch's src_idx)
+};
+struct LmeTab {
+    LmeBranch b[kChainMaxBranches];
+};
+static_assert(sizeof(LmeTab) + 16 <= 4096, "kernel argument buffer");
+
+__global__ __launch_bounds__(256) void lme_partial_kernel_star(LmeTab tab, long n_upper)
+{
+    const LmeBranch& b = tab.b[blockIdx.y];
+    lme_partial_body<true>(nullptr, b.h, b.lnprior, b.c0, n_upper, 1, b.ws, b.n_dev, b.fin.idx, b.amin_pv, b.amin_pi,
+                           b.bounds_base, b.fin);
 }
 
 __global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict__ ws, int nparts,
@@ -1816,7 +1990,6 @@ __global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-constexpr int kLmeMaxBlocks = 2048;
 // Process-wide diagnostics switches (include/trx.h, "Diagnostics"): read once per enqueue, relaxed
 // atomics so that a concurrent setter is a data-race-free (if unordered) change of mode.
 std::atomic<int> g_rows_per_wave{0};  // 0 = auto
@@ -1957,6 +2130,37 @@ bool fill_tiers(TierTable& T, int S)
     return ok;
 }
 
+// The part of the table a kernel takes by value (TierHead) and a device copy of its (node, weight) pairs, one per
+// (device, S), uploaded on first use and kept for the life of the process (1.1 KB).  Returns 0, or -1 when HIP fails;
+// *usable: S is large enough for at least one tier.
+int tier_device(int S, TierHead& head, const double** xw, bool* usable)
+{
+    TierTable T;
+    *usable = fill_tiers(T, S);
+    for (int q = 0; q < kTiers; ++q) { head.n[q] = T.n[q]; head.radius[q] = T.radius[q]; }
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, double*> dev_tabs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = dev_tabs.find(std::make_pair(dev, S));
+    if (it == dev_tabs.end()) {
+        double pairs[2 * kTiers * kTierMaxNodes];
+        for (int i = 0; i < kTiers * kTierMaxNodes; ++i) { pairs[2 * i] = T.x[i]; pairs[2 * i + 1] = T.w[i]; }
+        // (legal while another stream of this thread is being captured into a graph: nothing here touches that stream)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        double* p = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), sizeof(pairs));
+        if (e == hipSuccess) e = hipMemcpy(p, pairs, sizeof(pairs), hipMemcpyHostToDevice);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) { (void)hipGetLastError(); if (p) (void)hipFree(p); return -1; }
+        it = dev_tabs.emplace(std::make_pair(dev, S), p).first;
+    }
+    *xw = it->second;
+    return 0;
+}
+
 // ---- stencil memo (see cells_kernel) ------------------------------------------------------
 struct StencilMemo {
     static constexpr int kSlots = 256;
@@ -2005,9 +2209,9 @@ thread_local bool t_last_pruned = false;
 // costs more than it saves (0.54 -> 0.73 ms), with 76 % it pays (0.59 -> 0.50), with 93 % it halves the call.  The share
 // of pilot rows 150 above the best overstates what the probe cells can prove: 0.8 for TOI-411.02, 0.995 and more for
 // the cases that gain -- hence 90 %).
-__global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
-                                                          double* __restrict__ rowc, unsigned long long* __restrict__ surv_count,
-                                                          int pstride, unsigned long long* __restrict__ probe_count)
+__device__ __forceinline__ void pilot_stats_body(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
+                                                 double* __restrict__ rowc, unsigned long long* __restrict__ surv_count,
+                                                 int pstride, unsigned long long* __restrict__ probe_count)
 {
     if (threadIdx.x == 0 && surv_count) *surv_count = 0ull;
     if (threadIdx.x == 0 && probe_count) *probe_count = 0ull;
@@ -2043,13 +2247,26 @@ __global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void pilot_stats_kernel(const double* __restrict__ h, long n, const long* __restrict__ n_dev,
+                                                          double* __restrict__ rowc, unsigned long long* __restrict__ surv_count,
+                                                          int pstride, unsigned long long* __restrict__ probe_count)
+{
+    pilot_stats_body(h, n, n_dev, rowc, surv_count, pstride, probe_count);
+}
+
+__global__ __launch_bounds__(256) void pilot_stats_kernel_star(RowsArgs common, BranchTab bt)
+{
+    const RowsArgs a = star_args(common, bt, 0);
+    pilot_stats_body(a.out, a.n, a.n_dev, a.rowc, a.surv_count, a.pstride, a.probe_count);
+}
+
 // Depth screen of the rows behind the pilot (bounded evaluation of batches; after pilot_stats_kernel, before the probe
 // pass): lanes = rows.  A row too shallow (diluted) for the data is settled by its constants alone and reports the
 // bound; the others go on the probe pass's list, one atomic per wave.  Until round 4's last day the probe pass screened
 // its own rows: with four rows in five settled (TOI-465.01's lnZ_TTP: 82 %) its batches held one live row of six, and
 // the window pass -- 64 cells at a time over ALL cells of a batch -- ran on a fifth of its lanes.
 constexpr int kScreenRows = 512;           // rows per workgroup of depth_screen_kernel (two trips per wave)
-__global__ __launch_bounds__(256) void depth_screen_kernel(RowsArgs a)
+__device__ __forceinline__ void depth_screen_body(const RowsArgs& a)
 {
     // One reservation in the probe pass's list per WORKGROUP (512 rows): a device-scope atomic on one address costs
     // ~23 ns at the memory side whoever issues it, and one per wave of 64 rows -- 1600 of them for 10^5 rows -- made
@@ -2109,6 +2326,17 @@ __global__ __launch_bounds__(256) void depth_screen_kernel(RowsArgs a)
     if (lane == 0 && n_pruned) add_row_stat(1, n_pruned);
 }
 
+__global__ __launch_bounds__(256) void depth_screen_kernel(RowsArgs a)
+{
+    depth_screen_body(a);
+}
+
+__global__ __launch_bounds__(256) void depth_screen_kernel_star(RowsArgs common, BranchTab bt)
+{
+    const RowsArgs a = star_args(common, bt, 0);
+    depth_screen_body(a);
+}
+
 // the PRUNE instantiations exist for the likelihood mode only
 template <int MODE>
 void launch_pruned(const RowsArgs& a, hipStream_t st, bool long_rows, bool fp32, unsigned grid, size_t lds)
@@ -2124,11 +2352,24 @@ void launch_pruned(const RowsArgs& a, hipStream_t st, bool long_rows, bool fp32,
     }
 }
 
+// What launch_cells and the chain launcher decide before anything is enqueued: the rows per wave and the LDS layout, the
+// node tables, whether the bounded evaluation applies, the grids.
+struct CellsPlan {
+    bool long_rows, prune, split, fp32, step;
+    size_t lds;
+    unsigned grid_main;        // cells_kernel: the full evaluation, or the passes behind the pilot
+    unsigned grid_pilot;
+    unsigned grid_rowc;        // rowc_kernel (+ 1 header workgroup)
+    unsigned grid_scan;        // sec_scan_kernel<8>
+    unsigned grid_screen;      // depth_screen_kernel
+    bool passes;               // prune: there may be rows behind the pilot (pilot_stats_kernel and the later passes run)
+};
+
+std::atomic<int> g_debug_bug{0};      // trx_set_debug_bug (tests)
+
 template <int MODE>
-int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
+int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
 {
-    trx::StreamLock turn(st);            // rowc_kernel and cells_kernel of one call share the stream's scratch
-    RowsArgs a = a0;
     // rows per wave (batch_rows); with the row count on the device the LDS layout takes the largest value
     a.forced_B = g_rows_per_wave.load(std::memory_order_relaxed);
     a.B = long_rows ? 1 : batch_rows(a.n_dev ? -1 : a.n, a.n_time, a.forced_B);
@@ -2137,22 +2378,11 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.dS = (double)a.S;
     a.rS = 1.0 / a.dS;
     a.nbatch = 8 * batch_plan(a.n, a.B).P;          // wave positions of the launch (batch_plan)
-    const long max_grid = 1L << 20;
-    // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
-    // keeps 2-11 % of them (SURVEY section 8), so the grid takes a quarter of the bound -- blocks
-    // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
-    // (a workgroup is cells_waves() waves, each with its own batches; a multiple of 8 workgroups: one per XCD)
-    auto grid_for = [&](long batches, bool long_variant, long cap) -> unsigned {
-        if (a.n_dev) {
-            batches = (batches + 3) / 4;
-            batches = batches < 4096 ? 4096 : batches;
-        }
-        const long groups = (batches + cells_waves(long_variant) - 1) / cells_waves(long_variant);
-        long want = 8 * ((groups + 7) / 8);
-        if (cap > 0 && want > cap) want = cap;
-        return (unsigned)(want < max_grid ? want : max_grid);
-    };
-    a.use_tiers = fill_tiers(a.tiers, a.S) && g_tiers.load(std::memory_order_relaxed);
+    a.debug_bug = g_debug_bug.load(std::memory_order_relaxed);
+    a.mark_unwritten = (MODE == MODE_LNL) ? 1 : 0;
+    bool tiers_ok = false;
+    if (tier_device(a.S, a.tiers, &a.tier_xw, &tiers_ok)) return fail(TRX_ERR_HIP, "tier table upload failed%s", "", 0);
+    a.use_tiers = tiers_ok && g_tiers.load(std::memory_order_relaxed);
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
     // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
     // 46 -> 39 ms; at 100 binned points the batched variant gains or loses ~3 % (the probe phase, the pilot
@@ -2169,17 +2399,6 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     a.pstride = prune ? a.n_time / 16 : 1;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
-    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
-    const bool capturing = capture == hipStreamCaptureStatusActive;
-    int verdict = 0;                       // of an earlier launch on this light curve: 1 no stencil, 2 stencil
-    if (a.use_stencil && !capturing) {     // (a captured launch always carries both instantiations)
-        int dev = 0;
-        TRX_HIP(hipGetDevice(&dev));
-        a.memo = g_stencil_memo.slot({a.time, a.n_time, a.S, dev, a.exptime});
-        if (a.memo) verdict = *static_cast<volatile int*>(a.memo);
-        if (verdict == 1 || verdict == 2) a.use_stencil = 2;
-    }
     a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
@@ -2205,51 +2424,33 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     a.wave_off = (int)(shared / sizeof(double));
     a.wave_doubles = (int)(wave_bytes(long_rows) / sizeof(double));
-    // the row constants: 152 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
-    // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
-    // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
-    void* scratch = nullptr;
-    // [scan counter, scan list | (bounded evaluation of batches: survivor counter, survivor list, probe counter, probe
-    // list) | row blocks | launch header]
-    const size_t list_doubles = scan_list_doubles(a.n);
 #ifdef TRX_NO_SPLIT
     const bool split = false;              // (A/B builds: batches probe and finish in one kernel, as in round 3)
 #else
     const bool split = prune && !long_rows;
 #endif
-    const size_t surv_doubles = split ? 2 * scan_list_doubles(a.n) : 0;
-    const size_t scratch_bytes = (list_doubles + surv_doubles + (size_t)a.n * kRowDoubles + kHdrDoubles) * sizeof(double);
-    if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
-    else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
-    a.scan_count = static_cast<unsigned long long*>(scratch);
-    a.scan_list = reinterpret_cast<int*>(static_cast<double*>(scratch) + 2);
     a.split = split ? 1 : 0;
-    a.surv_count = split ? reinterpret_cast<unsigned long long*>(static_cast<double*>(scratch) + list_doubles) : nullptr;
-    a.surv_list = split ? reinterpret_cast<int*>(static_cast<double*>(scratch) + list_doubles + 2) : nullptr;
-    a.probe_count = split ? reinterpret_cast<unsigned long long*>(static_cast<double*>(scratch) + 2 * list_doubles) : nullptr;
-    a.probe_list = split ? reinterpret_cast<int*>(static_cast<double*>(scratch) + 2 * list_doubles + 2) : nullptr;
-    a.rowc = static_cast<double*>(scratch) + list_doubles + surv_doubles;
-    {
-        long rb = (a.n + 63) / 64;
-        if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
-        if (a.need_sec) {
-            // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
-            // that follows a scan; graph memory nodes hold anything)
-            if (capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(rowc_kernel<true>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
-            // every row when the depth is asked for; else the open rows, ~3 % of the rows of a likelihood call (which
-            // are themselves ~10 % of `n` when that is only the upper bound): workgroups stride over the list
-            long sb = (a.n + 63) / 64;
-            if (!a.out_sec && a.n_dev) sb = (sb + 3) / 4;
-            sb = sb < 64 ? 64 : (sb > 8192 ? 8192 : sb);
-            if (a.out_sec) hipLaunchKernelGGL(sec_scan_kernel<64>, dim3((unsigned)sb), dim3(64), 0, st, a);
-            else           hipLaunchKernelGGL(sec_scan_kernel<8>, dim3((unsigned)sb), dim3(64), 0, st, a);
-        } else {
-            hipLaunchKernelGGL(rowc_kernel<false>, dim3((unsigned)rb + 1), dim3(64), 0, st, a);
+    P.long_rows = long_rows;
+    P.prune = prune;
+    P.split = split;
+    P.lds = lds;
+    P.fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
+    P.step = g_step.load(std::memory_order_relaxed) != 0;
+    // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
+    // keeps 2-11 % of them (SURVEY section 8), so the grid takes a quarter of the bound -- blocks
+    // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
+    // (a workgroup is cells_waves() waves, each with its own batches; a multiple of 8 workgroups: one per XCD)
+    const long max_grid = 1L << 20;
+    auto grid_for = [&](long batches, bool long_variant, long cap) -> unsigned {
+        if (a.n_dev) {
+            batches = (batches + 3) / 4;
+            batches = batches < 4096 ? 4096 : batches;
         }
-    }
-    const bool fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    const bool step = g_step.load(std::memory_order_relaxed) != 0;
+        const long groups = (batches + cells_waves(long_variant) - 1) / cells_waves(long_variant);
+        long want = 8 * ((groups + 7) / 8);
+        if (cap > 0 && want > cap) want = cap;
+        return (unsigned)(want < max_grid ? want : max_grid);
+    };
     // Workgroups beyond the batches are not free: ~2.4 ns each to dispatch and leave, and while they are dealt out they
     // hold back the workgroups of the other streams' kernels.  A grid sized for the upper bound of a row count that
     // only the device knows is mostly such workgroups (a quarter of the bound: 10 000 of them per launch at N = 10^6,
@@ -2264,27 +2465,89 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     static const long cap_plain = getenv("TRX_GRID_CAP_PLAIN") ? atol(getenv("TRX_GRID_CAP_PLAIN")) : 5120;
     static const long cap_long = getenv("TRX_GRID_CAP_LONG") ? atol(getenv("TRX_GRID_CAP_LONG")) : 16384;
     const long cap = (a.n_dev || prune) ? (long_rows ? cap_long : (prune ? cap_probe : cap_plain)) : 0;
-    const unsigned g2 = grid_for(long_rows ? a.n : a.nbatch, long_rows, cap);
+    P.grid_main = grid_for(long_rows ? a.n : a.nbatch, long_rows, cap);
+    {
+        // pilot rows (evaluated to the end; first values of the running bounds)
+        const long np = a.n < kPilotRows ? a.n : kPilotRows;
+        const long pilot_batches = (long_rows || split) ? np : (np + a.B - 1) / a.B;      // (split: one pilot row per wave)
+        const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
+        P.grid_pilot = (unsigned)(8 * ((pilot_groups + 7) / 8));
+        P.passes = a.n_dev || a.n > kPilotRows;
+    }
+    {
+        long rb = (a.n + 63) / 64;
+        if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
+        P.grid_rowc = (unsigned)rb + 1;
+        // every row when the depth is asked for; else the open rows, ~3 % of the rows of a likelihood call (which
+        // are themselves ~10 % of `n` when that is only the upper bound): workgroups stride over the list
+        long sb = (a.n + 63) / 64;
+        if (!a.out_sec && a.n_dev) sb = (sb + 3) / 4;
+        P.grid_scan = (unsigned)(sb < 64 ? 64 : (sb > 8192 ? 8192 : sb));
+        // the depth screen of the rows behind the pilot, lanes = rows; what it leaves goes to the probe pass
+        long sg = (a.n + kScreenRows - 1) / kScreenRows;
+        if (a.n_dev) sg = (sg + 3) / 4;
+        P.grid_screen = (unsigned)(sg < 8 ? 8 : (sg > 512 ? 512 : sg));
+    }
+    return TRX_OK;
+}
+
+template <int MODE>
+int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
+{
+    trx::StreamLock turn(st);            // rowc_kernel and cells_kernel of one call share the stream's scratch
+    RowsArgs a = a0;
+    CellsPlan P;
+    if (int rc = plan_cells<MODE>(a, long_rows, P)) return rc;
+    long_rows = P.long_rows;
+    const bool prune = P.prune, split = P.split, fp32 = P.fp32, step = P.step;
+    const size_t lds = P.lds;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool capturing = capture == hipStreamCaptureStatusActive;
+    int verdict = 0;                       // of an earlier launch on this light curve: 1 no stencil, 2 stencil
+    if (a.use_stencil && !capturing) {     // (a captured launch always carries both instantiations)
+        int dev = 0;
+        TRX_HIP(hipGetDevice(&dev));
+        a.memo = g_stencil_memo.slot({a.time, a.n_time, a.S, dev, a.exptime});
+        if (a.memo) verdict = *static_cast<volatile int*>(a.memo);
+        if (verdict == 1 || verdict == 2) a.use_stencil = 2;
+    }
+    // the row constants: 152 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
+    // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
+    // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
+    void* scratch = nullptr;
+    const size_t scratch_bytes = launch_scratch_doubles(a.n, split) * sizeof(double);
+    if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
+    else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
+    set_scratch(a, static_cast<double*>(scratch));
+    // From here on a failure may leave the scan's counter non-zero in the stream's scratch (rowc_kernel<true> counts,
+    // the cells_kernel behind it resets): cleared on the way out, or the next call's list would start beyond its end
+    auto fail_launch = [&](hipError_t e) {
+        if (!capturing) (void)hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st);
+        return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipGetErrorString(e), (long)e);
+    };
+    if (a.need_sec) {
+        // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
+        // that follows a scan; graph memory nodes hold anything)
+        if (capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(rowc_kernel<true>, dim3(P.grid_rowc), dim3(64), 0, st, a);
+        if (a.out_sec) hipLaunchKernelGGL(sec_scan_kernel<64>, dim3(P.grid_scan), dim3(64), 0, st, a);
+        else           hipLaunchKernelGGL(sec_scan_kernel<8>, dim3(P.grid_scan), dim3(64), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(rowc_kernel<false>, dim3(P.grid_rowc), dim3(64), 0, st, a);
+    }
+    const unsigned g2 = P.grid_main;
     t_last_rowc = a.rowc;
     t_last_pruned = prune;
     if (prune) {
         // pilot rows (evaluated to the end; first values of the running bounds), verdict on probing, the rest
-        const long np = a.n < kPilotRows ? a.n : kPilotRows;
-        const long pilot_batches = (long_rows || split) ? np : (np + a.B - 1) / a.B;      // (split: one pilot row per wave)
         RowsArgs ap = a;
         ap.part = 1;
-        const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
-        launch_pruned<MODE>(ap, st, long_rows, fp32, (unsigned)(8 * ((pilot_groups + 7) / 8)), lds);
-        if (a.n_dev || a.n > kPilotRows) {
+        launch_pruned<MODE>(ap, st, long_rows, fp32, P.grid_pilot, lds);
+        if (P.passes) {
             hipLaunchKernelGGL(pilot_stats_kernel, dim3(1), dim3(256), 0, st, a.out, a.n, a.n_dev, a.rowc, a.surv_count, a.pstride,
                                a.probe_count);
-            if (split) {
-                // the depth screen of the rows behind the pilot, lanes = rows; what it leaves goes to the probe pass
-                long sg = (a.n + kScreenRows - 1) / kScreenRows;
-                if (a.n_dev) sg = (sg + 3) / 4;
-                sg = sg < 8 ? 8 : (sg > 512 ? 512 : sg);
-                hipLaunchKernelGGL(depth_screen_kernel, dim3((unsigned)sg), dim3(256), 0, st, a);
-            }
+            if (split) hipLaunchKernelGGL(depth_screen_kernel, dim3(P.grid_screen), dim3(256), 0, st, a);
             ap.part = 2;
             launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
             if (split) {
@@ -2312,7 +2575,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     }
     const hipError_t launched = hipGetLastError();
     if (capturing) TRX_HIP(hipFreeAsync(scratch, st));
-    TRX_HIP(launched);
+    if (launched != hipSuccess) return fail_launch(launched);
     return TRX_OK;
 }
 
@@ -2356,10 +2619,17 @@ int check_rows(int model, const double* time, int n_time, const double* params, 
 // ---- per-stream scratch (trx_internal.hpp) ------------------------------------------------
 namespace trx {
 namespace {
+constexpr int kStageRing = 32;           // pinned blocks per stream for small uploads (pinned_stage_begin)
 struct ScratchEntry {
     void* p[kScratchSlots] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[kScratchSlots] = {0, 0, 0, 0};
     std::recursive_mutex mu;             // StreamLock: one call at a time enqueues on the stream
+    // ring of pinned staging blocks: a block is reused once the event recorded behind its copy has passed
+    void* stage[kStageRing] = {};
+    size_t stage_cap[kStageRing] = {};
+    hipEvent_t stage_ev[kStageRing] = {};
+    bool stage_busy[kStageRing] = {};
+    int stage_next = 0;
 };
 std::mutex g_scratch_mu;
 std::map<std::pair<int, hipStream_t>, ScratchEntry> g_scratch;      // (node addresses are stable)
@@ -2401,6 +2671,120 @@ hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
 }
 
 int fail_hip(hipError_t e) { return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipGetErrorString(e), (long)e); }
+
+hipError_t pinned_stage_begin(hipStream_t st, size_t bytes, void** block, void** ticket)
+{
+    ScratchEntry& en = *scratch_entry(st);
+    std::lock_guard<std::recursive_mutex> lock(en.mu);
+    const int k = en.stage_next;
+    en.stage_next = (k + 1) % kStageRing;
+    hipError_t e = hipSuccess;
+    if (en.stage_busy[k]) {
+        // (32 uploads ahead of the device on this stream: wait for the oldest to have been copied)
+        if ((e = hipEventSynchronize(en.stage_ev[k])) != hipSuccess) return e;
+        en.stage_busy[k] = false;
+    }
+    if (en.stage_cap[k] < bytes) {
+        if (en.stage[k]) (void)hipHostFree(en.stage[k]);
+        en.stage[k] = nullptr;
+        en.stage_cap[k] = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        if ((e = hipHostMalloc(&en.stage[k], want, hipHostMallocDefault)) != hipSuccess) return e;
+        en.stage_cap[k] = want;
+    }
+    if (!en.stage_ev[k] && (e = hipEventCreateWithFlags(&en.stage_ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+    *block = en.stage[k];
+    *ticket = reinterpret_cast<void*>((intptr_t)(k + 1));
+    return hipSuccess;
+}
+
+void pinned_stage_end(hipStream_t st, void* ticket)
+{
+    ScratchEntry& en = *scratch_entry(st);
+    std::lock_guard<std::recursive_mutex> lock(en.mu);
+    const int k = (int)(intptr_t)ticket - 1;
+    if (k < 0 || k >= kStageRing) return;
+    if (hipEventRecord(en.stage_ev[k], st) == hipSuccess) en.stage_busy[k] = true;
+    else (void)hipGetLastError();
+}
+
+bool lnl_chain_applicable(int flags, int n_time, long N, int S)
+{
+    if (N < 1 || n_time < 1 || S < 1) return false;
+    RowsArgs a{};
+    a.model = TRX_MODEL_TP; a.flags = flags; a.n_time = n_time; a.sigma = 1.0; a.n = N; a.S = S; a.exptime = 0.0;
+    static const long dummy_n = 0;
+    a.n_dev = &dummy_n;              // (never read on the host: "the row count lives on the device")
+    a.prune = 1;
+    const bool batches = n_time < g_cells_below.load(std::memory_order_relaxed);
+    CellsPlan P;
+    if (plan_cells<MODE_LNL>(a, !batches, P) != TRX_OK) return false;
+    return P.prune && P.step && P.passes;
+}
+
+size_t chain_branch_scratch_bytes(long n_upper) { return launch_scratch_doubles(n_upper, true) * sizeof(double); }
+
+// The likelihood and the reduction of every branch of a chain, one launch per stage with the branch as the grid's
+// second dimension (trx_internal.hpp).  Returns kChainNotApplicable -- nothing enqueued -- when the launch would not
+// take the bounded evaluation's passes (switched off, fewer than 48 points, a batch beyond one window): the caller
+// then enqueues the branches one by one.
+int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time, long N, double exptime, int S,
+                  hipStream_t st)
+{
+    if (!br || nbr < 1 || nbr > kChainMaxBranches) return fail(TRX_ERR_ARG, "lnl_lme_chain: bad branch count%s %ld", "", (long)nbr);
+    if (int rc = check_rows(br[0].model, time, n_time, br[0].cols, N, S)) return rc;
+    RowsArgs a{};
+    a.model = br[0].model; a.flags = br[0].flags; a.time = time; a.flux = br[0].flux; a.n_time = n_time; a.sigma = br[0].sigma;
+    a.params = br[0].cols; a.n = N; a.exptime = exptime; a.S = S; a.out = br[0].h;
+    a.n_dev = br[0].n_dev; a.src_idx = br[0].src_idx; a.src_stride = N; a.twin_cols = br[0].twin;
+    a.prune = 1;
+    const bool batches = n_time > 0 && n_time < g_cells_below.load(std::memory_order_relaxed);
+    CellsPlan P;
+    if (int rc = plan_cells<MODE_LNL>(a, !batches, P)) return rc;
+    if (!P.prune || !P.step || !P.passes) return kChainNotApplicable;
+    BranchTab bt{};
+    LmeTab lt{};
+    bool any_sec = false;
+    for (int i = 0; i < nbr; ++i) {
+        const ChainBranch& c = br[i];
+        if (c.model == TRX_MODEL_RAW || !c.n_dev || !c.src_idx || !c.h || !c.cols || !c.flux || !c.scratch || !c.scan_count ||
+            !c.ws || !c.amin_pv || !c.amin_pi || ((uintptr_t)c.h % 16) != 0 ||
+            ((c.flags ^ br[0].flags) & (TRX_FLAG_FP32_MODEL | TRX_FLAG_EVALUATE_EXCLUDED)))
+            return fail(TRX_ERR_ARG, "lnl_lme_chain: bad argument in branch%s %ld", "", (long)i);
+        BranchArgs& b = bt.b[i];
+        b.model = c.model; b.flags = c.flags; b.twin_cols = c.twin; b.need_sec = (c.model == TRX_MODEL_EB) ? 1 : 0;
+        any_sec = any_sec || b.need_sec;
+        b.flux = c.flux; b.sigma = c.sigma; b.s2 = c.sigma * c.sigma; b.rs2 = 1.0 / b.s2;
+        b.prune_c0 = -0.5 * log(kTwoPi) - c.lnsigma;
+        b.params = c.cols; b.out = c.h; b.n_dev = c.n_dev; b.src_idx = c.src_idx; b.prune_lp = c.lnprior;
+        b.scratch = c.scratch; b.scan_count = c.scan_count;
+        RowsArgs tmp = a;                       // (where set_scratch puts this branch's row blocks and header)
+        set_scratch(tmp, c.scratch);
+        LmeBranch& l = lt.b[i];
+        l.h = c.h; l.lnprior = c.lnprior; l.c0 = b.prune_c0; l.ws = c.ws; l.n_dev = c.n_dev;
+        l.amin_pv = c.amin_pv; l.amin_pi = c.amin_pi; l.bounds_base = tmp.rowc; l.fin = *c.fin;
+    }
+    const unsigned y = (unsigned)nbr;
+    hipLaunchKernelGGL(rowc_kernel_star, dim3(P.grid_rowc, y), dim3(64), 0, st, a, bt);
+    if (any_sec) hipLaunchKernelGGL(sec_scan_kernel_star, dim3(P.grid_scan, y), dim3(64), 0, st, a, bt);
+    auto cells = [&](unsigned grid, int part) {
+        if (P.long_rows) {
+            if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, true>), dim3(grid, y), dim3(64), P.lds, st, a, bt, part);
+            else        hipLaunchKernelGGL((cells_kernel_star<false, true>), dim3(grid, y), dim3(64), P.lds, st, a, bt, part);
+        } else {
+            if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, false>), dim3(grid, y), dim3(64 * kBatchWaves), P.lds, st, a, bt, part);
+            else        hipLaunchKernelGGL((cells_kernel_star<false, false>), dim3(grid, y), dim3(64 * kBatchWaves), P.lds, st, a, bt, part);
+        }
+    };
+    cells(P.grid_pilot, 1);
+    hipLaunchKernelGGL(pilot_stats_kernel_star, dim3(1, y), dim3(256), 0, st, a, bt);
+    if (P.split) hipLaunchKernelGGL(depth_screen_kernel_star, dim3(P.grid_screen, y), dim3(256), 0, st, a, bt);
+    cells(P.grid_main, 2);
+    if (P.split) cells(P.grid_main, 3);
+    hipLaunchKernelGGL(lme_partial_kernel_star, dim3((unsigned)lme_blocks(N), y), dim3(256), 0, st, lt, N);
+    TRX_HIP(hipGetLastError());
+    return TRX_OK;
+}
 
 int lnl_draws(int model, int flags, const double* time, const double* flux, int n_time, double sigma,
               const double* cols, long n_upper, const long* n_dev, const int* src_idx, long src_stride,
@@ -2679,6 +3063,12 @@ int trx_set_bounded_evaluation(int mode)
 }
 
 /* tests (include/trx.h): trx_lnl_batch / trx_lnz_scenario evaluate their rows the bounded way, too */
+int trx_set_debug_bug(int on)
+{
+    g_debug_bug = on ? 1 : 0;
+    return TRX_OK;
+}
+
 int trx_set_debug_bounded_lnl(int on)
 {
     g_prune_lnl = on ? 1 : 0;
@@ -2739,6 +3129,10 @@ int trx_release_scratch(void)
         TRX_HIP(hipSetDevice(kv.first.first));
         for (int sl = 0; sl < trx::kScratchSlots; ++sl)
             if (kv.second.p[sl]) (void)(sl == 3 ? hipHostFree(kv.second.p[sl]) : hipFree(kv.second.p[sl]));
+        for (int k = 0; k < trx::kStageRing; ++k) {
+            if (kv.second.stage[k]) (void)hipHostFree(kv.second.stage[k]);
+            if (kv.second.stage_ev[k]) (void)hipEventDestroy(kv.second.stage_ev[k]);
+        }
     }
     trx::g_scratch.clear();
     TRX_HIP(hipSetDevice(cur));

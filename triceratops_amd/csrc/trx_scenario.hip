@@ -29,6 +29,7 @@
 // fused.py (same arithmetic on the same rows in the same order).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -89,7 +90,7 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
                  o_prior = A.reserve(s->want_prior ? sizeof(double) * N : 0),
                  o_n = A.reserve(2 * sizeof(long)), o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1)),
                  o_ws = A.reserve(sizeof(double) * 2 * 3 * kLmeParts), o_pv = A.reserve(sizeof(double) * 2 * kLmeParts),
-                 o_pi = A.reserve(sizeof(long) * 2 * kLmeParts), o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups),
+                 o_pi = A.reserve(sizeof(long) * 2 * 2 * kLmeParts), o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups),
                  o_idx0 = A.reserve(sizeof(int) * N), o_idx1 = A.reserve(planet ? 0 : sizeof(int) * N),
                  o_h0 = A.reserve(sizeof(double) * N), o_h1 = A.reserve(planet ? 0 : sizeof(double) * N);
     TRXS_HIP(trx::stream_scratch(st, 1, A.used, reinterpret_cast<void**>(&A.base)));
@@ -134,12 +135,177 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         fin.state = state;
         if (int rc = trx::lme_draws(h[b], d.lnprior, s->lnsigma, N, n_dev + b, idx[b],
                                     A.at<double>(o_ws) + (size_t)b * 3 * kLmeParts, A.at<double>(o_pv) + (size_t)b * kLmeParts,
-                                    A.at<long>(o_pi) + (size_t)b * kLmeParts, bounds, fin, st))
+                                    A.at<long>(o_pi) + (size_t)b * 2 * kLmeParts, bounds, fin, st))
             return bail(rc);
     }
     if (!rec_dev)
         TRXS_HIP(hipMemcpyAsync(out_host, res, sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), hipMemcpyDeviceToHost, st));
     return TRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launch chain for several calls: draw_kernel, compact_fill_kernel, rowc_kernel, (sec_scan_kernel,) the passes of the
+// bounded evaluation and lme_partial_kernel are launched ONCE each, with the call (draw side) or the branch (likelihood
+// side) as a further grid dimension -- 11 launches and one small upload for up to 16 calls / 24 branches, where the calls
+// one by one take 9 (planet) to 17 (binary) launches EACH.  Round 4 measured why that matters (profiles/
+// r04_concurrency_levels.txt, r04_j_batch_kernel_stats.txt): the chip runs ~3 kernels at a time whatever the number of
+// streams, a 64-target step was 10 183 launches, most of them 8-45 us long on a tenth of the machine, and the host spent
+// 113 of the step's 155 ms enqueueing them.  The calls of a chain must share N, the time stamps, the exposure settings
+// and the precision flag (the calls of one target do: triceratops.py:767-1428); flux and sigma may differ (a nearby
+// star's light curve is the target's, renormalised).  Results are those of the calls one by one, bit for bit: the same
+// kernels' bodies on the same rows in the same order.
+constexpr size_t kBranchHead = 64;       // bytes of the zeroed head per branch: [scan counter | finished blocks, flag]
+static_assert(trx::kChainMaxBranchesHost * kBranchHead <= trx::kScratchZeroed, "zeroed head of the chain's arena");
+
+int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, double* const* out, hipStream_t st)
+{
+    const trx_scenario_args& s0 = calls[which[0]];
+    const long N = s0.draw->N;
+    if (N < 1 || N > 0x7fffffffL || n < 1 || n > trx::kChainMaxCalls) return TRX_ERR_ARG;
+    trx::StreamLock turn(st);
+    int nbr_total = 0;
+    for (int i = 0; i < n; ++i) nbr_total += calls[which[i]].draw->planet ? 1 : 2;
+    if (nbr_total > trx::kChainMaxBranchesHost) return TRX_ERR_ARG;
+    const size_t branch_bytes = trx::chain_branch_scratch_bytes(N);
+
+    Arena A;
+    const size_t o_head = A.reserve(trx::kScratchZeroed);
+    const size_t o_tab = A.reserve(sizeof(trx_draw_args) * (size_t)n);
+    const size_t o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups * (size_t)n);
+    struct CallOff { size_t cols, mask, mask2, prior, n, res, ws, pv, pi, idx[2], h[2]; };
+    CallOff co[trx::kChainMaxCalls];
+    for (int i = 0; i < n; ++i) {
+        const trx_scenario_args& s = calls[which[i]];
+        const int planet = s.draw->planet != 0, ncol = planet ? 11 : 14;
+        co[i].cols = A.reserve(sizeof(double) * ncol * N);
+        co[i].mask = A.reserve(N);
+        co[i].mask2 = A.reserve(planet ? 0 : N);
+        co[i].prior = A.reserve(s.want_prior ? sizeof(double) * N : 0);
+        co[i].n = A.reserve(2 * sizeof(long));
+        co[i].res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1));
+        co[i].ws = A.reserve(sizeof(double) * 2 * 3 * kLmeParts);
+        co[i].pv = A.reserve(sizeof(double) * 2 * kLmeParts);
+        co[i].pi = A.reserve(sizeof(long) * 2 * 2 * kLmeParts);
+        co[i].idx[0] = A.reserve(sizeof(int) * N);
+        co[i].idx[1] = A.reserve(planet ? 0 : sizeof(int) * N);
+        co[i].h[0] = A.reserve(sizeof(double) * N);
+        co[i].h[1] = A.reserve(planet ? 0 : sizeof(double) * N);
+    }
+    const size_t o_branch = A.reserve(branch_bytes * (size_t)nbr_total);
+    TRXS_HIP(trx::stream_scratch(st, 2, A.used, reinterpret_cast<void**>(&A.base)));
+
+    // the calls' argument blocks, output pointers set, staged in pinned memory and copied to the device table
+    trx_draw_args* stage = nullptr;
+    void* stage_ticket = nullptr;
+    TRXS_HIP(trx::pinned_stage_begin(st, sizeof(trx_draw_args) * (size_t)n, reinterpret_cast<void**>(&stage), &stage_ticket));
+    trx::ChainFill fills[trx::kChainMaxCalls];
+    trx::ChainBranch br[trx::kChainMaxBranchesHost];
+    trx::ScenFinal fin[trx::kChainMaxBranchesHost];
+    double* res_of[trx::kChainMaxCalls];
+    bool copy_back[trx::kChainMaxCalls];
+    int b_at = 0;
+    for (int i = 0; i < n; ++i) {
+        const trx_scenario_args& s = calls[which[i]];
+        trx_draw_args d = *s.draw;
+        const int planet = d.planet != 0, ncol = planet ? 11 : 14, nbr = planet ? 1 : 2;
+        if (d.N != N || s.n_time != s0.n_time || s.time != s0.time || s.nsupersample != s0.nsupersample ||
+            s.exptime != s0.exptime) return TRX_ERR_ARG;
+        double* rec_dev = nullptr;
+        {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, out[which[i]]) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer)
+                rec_dev = static_cast<double*>(attr.devicePointer);
+            else
+                (void)hipGetLastError();
+        }
+        copy_back[i] = rec_dev == nullptr;
+        double* res = rec_dev ? rec_dev : A.at<double>(co[i].res);
+        res_of[i] = res;
+        unsigned* state0 = reinterpret_cast<unsigned*>(A.base + o_head + (size_t)b_at * kBranchHead + 8);
+        d.cols = A.at<double>(co[i].cols);
+        d.mask = A.at<unsigned char>(co[i].mask);
+        d.mask_twin = planet ? nullptr : A.at<unsigned char>(co[i].mask2);
+        d.lnprior = s.want_prior ? A.at<double>(co[i].prior) : nullptr;
+        d.flag = reinterpret_cast<int*>(state0 + 1);
+        d.dump = nullptr;
+        stage[i] = d;
+        long* n_dev = A.at<long>(co[i].n);
+        fills[i] = trx::ChainFill{A.at<int>(co[i].idx[0]), planet ? nullptr : A.at<int>(co[i].idx[1]), n_dev};
+        for (int b = 0; b < nbr; ++b, ++b_at) {
+            char* head = A.base + o_head + (size_t)b_at * kBranchHead;
+            trx::ChainBranch& c = br[b_at];
+            c.model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
+            c.flags = s.flags;
+            c.twin = b;
+            c.flux = s.flux;
+            c.sigma = s.sigma;
+            c.lnsigma = s.lnsigma;
+            c.cols = d.cols;
+            c.n_dev = n_dev + b;
+            c.src_idx = A.at<int>(co[i].idx[b]);
+            c.h = A.at<double>(co[i].h[b]);
+            c.lnprior = d.lnprior;
+            c.scratch = reinterpret_cast<double*>(A.base + o_branch + branch_bytes * (size_t)b_at);
+            c.scan_count = reinterpret_cast<unsigned long long*>(head);
+            c.ws = A.at<double>(co[i].ws) + (size_t)b * 3 * kLmeParts;
+            c.amin_pv = A.at<double>(co[i].pv) + (size_t)b * kLmeParts;
+            c.amin_pi = A.at<long>(co[i].pi) + (size_t)b * 2 * kLmeParts;
+            trx::ScenFinal& f = fin[b_at];
+            f = trx::ScenFinal{};
+            f.idx = c.src_idx;
+            f.cols = d.cols;
+            f.N = N;
+            f.n_total = N;
+            f.ncol = ncol;
+            f.branch = b;
+            f.last_branch = (b == nbr - 1) ? 1 : 0;
+            f.res = res + (size_t)b * TRX_SCENARIO_OUT;
+            f.flag_out = (b == 0) ? res + 2 * TRX_SCENARIO_OUT : nullptr;
+            f.state = reinterpret_cast<unsigned*>(head + 8);      // (branch 0: == state0, whose word 1 is the call's flag)
+            c.fin = &f;
+        }
+    }
+    trx_draw_args* dev_tab = A.at<trx_draw_args>(o_tab);
+    {
+        const hipError_t e = hipMemcpyAsync(dev_tab, stage, sizeof(trx_draw_args) * (size_t)n, hipMemcpyHostToDevice, st);
+        trx::pinned_stage_end(st, stage_ticket);
+        if (e != hipSuccess) return trx::fail_hip(e);
+    }
+    auto bail = [&](int rc) {
+        (void)hipMemsetAsync(A.base + o_head, 0, trx::kScratchZeroed, st);
+        return rc;
+    };
+    long per = 0;
+    int groups = 0;
+    if (int rc = trx::draw_chain(stage, dev_tab, n, A.at<int>(o_cnt), fills, &per, &groups, st)) return bail(rc);
+    if (g_poison.load(std::memory_order_relaxed))          // tests: an unwritten row must show (include/trx.h)
+        for (int b = 0; b < nbr_total; ++b) TRXS_HIP(hipMemsetAsync(br[b].h, 0, sizeof(double) * (size_t)N, st));
+    if (int rc = trx::lnl_lme_chain(br, nbr_total, s0.time, s0.n_time, N, s0.exptime, s0.nsupersample, st)) return bail(rc);
+    for (int i = 0; i < n; ++i)
+        if (copy_back[i])
+            TRXS_HIP(hipMemcpyAsync(out[which[i]], res_of[i], sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), hipMemcpyDeviceToHost, st));
+    return TRX_OK;
+}
+
+std::atomic<int> g_chain{-1};          // trx_set_star_chain: -1 = from the environment (TRX_STAR_CHAIN, default on)
+
+bool chain_enabled()
+{
+    int v = g_chain.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("TRX_STAR_CHAIN");
+        v = (e && e[0] == '0' && !e[1]) ? 0 : 1;
+        g_chain = v;
+    }
+    return v != 0;
+}
+
+// may call j join a chain that starts with call i?  (same stream is the caller's business)
+bool chain_compatible(const trx_scenario_args& a, const trx_scenario_args& b)
+{
+    return a.draw->N == b.draw->N && a.n_time == b.n_time && a.time == b.time && a.nsupersample == b.nsupersample &&
+           a.exptime == b.exptime &&
+           ((a.flags ^ b.flags) & (TRX_FLAG_FP32_MODEL | TRX_FLAG_EVALUATE_EXCLUDED)) == 0;
 }
 
 }  // namespace
@@ -155,11 +321,43 @@ extern "C" int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, dou
 {
     if (n_done) *n_done = 0;
     if (n_calls < 0 || (n_calls > 0 && (!calls || !out || !streams))) return TRX_ERR_ARG;
-    for (int i = 0; i < n_calls; ++i) {
+    for (int i = 0; i < n_calls; ++i)
         if (!calls[i].draw || !out[i]) return TRX_ERR_ARG;
-        if (int rc = enqueue(&calls[i], out[i], static_cast<hipStream_t>(streams[i]))) return rc;
-        if (n_done) *n_done = i + 1;
+    // Consecutive calls on one stream that share N, the time stamps, the exposure settings and the precision go into ONE
+    // launch chain (enqueue_chain), up to kChainMaxCalls calls / kChainMaxBranchesHost branches at a time -- when the
+    // bounded evaluation's passes apply to them and their scratch together stays below the budget (TRX_CHAIN_DRAWS,
+    // default 2.5e7 draws' worth per chain: ~0.36 GB per 1e6 draws and call); everything else goes call by call.
+    static const double draw_budget = getenv("TRX_CHAIN_DRAWS") ? atof(getenv("TRX_CHAIN_DRAWS")) : 2.5e7;
+    int i = 0;
+    while (i < n_calls) {
+        hipStream_t st = static_cast<hipStream_t>(streams[i]);
+        int which[trx::kChainMaxCalls];
+        int n = 0, nbr = 0;
+        if (chain_enabled() && trx::lnl_chain_applicable(calls[i].flags, calls[i].n_time, calls[i].draw->N, calls[i].nsupersample)) {
+            for (int j = i; j < n_calls && n < trx::kChainMaxCalls; ++j) {
+                if (streams[j] != streams[i] || !chain_compatible(calls[i], calls[j])) break;
+                const int add = calls[j].draw->planet ? 1 : 2;
+                if (nbr + add > trx::kChainMaxBranchesHost) break;
+                if ((double)(n + 1) * (double)calls[i].draw->N > draw_budget && n > 0) break;
+                which[n++] = j;
+                nbr += add;
+            }
+        }
+        if (n >= 2) {
+            if (int rc = enqueue_chain(calls, which, n, out, st)) return rc;
+            i += n;
+        } else {
+            if (int rc = enqueue(&calls[i], out[i], st)) return rc;
+            i += 1;
+        }
+        if (n_done) *n_done = i;
     }
+    return TRX_OK;
+}
+
+extern "C" int trx_set_star_chain(int on)
+{
+    g_chain = on ? 1 : 0;
     return TRX_OK;
 }
 

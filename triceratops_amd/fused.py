@@ -108,7 +108,8 @@ class ScenarioArgs(ctypes.Structure):
                 ("out", ctypes.POINTER(ctypes.c_double)), ("out_flag", ctypes.POINTER(ctypes.c_int))]
 
 
-SCENARIO_OUT = 16      # TRX_SCENARIO_OUT
+SCENARIO_OUT = 18      # TRX_SCENARIO_OUT
+SCEN_TIES, SCEN_STATUS = 16, 17      # record slots: rows holding the smallest chi^2; 1 = a row was never written
 # True: a lnZ_* call that only has to return its best draw (calc_probs: TABLE_ROWS == 1, device
 # generator) is ONE library call, trx_scenario_evidence; False: the chain of torch operators around
 # trx_draw_scenario / trx_lnz_scenario below (the path of the 100-row table; kept as cross-check)
@@ -151,16 +152,21 @@ RECORD = 2 * SCENARIO_OUT + 1      # doubles per call: two branch records + the 
 class Pending:
     """one trx_scenario_enqueue call whose record has not been read yet"""
 
-    def __init__(self, scen, out, stream, keep, ncol, n_time):
+    def __init__(self, scen, out, stream, keep, ncol, n_time, is_host=False):
         self.scen, self.out, self.stream, self.keep, self.ncol, self.n_time = scen, out, stream, keep, ncol, n_time
+        self.is_host = is_host
 
     def result(self):
         """the call's result dict(s); the stream must have been synchronised"""
         rec = self.out.numpy()
-        self.keep = None
         if rec[2 * SCENARIO_OUT] != 0.0:
+            self.keep = None
             raise ValueError("can only convert an array of size 1 to a Python scalar")
         planet, ncol = bool(self.scen.a.planet), self.ncol
+        _check_status(rec[None, :], [planet])
+        if self.replay_for_ties(rec):
+            return self.scen.run_operator_chain(self.is_host, ncol)
+        self.keep = None
         res = []
         for b in range(1 if planet else 2):
             row = rec[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT]
@@ -173,6 +179,32 @@ class Pending:
         return res[0] if planet else (res[0], res[1])
 
 
+    def replay_for_ties(self, rec):
+        """The seeded numpy modes promise the reference's OWN best draw, and the reference takes it from an argsort
+        that orders exact ties its own way (marginal_likelihoods.py:152: introsort, not stable); the library reports
+        the first of equals and how many rows tie (record slot 16).  With a tie at the minimum the call is evaluated
+        again by the operator chain, on the same staged numbers (still alive in self.keep), whose best-draw search
+        reproduces numpy's order.  (Exact ties at the minimum are what flat models give: a scenario none of whose
+        draws touches the data.)"""
+        if not isinstance(dp.RNG, dp.NumpyStreamRng) or self.scen.philox:
+            return False
+        nbr = 1 if self.scen.a.planet else 2
+        return any(rec[b * SCENARIO_OUT + SCEN_TIES] > 1.0 for b in range(nbr))
+
+
+def _check_status(recs, planet):
+    """raises when a record says that a masked draw's chi^2 was never written (an internal error of the passes of the
+    bounded evaluation: round 4 shipped two such bugs, and a stale value read as a result gave FPP = 1)"""
+    for b in range(2):
+        bad = recs[:, b * SCENARIO_OUT + SCEN_STATUS] != 0.0
+        if b == 1:
+            bad = bad & ~np.asarray(planet, dtype=bool)
+        if np.any(bad):
+            raise _lib.TrxError("libtrx: %d lnZ_* call(s) of this pass report rows of their likelihood that no kernel "
+                                "wrote (branch %d; record status 1) -- an internal error, the results are not usable; "
+                                "trx_set_bounded_evaluation(0) evaluates every row in one pass" % (int(bad.sum()), b))
+
+
 _stats_lock = threading.Lock()
 
 
@@ -183,10 +215,29 @@ def records_to_rows(pending):
     expressions).  The streams must have been synchronised."""
     if not pending:
         return {}
-    recs = np.stack([p.out.numpy() for _, p in pending])                 # [calls][33]
+    recs = np.stack([p.out.numpy() for _, p in pending])                 # [calls][37]
     if np.any(recs[:, 2 * SCENARIO_OUT] != 0.0):
         raise ValueError("can only convert an array of size 1 to a Python scalar")
     planet = np.array([bool(p.scen.a.planet) for _, p in pending])
+    _check_status(recs, planet)
+    replay = [i for i, (_, p) in enumerate(pending) if p.replay_for_ties(recs[i])]
+    if replay:
+        # (seeded numpy modes only: the reference's own order among exactly tied best draws, see Pending.replay_for_ties)
+        redo = {}
+        for i in replay:
+            k, p = pending[i]
+            with torch.cuda.stream(p.stream):
+                res = p.scen.run_operator_chain(p.is_host, p.ncol)
+            p.stream.synchronize()
+            dicts = res if isinstance(res, tuple) else (res,)
+            from .sharding import RECORD_COLS
+            redo[k] = np.array([[d[c] if c == "lnZ" else d[c][0] for c in RECORD_COLS] for d in dicts])
+        rest = [kp for i, kp in enumerate(pending) if i not in set(replay)]
+        out = records_to_rows(rest)
+        out.update(redo)
+        for _, p in pending:
+            p.keep = None
+        return out
     n_time = np.array([p.n_time for _, p in pending])
     out = {}
 
@@ -656,6 +707,13 @@ class _Scenario:
         # reference's argsort may order exact ties differently (the operator chain below reproduces that too).
         if NATIVE and TABLE_ROWS == 1 and DUMP is None and _lib.TRACE is None:
             return self._run_native(is_host, ncol)
+        return self.run_operator_chain(is_host, ncol)
+
+    def run_operator_chain(self, is_host, ncol):
+        """trx_draw_scenario (every draw in full) + torch operators for the compaction and the best-draw table +
+        trx_lnz_scenario per branch: the path of the 100-row tables of direct lnZ_* calls, and the cross-check of
+        the library's own chain"""
+        a, N, dev = self.a, self.N, self.dev
         cols = torch.empty((ncol, N), dtype=F64, device=dev)
         mask = torch.empty(N, dtype=torch.uint8, device=dev)
         mask2 = torch.empty(N, dtype=torch.uint8, device=dev) if not a.planet else None
@@ -713,7 +771,7 @@ class _Scenario:
         sa.want_prior = int(self.want_prior)
         out, deferred = _record_slot()
         stream = torch.cuda.current_stream(dev)
-        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time)
+        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time, is_host)
         self.keep = []
         if deferred and getattr(_tls, "batch", None) is not None:
             _tls.batch.append((sa, out, stream, dev))      # (sa.draw points at self.a: alive in the Pending)

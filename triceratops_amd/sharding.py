@@ -196,6 +196,42 @@ def _worker_streams(device, n):
     return have[:n]
 
 
+# lnZ_* calls per launch chain the dealing aims at (the library takes up to 16 calls / 24 branches per chain)
+chain_calls = int(os.environ.get("TRX_CHAIN_CALLS", "12"))
+
+
+def _pieces(units, mine_k, n_streams):
+    """this rank's units as contiguous runs of one target's calls: whole targets when there are at least as many as
+    streams, else a target's calls in enough runs to keep the streams busy (a 75-scenario calc_probs: 50 calls in
+    five runs of ten)"""
+    jobs = []
+    for k in mine_k:
+        j = _job_of(units[k])
+        if jobs and jobs[-1][0] == j:
+            jobs[-1][1].append(k)
+        else:
+            jobs.append((j, [k]))
+    out = []
+    for _, ks in jobs:
+        n = len(ks)
+        want = -(-n // max(chain_calls, 1))
+        if len(jobs) < n_streams:
+            want = max(want, min(n_streams // len(jobs), n // 5))
+        want = max(1, min(want, n))
+        cost = [_COST.get(units[k][5], 1.0) for k in ks]
+        total, acc, at = sum(cost), 0.0, 0
+        for p in range(want):
+            # contiguous, balanced by cost: piece p ends where the running cost passes (p + 1) / want of the total
+            end = at
+            while end < n and (p == want - 1 or acc + cost[end] <= total * (p + 1) / want + 1e-9 or end == at):
+                acc += cost[end]
+                end += 1
+            if end > at:
+                out.append(ks[at:end])
+            at = end
+    return out
+
+
 def _star_of(u):
     """(job, star) of a unit when the caller gave it (target._prepare), else its star's ID"""
     return u[8] if len(u) > 8 else u[3]
@@ -265,18 +301,18 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         try:
             import time
             t0 = time.perf_counter()
-            # each call goes to the stream with the least work queued so far (by the schedule's cost weights):
-            # dealt round-robin, the planet calls and the dearer binary calls of a star's twelve end up on
-            # different streams whenever their number divides twelve, and the step waits for the slowest
+            # The library turns consecutive calls on ONE stream that share a light curve's time stamps and N into one
+            # launch chain (trx_star_enqueue, include/trx.h): every kernel once for up to 16 calls.  So the calls go
+            # to the streams in PIECES -- contiguous runs of one target's calls, ~chain_calls each -- and a piece to
+            # the stream with the least work queued so far (by the schedule's cost weights); one library call per piece.
             load = [0.0] * len(pool)
-            for n_, k in enumerate(mine_k):
+            for piece in _pieces(units, mine_k, len(pool)):
                 j = min(range(len(pool)), key=lambda i: (load[i], i))
-                load[j] += _COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0)
+                load[j] += sum(_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0) for k in piece)
                 with torch.cuda.stream(pool[j]):
-                    one(k)
-                # the calls of one star go to the library together (trx_star_enqueue): at the last unit of a star
-                if n_ + 1 == len(mine_k) or _star_of(units[mine_k[n_ + 1]]) != _star_of(units[k]):
-                    _fused.flush()
+                    for k in piece:
+                        one(k)
+                _fused.flush()
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
                 st.synchronize()
