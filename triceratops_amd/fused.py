@@ -164,6 +164,8 @@ class Pending:
             raise ValueError("can only convert an array of size 1 to a Python scalar")
         planet, ncol = bool(self.scen.a.planet), self.ncol
         _check_status(rec[None, :], [planet])
+        with _stats_lock:
+            _lib.STATS["native_calls"] += 1
         if self.replay_for_ties(rec):
             return self.scen.run_operator_chain(self.is_host, ncol)
         self.keep = None
@@ -174,8 +176,6 @@ class Pending:
             with _stats_lock:
                 _lib.count_launch(n, self.n_time)
             res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
-        with _stats_lock:
-            _lib.STATS["native_calls"] += 1
         return res[0] if planet else (res[0], res[1])
 
 
@@ -232,6 +232,8 @@ def records_to_rows(pending):
             dicts = res if isinstance(res, tuple) else (res,)
             from .sharding import RECORD_COLS
             redo[k] = np.array([[d[c] if c == "lnZ" else d[c][0] for c in RECORD_COLS] for d in dicts])
+        with _stats_lock:
+            _lib.STATS["native_calls"] += len(replay)
         rest = [kp for i, kp in enumerate(pending) if i not in set(replay)]
         out = records_to_rows(rest)
         out.update(redo)
