@@ -3035,19 +3035,22 @@ int trx_set_skip_excluded(int on)
 /* statistics (include/trx.h): rows skipped on the current device since the last reset */
 static int read_row_stat(int which, unsigned long long* out, int reset)
 {
-    static unsigned long long host[2][kStatShards][kStatPad];
+    static unsigned long long host[kStatShards][kStatPad];
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
+    constexpr size_t slice = sizeof(host);                 // one counter's shards
     TRX_HIP(hipDeviceSynchronize());
-    TRX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_row_stats), sizeof(host)));
+    TRX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_row_stats), slice, (size_t)which * slice));
     if (out) {
         unsigned long long sum = 0;
-        for (int i = 0; i < kStatShards; ++i) sum += host[which][i][0];
+        for (int i = 0; i < kStatShards; ++i) sum += host[i][0];
         *out = sum;
     }
     if (reset) {
-        for (int i = 0; i < kStatShards; ++i) host[which][i][0] = 0;
-        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), host, sizeof(host)));
+        // only this counter's slice is cleared (a copy of the WHOLE table written back would roll back what kernels of
+        // another host thread added to the other counter between the read and the write: advisor, round 4)
+        memset(host, 0, slice);
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), host, slice, (size_t)which * slice));
     }
     return TRX_OK;
 }

@@ -47,11 +47,13 @@ threads = 1
 streams = int(os.environ.get("TRX_STREAMS", "4"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
 # (+ the collective, and -- calc_probs_many -- the unit lists and the result tables of all targets)
-timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "finish_s": 0.0}
+timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "finish_s": 0.0, "build_s": 0.0,
+          "library_s": 0.0}
 # seed bases of the ranks of the last multi-rank run_units (from the all_gather's header rows)
 last_seed_bases = None
 # what the schedule of the last run_units gave every rank: lnZ_* calls, distinct (job, star)s and distinct jobs
 last_share = {"calls": [0], "stars": [0], "jobs": [0]}
+_warned_bases = False
 # The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
 # their scratch together stays near this many draws' worth (6 streams at N = 1e6, 2 at N >= 3e6)
 scratch_budget_draws = 6_000_000
@@ -306,13 +308,19 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             # to the streams in PIECES -- contiguous runs of one target's calls, ~chain_calls each -- and a piece to
             # the stream with the least work queued so far (by the schedule's cost weights); one library call per piece.
             load = [0.0] * len(pool)
+            t_build = t_lib = 0.0          # of enqueue_s: Python building the argument blocks / inside trx_star_enqueue
             for piece in _pieces(units, mine_k, len(pool)):
                 j = min(range(len(pool)), key=lambda i: (load[i], i))
                 load[j] += sum(_COST.get(units[k][5], 1.0) * (units[k][6] if len(units[k]) > 6 else 1.0) for k in piece)
+                t_a = time.perf_counter()
                 with torch.cuda.stream(pool[j]):
                     for k in piece:
                         one(k)
+                t_b = time.perf_counter()
                 _fused.flush()
+                t_build += t_b - t_a
+                t_lib += time.perf_counter() - t_b
+            timing["build_s"], timing["library_s"] = t_build, t_lib
             timing["enqueue_s"] = time.perf_counter() - t0
             for st in pool:
                 st.synchronize()
@@ -389,8 +397,17 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=dev)
         dist.all_gather_into_tensor(gathered, mine)          # the single collective
         g = gathered.cpu().numpy().reshape((world,) + chunk.shape)
-        global last_seed_bases
+        global last_seed_bases, _warned_bases
         last_seed_bases = [int(b) for b in g[:, 0, 0]]
+        if len(set(last_seed_bases)) > 1 and not _warned_bases:
+            # (relaxed in round 4: unseeded ranks just run -- but a user who seeded only some ranks, or only numpy in
+            # "device" mode, should hear that the run cannot be repeated)
+            import warnings
+            warnings.warn("calc_probs on %d ranks: the ranks drew different seed bases %s, so this run is not reproducible "
+                          "and its numbers depend on the partition.  Seed every rank alike (torch.manual_seed in 'device' "
+                          "mode, np.random.seed in the numpy modes) for a repeatable, partition-independent run."
+                          % (world, last_seed_bases[:4]), RuntimeWarning, stacklevel=4)
+            _warned_bases = True
         at = [1] * world
         for k in live:
             r = owner[k]
