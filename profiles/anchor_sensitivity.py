@@ -30,6 +30,9 @@ Variants
   parallel  parallel=False (TOI-465.01's cell 9 run; the per-draw-loop semantics of App. C)
   expo:*    exptime / nsamples: no supersampling, 10 and 40 sub-exposures, a 30-minute exposure
   N:*       1e5 and 1e7 draws (bias of ln(mean) at finite N)
+  prior:*   (round 5) the bound-companion prior: the earlier forms the reference keeps as comments (priors.py:661-688,
+            749-776, 863-890, 951-970) and the separation limit used when no contrast curve is given
+            (ANCHOR_ONLY=prior python profiles/anchor_sensitivity.py 100 > profiles/r05/anchor_prior_forms.txt)
 """
 import json
 import os
@@ -123,7 +126,31 @@ def variants(case):
     out.append(("expo:exptime=30 min", dict(kw=dict(exptime=0.0208333))))
     out.append(("N:1e5", dict(N=100_000)))
     out.append(("N:1e7", dict(N=10_000_000, seeds=32)))
+    # Round 5: the bound-companion prior itself.  The reference keeps an EARLIER form of it as comments
+    # (priors.py:661-688, 749-776: f_comp = t1 + t2 + t3 + t4_partial ... for the planet scenarios; :863-890, 951-970: + t1
+    # for the binaries).  Without a contrast curve every draw has the same separation limit (2.2 arcsec at the target's
+    # distance: log10 P_max = 5.74 for TOI-411.02, 6.21 for TOI-465.01), so a form of the prior is ONE factor on PTP and STP
+    # alike; beyond log10 P = 5.5 the earlier planet form is the current one plus the constant t1 + t2 + t3, which the
+    # host-computed t4 of trx_draw_args can carry.  Also: the separation limit that stands in for a contrast curve.
+    out.append(("prior:earlier TP form (+ t1 + t2 + t3)", dict(hook="tp_close")))
+    out.append(("prior:earlier EB form (+ t1)", dict(hook="eb_t1")))
+    out.append(("prior:no-cc separation 1.1 arcsec", dict(no_cc_sep=1.1)))
+    out.append(("prior:no-cc separation 4.4 arcsec", dict(no_cc_sep=4.4)))
     return b, out
+
+
+def _hook(name):
+    from triceratops_amd import fused
+
+    def tp_close(a, kind):          # planet scenarios: + t1 + t2 + t3 (valid where log10 P_max >= 5.5: checked in run())
+        if kind == fused.PRIOR_BOUND_TP:
+            a.t4 = a.t4 + a.f1 + a.t2 + a.t3
+
+    def eb_t1(a, kind):             # binaries: + t1 (every range from log10 P = 2 on carries t2)
+        if kind == fused.PRIOR_BOUND_EB:
+            a.t2 = a.t2 + a.f1
+
+    return {"tp_close": tp_close, "eb_t1": eb_t1}[name]
 
 
 def run(case, inp, seed):
@@ -134,14 +161,19 @@ def run(case, inp, seed):
     tg = target(c["ID"], np.array([1]), mission=c["mission"], stars=inp["stars"], trilegal_fname=anchors.TRILEGAL)
     prev = triceratops_amd.get_sampling()
     triceratops_amd.set_sampling(inp["sampling"])
+    from triceratops_amd import fused
     try:
         np.random.seed(seed)
         torch.manual_seed(seed)
         kw = dict(parallel=True)
         kw.update(inp["kw"])
+        fused.BOUND_HOOK = _hook(inp["hook"]) if inp.get("hook") else None
+        fused.NO_CC_SEPARATION = inp.get("no_cc_sep", 2.2)
         tg.calc_probs(inp["time"], inp["flux"], inp["sigma"], inp["P"], contrast_curve_file=c["cc"], N=inp["N"],
                       verbose=0, **kw)
     finally:
+        fused.BOUND_HOOK = None
+        fused.NO_CC_SEPARATION = 2.2
         triceratops_amd.set_sampling(prev)
     lnZ = np.array(tg.lnZ)
     i_tp, i_ptp, i_stp = (anchors.SCENARIOS.index(s) for s in ("TP", "PTP", "STP"))
@@ -154,6 +186,9 @@ def main():
     report = {}
     for case in cases:
         b, var = variants(case)
+        only = os.environ.get("ANCHOR_ONLY")           # e.g. ANCHOR_ONLY=prior: the baseline and the prior:* variants
+        if only:
+            var = [v for v in var if v[0] == "baseline" or v[0].startswith(only)]
         nb_prob, nb_fpp, _ = anchors.notebook(case)
         i_tp, i_ptp, i_stp = (anchors.SCENARIOS.index(s) for s in ("TP", "PTP", "STP"))
         nb = (np.log(nb_prob[i_ptp] / nb_prob[i_tp]), np.log(nb_prob[i_stp] / nb_prob[i_tp]), nb_fpp)

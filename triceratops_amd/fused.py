@@ -461,13 +461,18 @@ def _flux0(M_s, band):
 
 
 _cc_cache = {}
+# Experiments only (profiles/anchor_sensitivity.py): a callable(args, kind) applied to the Moe & Di Stefano constants of a
+# bound-companion prior after they are set, and the angular separation that stands in for a contrast curve
+# (marginal_likelihoods.py:479-487: 2.2 arcsec)
+BOUND_HOOK = None
+NO_CC_SEPARATION = 2.2
 
 
 def _contrast_curve(cc_file, device):
-    key = (cc_file, device.type, device.index)
+    key = (cc_file, device.type, device.index, NO_CC_SEPARATION if cc_file is None else None)
     if key not in _cc_cache:
         if cc_file is None:
-            seps, cons = np.array([2.2]), np.array([1.0])
+            seps, cons = np.array([float(NO_CC_SEPARATION)]), np.array([1.0])
         else:
             seps, cons = funcs.file_to_contrast_curve(cc_file)
         if cons.size > MAX_CC:
@@ -644,6 +649,8 @@ class _Scenario:
         a.prior = kind
         self.want_prior = True
         _bound_constants(a, M_s, plx)
+        if BOUND_HOOK is not None:
+            BOUND_HOOK(a, kind)
         self._cc(cc_file, filt, M_s)
 
     def _cc(self, cc_file, filt, M_s):
