@@ -22,6 +22,26 @@
 
 namespace trx {
 
+// Trip census (build with -DTRX_CENSUS; profiles/r05/isa_histogram.py weights the static opcode counts of cells_kernel's
+// regions with it).  Not compiled into the product library.  A count is added once per WAVE execution of the place it
+// stands at (the first active lane adds).
+#ifdef TRX_CENSUS
+__device__ unsigned long long g_census[32];
+__device__ __forceinline__ void census_add(int slot, unsigned long long n = 1ull)
+{
+    const unsigned long long m = __ballot(1);
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == __ffsll((long long)m) - 1) atomicAdd(&g_census[slot], n);
+}
+#define TRX_CENSUS_ADD(slot, n) census_add(slot, n)
+#else
+#define TRX_CENSUS_ADD(slot, n)
+#endif
+// census slots
+constexpr int kCenBatch = 0, kCenWindowTrip = 1, kCenChunk0 = 2, kCenChunk1 = 3, kCenPass = 4, kCenPairTrip = 5,
+              kCenPairLanes = 6, kCenFluxTrip = 7, kCenAgmTrip = 8, kCenKeplerFullPair = 9, kCenKeplerFullPlan = 10,
+              kCenFluxLanes = 11, kCenContactTrip = 12, kCenCrossingTrip = 13, kCenInsideTrip = 14;
+
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr double kTwoPi = 6.28318530717958647692528676655900577;
 constexpr double kHalfPi = 1.57079632679489661923132169163975144;
@@ -183,6 +203,15 @@ __device__ __forceinline__ double atan_pos_tab(double x, const double* tab)
     const double num = fma(r[0], x, r[1]);
     const double den = fma(r[2], x, r[3]);
     const double t = (den > 1.7e308) ? 0.0 : num * rcp_fast(den);
+#ifdef TRX_ATAN_LATE_LOADS
+    // (hi, lo) are needed last: tied to t, their loads cannot be hoisted above the division and do not hold four
+    // registers across it and the polynomial (the batched bounded instantiation sits exactly at its 96-register limit)
+    int i_late = i;
+    asm("" : "+v"(i_late) : "v"(t));
+    const double* r_late = tab + kAtanCols * i_late;
+#else
+    const double* r_late = r;
+#endif
     const double z = t * t, w = z * z;
     const double s1 = z * fma_k(w, fma_k(w, fma_k(w, fma_k(w, fma_k(w, 1.62858201153657823623e-02,
                       4.97687799461593236017e-02), 6.66107313738753120669e-02),
@@ -191,7 +220,7 @@ __device__ __forceinline__ double atan_pos_tab(double x, const double* tab)
     const double s2 = w * fma_k(w, fma_k(w, fma_k(w, fma_k(w, -3.65315727442169155270e-02,
                       -5.83357013379057348645e-02), -7.69187620504482999495e-02),
                       -1.11111104054623557880e-01), -1.99999999998764832476e-01);
-    return r[4] - ((t * (s1 + s2) - r[5]) - t);
+    return r_late[4] - ((t * (s1 + s2) - r_late[5]) - t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -229,6 +258,7 @@ __device__ __forceinline__ double cel_pair(double kc, double a1, double b1, doub
     // four v_mov_b64 per iteration (4 cycles each, as much as an fp64 fma) to rotate them back
 #pragma unroll 1
     for (int it = 0; it < 20; ++it) {
+        TRX_CENSUS_ADD(kCenAgmTrip, 1);
         if (step()) break;
         if (step()) break;
     }
@@ -256,6 +286,10 @@ __device__ __forceinline__ Limb limb_weights(double u1, double u2)
 // Mandel & Agol (2002) quadratic-law flux for 0 <= z < 1+p, p > 0 (callers handle the
 // unocculted side).  Case analysis and factored contact-triangle form: DESIGN.md section 4.
 // Both regions (disk inside the limb / crossing it) feed ONE cel_pair call.
+// TAB: the arctangent's range constants come from the 5 x 6 table at `atab` (in LDS: cells_kernel).  A template
+// parameter, not a test of the pointer: the compiler cannot tell that an LDS address is not null and kept BOTH
+// arctangents behind a branch -- 100 instructions of every instantiation that nobody executed.
+template <int TAB = 0>
 __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L, const double* atab = nullptr)
 {
     if (p >= 1.0 && z <= p - 1.0) return 0.0;
@@ -280,7 +314,10 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L, con
     const double b = zpp * zpp;
     double le, ed, kc2, al, be, pp, a2, b2, scale;
     bool contact = false;
+    TRX_CENSUS_ADD(kCenFluxTrip, 1);
+    TRX_CENSUS_ADD(kCenFluxLanes, (unsigned long long)__popcll(__ballot(1)));
     if (inside) {
+        TRX_CENSUS_ADD(kCenInsideTrip, 1);
         le = p2;
         ed = eta2;
         const double g1 = omp - z;
@@ -296,14 +333,17 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L, con
         b2 = m3;                                  // a2 / pp
         scale = (2.0 / (9.0 * kPi)) * rso;
     } else {
+        TRX_CENSUS_ADD(kCenCrossingTrip, 1);
         const double f1 = (p < 1.0) ? (z - omp) : (z + (p - 1.0));
         // contact triangle (sides 1, p, z): one square root, area4 = 4 x area; the half-angle
         // tangents are sqrt(f2 f3 / (f1 f4)) = area4/(f1 f4) and sqrt(f1 f2 / (f3 f4)) = area4/(f3 f4)
         const double f14 = f1 * f4, f34 = f3 * f4;
         const double area4 = sqrt_fast(f14 * (f2 * f3));
         const double x0 = (f14 > 0.0) ? area4 * rcp_fast(f14) : INFINITY, x1 = area4 * rcp_fast(f34);
-        const double kap0 = 2.0 * (atab ? atan_pos_tab(x0, atab) : atan_pos(x0));
-        const double kap1 = 2.0 * (atab ? atan_pos_tab(x1, atab) : atan_pos(x1));
+        // (TAB 2: decided by a test of the pointer at run time -- both versions in the binary; see trx_kernels.hip TRX_ATAN_TAB)
+        const bool tab = TAB == 1 || (TAB == 2 && atab != nullptr);
+        const double kap0 = 2.0 * (tab ? atan_pos_tab(x0, atab) : atan_pos(x0));
+        const double kap1 = 2.0 * (tab ? atan_pos_tab(x1, atab) : atan_pos(x1));
         le = (p2 * kap0 + kap1 - 0.5 * area4) * (1.0 / kPi);
         ed = (kap1 + 2.0 * eta2 * kap0 - 0.25 * (1.0 + 5.0 * p2 + z2) * area4) * (1.0 / kTwoPi);
         const double fzp = 4.0 * z * p;
@@ -719,9 +759,15 @@ struct CellPlan {
     bool st_ok = false;                          // no limb contact within the stencil radius (cells_kernel)
 };
 
-template <bool CHECK_WINDOW = true, bool FREEZE = false>
+// th_lds: the table's radii [kTiers] and node counts [kTiers] (as doubles) in LDS, or null.  cells_kernel stages them
+// there: as kernel arguments they occupy 21 scalar registers for the whole kernel, which is already past the 102 it has
+// (the compiler then parks scalars in VGPR lanes -- v_writelane / v_readlane, VALU issue both -- inside the chunk loop);
+// an LDS read at a wave-uniform or lane-chosen address costs an LDS slot, no VALU issue.
+constexpr int kTierHeadDoubles = 2 * kTiers;
+template <bool CHECK_WINDOW = true, bool FREEZE = false, bool LDS_HEAD = false>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
-                                              const TierHead& tt, bool use_tiers, double st_radius = 0.0)
+                                              const TierHead& tt, bool use_tiers, double st_radius = 0.0,
+                                              const double* th_lds = nullptr)
 {
     CellPlan p;
     const double phase = c.nmot * (t - c.t0);
@@ -744,6 +790,7 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     const bool stepped = kepler_step_wide<FREEZE>(reduce_2pi(phase), c.e, p.sE, p.cE);
     if (!__all(stepped)) {
         double sF, cF;
+        TRX_CENSUS_ADD(kCenKeplerFullPlan, 1);
         kepler_full(p.Mprev, c.e, sF, cF);
         if (!stepped) { p.sE = sF; p.cE = cF; }
     }
@@ -778,6 +825,28 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     // is a choice between two ADDRESSES to the compiler, and a loop over q an indexed one -- either keeps a kernel's
     // patched local copy of its argument block (star_args, trx_kernels.hip) from being split into registers, and the
     // whole block then lives in scratch memory)
+    if (LDS_HEAD) {
+        // (the table in LDS: the bisection reads three radii and one count at addresses it computes)
+        if (th_lds[kTiers + kTiers - 1] > 0.0) {
+            const bool ok3 = admissible(th_lds[3]);
+            const bool ok1 = admissible(th_lds[ok3 ? 1 : 5]);
+            const bool ok2 = admissible(th_lds[ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)]);
+            const int q = (ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)) + (ok2 ? 0 : 1);      // first admissible tier, 7 = none
+            if (q < kTiers) {
+                p.tier = q;
+                p.n = (int)th_lds[kTiers + q];
+            }
+        } else {
+            for (int q = kTiers - 1; q >= 0; --q) {
+                const bool ok = th_lds[kTiers + q] > 0.0 && admissible(th_lds[q]);
+                if (ok) { p.tier = q; p.n = (int)th_lds[kTiers + q]; }
+            }
+        }
+        if (st_radius > 0.0) p.st_ok = admissible(st_radius);
+        const double tau1l = 1.5 * hx;
+        if (z2 > opp2 && G >= 1.25 * fma(g2 * tau1l, tau1l, g1 * tau1l) && om * tau1l <= 0.15) p.n = 0;
+        return p;
+    }
     const int n0 = tt.n[0], n1 = tt.n[1], n2 = tt.n[2], n3 = tt.n[3], n4 = tt.n[4], n5 = tt.n[5], n6 = tt.n[6];
     const double r0 = tt.radius[0], r1 = tt.radius[1], r2 = tt.radius[2], r3 = tt.radius[3], r4 = tt.radius[4],
                  r5 = tt.radius[5], r6 = tt.radius[6];
@@ -849,10 +918,10 @@ __device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, 
     return fma(X, X, yc * yc);
 }
 
-template <bool FP32>
-__device__ __forceinline__ double disc_flux(double z, double k, const Limb& L, const double* atab = nullptr)
+template <bool FP32, int TAB = 1>
+__device__ __forceinline__ double disc_flux(double z, double k, const Limb& L, const double* atab)
 {
-    return FP32 ? ma_flux_f32(z, k, L) : ma_flux(z, k, L, atab);
+    return FP32 ? ma_flux_f32(z, k, L) : ma_flux<TAB>(z, k, L, atab);
 }
 
 // Mean model flux of one exposure (centre t) evaluated by one lane: the body of pytransit's

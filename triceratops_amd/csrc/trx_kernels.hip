@@ -160,6 +160,14 @@ __device__ __forceinline__ long uniform_long(long v)
     return (long)(((unsigned long long)hi << 32) | lo);
 }
 
+// bit i (a lane's own index) of a wave-uniform 64-bit mask: the half is chosen first, so the mask stays in its scalar
+// register pair (a 64-bit shift by a lane's amount wants it in two VGPRs, held for as long as the mask lives)
+__device__ __forceinline__ bool mask_bit(unsigned long long m, int i)
+{
+    const unsigned w = (i & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+    return ((w >> (i & 31)) & 1u) != 0u;
+}
+
 // number of set bits of `m` below this lane
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
@@ -244,6 +252,25 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 
 constexpr int kBatchWaves = TRX_BATCH_WAVES;
 __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows ? 1 : kBatchWaves; }
+// (experiment, profiles/r05: 1 = one row per wave reads its row constants from LDS like the batched variant instead of
+// holding them in ~30 scalar registers)
+// which instantiations take the arctangent's range constants from the LDS table (the others select them)
+// plan_cell reads the tiers' radii and node counts from LDS (true) or from the kernel's arguments
+#ifndef TRX_TIER_LDS
+#define TRX_TIER_LDS(PRUNE, LONG) true
+#endif
+// How an instantiation takes the arctangent's range constants (ma_flux<TAB>): 1 = from the LDS table, known at compile
+// time (the select-based version is not even in the binary: until round 5 both were, behind a test of the pointer --
+// 100 instructions per instantiation that nobody executed, and with them gone the compiler needs 10-40 fewer scalar
+// spills and up to 12 fewer VGPRs); 2 = the test of the pointer at run time.  The batched instantiation of the bounded
+// evaluation keeps 2: with 1 the register allocator lands on 98 VGPRs, two over the 96 that five waves per SIMD allow
+// (two 8-byte spills outside the loops; tests/test_build_resources.py wants none), with 2 on 93.
+#ifndef TRX_ATAN_TAB
+#define TRX_ATAN_TAB(PRUNE, LONG) (((PRUNE) && !(LONG)) ? 2 : 1)
+#endif
+#ifndef TRX_LONG_ROWS_IN_LDS
+#define TRX_LONG_ROWS_IN_LDS 0
+#endif
 #ifndef TRX_CELLS_WAVES_PER_EU
 #define TRX_CELLS_WAVES_PER_EU 4
 #endif
@@ -900,6 +927,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // shared by the workgroup's waves: node tables, atan constants, (short curves) the light curve
     double* tier_xw = lds_all;
     double* atab = tier_xw + 2 * kTiers * kTierMaxNodes;             // atan_pos_tab's range constants
+    double* thead = atab + kAtanRanges * kAtanCols;                  // the tiers' radii and node counts (plan_cell)
     // this wave's own: row blocks, accumulators, pair table, in-window list, cell state
     double* lds = lds_all + a.wave_off + (size_t)wave * a.wave_doubles;
     const int Bl = LONG ? 1 : a.B;                                    // rows the LDS layout holds
@@ -907,7 +935,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     double* hacc = lds + (size_t)Bl * kRowDoubles;                    // [Bl] chi^2 corrections per row
     double* hmout = hacc + Bl;                                        // [Bl] diluted model of an unocculted cell: 1, or NaN
     double* hrem = hmout + Bl;                                        // [Bl] PRUNE: (f - 1)^2 / s2 over the row's in-window cells not done yet
-    unsigned short* pdesc = reinterpret_cast<unsigned short*>(hrem + Bl);   // [kCellsPairs] pair -> cell lane | node << 6
+    double* hlp = hrem + Bl;                                          // [Bl] PRUNE: lnprior of the row's draw (read twice per batch: not worth two VGPRs)
+    unsigned short* pdesc = reinterpret_cast<unsigned short*>(hlp + Bl);    // [kCellsPairs] pair -> cell lane | node << 6
     constexpr int kCellsWindow = cells_window(LONG);
     unsigned short* winlist = pdesc + kCellsPairs;                    // [kCellsWindow] in-window cells
     CellState& cs = *reinterpret_cast<CellState*>(winlist + kCellsWindow);
@@ -923,6 +952,14 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         for (int i = threadIdx.x; i < 2 * kTiers * kTierMaxNodes; i += 64 * W) tier_xw[i] = a.tier_xw[i];
     }
     if (threadIdx.x < kAtanRanges * kAtanCols) atab[threadIdx.x] = kAtanTable[threadIdx.x];
+    if (threadIdx.x == 0) {
+        // (literal indices: see plan_cell)
+        thead[0] = a.tiers.radius[0]; thead[1] = a.tiers.radius[1]; thead[2] = a.tiers.radius[2]; thead[3] = a.tiers.radius[3];
+        thead[4] = a.tiers.radius[4]; thead[5] = a.tiers.radius[5]; thead[6] = a.tiers.radius[6];
+        thead[7] = (double)a.tiers.n[0]; thead[8] = (double)a.tiers.n[1]; thead[9] = (double)a.tiers.n[2];
+        thead[10] = (double)a.tiers.n[3]; thead[11] = (double)a.tiers.n[4]; thead[12] = (double)a.tiers.n[5];
+        thead[13] = (double)a.tiers.n[6];
+    }
     const int lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     // Probe pass of a batched launch: the rows its waves leave alive are gathered per WORKGROUP and reserved in the
     // launch's list with one device-scope atomic (one per wave -- several thousand on one address, ~23 ns each at the
@@ -934,7 +971,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const bool eblike = (a.model == TRX_MODEL_EB) || (a.model == TRX_MODEL_EB_TWIN);
     const double rs2 = a.rs2;
     const int n_time = a.n_time;
-    const float inv_nt = 1.0f / (float)n_time;
+    const float inv_nt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (float)n_time)));   // (scalar register)
     // the row count: known to the host, or left on the device by an earlier kernel of the stream (the
     // rows per wave and the batch count then follow here, by the host's rule)
     long n = a.n, nbatch = a.nbatch;          // (nbatch: one row per wave only; batches follow batch_plan)
@@ -961,7 +998,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     if (W > 1) __syncthreads();       // the only workgroup barrier: from here on every wave is on its own
     // chi^2 of the flat model (every cell exactly 1): one number per launch (rowc_kernel)
     const double* hdr = a.rowc + n * kRowDoubles;
-    const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? hdr[kHdrFlat] : 0.0;
+    // (one number per launch, read from memory: held in a scalar register pair, not in two VGPRs for the whole kernel)
+    const double flat_sum = (MODE == MODE_LNL && n_time > 0) ? uniform(hdr[kHdrFlat]) : 0.0;
     if (ST && lane <= 2 * kStM) ss.stw[lane] = hdr[kHdrStW + lane];
 
     // the rows of this launch: all of them, or (PRUNE) the pilot rows / the rows behind the pilot
@@ -1021,10 +1059,11 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             if (row1 - base < nb) nb = (int)(row1 - base);
         }
         TRX_TICK(t_pro);
+        TRX_CENSUS_ADD(kCenBatch, 1);
         // ---- the batch's row blocks (rowc_kernel), one coalesced copy -----------------------
-        long rowid = base + lane;          // the row of lane `lane` of the batch (lanes < nb)
+        int rowid = (int)base + lane;      // the row of lane `lane` of the batch (lanes < nb; row counts fit an int: trx_scenario.hip)
         if (PRUNE && rlist) {
-            if (lane < nb) rowid = (long)rlist[base + lane];
+            if (lane < nb) rowid = rlist[base + lane];
             double* dst = reinterpret_cast<double*>(rows);
             for (int i = lane; i < nb * kRowDoubles; i += 64) {
                 const int r = i / kRowDoubles, q = i - r * kRowDoubles;
@@ -1062,7 +1101,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         // and no LDS reads in the pair loop
         // (the window, dilution and exclusion constants are used once per 64 cells: those stay in LDS)
         RowC cu;
-        if (LONG) {
+        if (LONG && !TRX_LONG_ROWS_IN_LDS) {
             const RowC& r0 = rows[0];
             cu.k = uniform(r0.k); cu.t0 = uniform(r0.t0); cu.nmot = uniform(r0.nmot); cu.e = uniform(r0.e);
             cu.Mtr = uniform(r0.Mtr); cu.ax = uniform(r0.ax); cu.ay = uniform(r0.ay); cu.bx = uniform(r0.bx);
@@ -1073,10 +1112,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         double lacc = 0.0;                 // LONG: this lane's share of the row's chi^2
         bool nonflat = false;              // LONG: a cell of this lane has a model value other than 1
         // PRUNE: lnprior of this lane's row (lanes = rows) and the rows abandoned so far
-        double lp_row = 0.0;
         unsigned long long deadmask = 0;
         bool long_dead = false;
-        if (PRUNE && a.prune_lp && lane < nb) lp_row = a.prune_lp[a.src_idx ? (long)a.src_idx[rowid] : rowid];
+        if (PRUNE && lane < nb) hlp[lane] = a.prune_lp ? a.prune_lp[a.src_idx ? a.src_idx[rowid] : rowid] : 0.0;
+#define lp_row (hlp[lane < nb ? lane : 0])
         bool probe_done = false;           // split, part 2: the batch ends with the verdict
         const unsigned long long exclmask = skipmask;       // the rows the EB secondary rule excludes (+inf)
         // The probe pass (split, part 2) ends with the verdict: an abandoned row reports its bound, an excluded one
@@ -1086,7 +1125,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         // 15 % faster where the arithmetic allows 2.5 x.
         auto finish_probe = [&]() __attribute__((always_inline)) {
             const bool in_batch = lane < nb;
-            const bool is_dead = (deadmask >> lane) & 1ull, is_excl = (exclmask >> lane) & 1ull;
+            const bool is_dead = mask_bit(deadmask, lane), is_excl = mask_bit(exclmask, lane);
             const bool alive = in_batch && !is_dead && !is_excl;
             if (in_batch && !alive) a.out[rowid] = is_excl ? INFINITY : hrem[lane];
             const unsigned long long ma = __ballot(alive);
@@ -1117,7 +1156,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             const double hmin_run = __hip_atomic_load(&hdr[kHdrHmin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double xmax_run = __hip_atomic_load(&hdr[kHdrXmax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool shallow = false;
-            if (lane < nb && !((skipmask >> lane) & 1ull)) {
+            if (lane < nb && !mask_bit(skipmask, lane)) {
                 const double lb = depth_screen(hdr, depth_bound(rows[lane]));
                 shallow = hmout[lane] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp_row) < xmax_run - 90.0;
 #ifdef TRX_PRUNE_NEVER_DEAD
@@ -1163,15 +1202,16 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     j = valid ? (cell - rr * n_time) : 0;
                 }
                 bool inw = false;
+                TRX_CENSUS_ADD(kCenWindowTrip, 1);
                 // (a trip all of whose rows are settled -- abandoned, excluded -- has nothing to test)
-                if (PRUNE && !LONG && !__any(valid && !((skipmask >> rr) & 1ull))) continue;
+                if (PRUNE && !LONG && !__any(valid && !mask_bit(skipmask, rr))) continue;
                 if (valid) {
-                    const RowC& c = LONG ? cu : rows[rr];
+                    const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
                     const double phase = c.nmot * (tl[j] - c.t0);
                     const double dMc = reduce_2pi(phase);
                     const double slack = 1e-15 * fabs(phase);
                     const RowC& cw = rows[rr];                       // (LONG: rr = 0)
-                    inw = in_window(cw.wlo - slack, cw.whi + slack, dMc) && !((skipmask >> rr) & 1ull);
+                    inw = in_window(cw.wlo - slack, cw.whi + slack, dMc) && !mask_bit(skipmask, rr);
                     // no occultation anywhere in the exposure: the model is 1, diluted
                     if (MODE == MODE_GRID && (!inw || a.debug_nodes))
                         a.out[(size_t)base * n_time + cell] = a.debug_nodes ? 0.0 : hmout[rr];
@@ -1214,6 +1254,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             int carry_rel = 0;
             for (int w0 = 0, step = 64; w0 < count; w0 += step) {
                 TRX_TICK(t_plan);
+                TRX_CENSUS_ADD(sweep ? kCenChunk1 : kCenChunk0, 1);
                 bool owned = true;
                 bool valid = (w0 + lane) < count;
                 int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
@@ -1240,14 +1281,15 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (LONG && MODE == MODE_LNL) fobs = fl[j];          // in flight during the chunk
                 CellPlan pl;
                 if (valid) {
-                    const RowC& c = LONG ? cu : rows[rr];
+                    const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
 #ifndef TRX_PLAN_FULL_SOLVE
                     // (one row per wave only: in the batched variant the second code path costs more -- measured
                     // -2 % at 100-200 points -- than the criteria it skips; +1-3 % here)
                     if (LONG && sweep == 1) pl = plan_all_subexposures<PRUNE>(c, t, a.S);      // filed as such by the first sweep
                     else
 #endif
-                    pl = plan_cell<false, PRUNE>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0);
+                    pl = plan_cell<false, PRUNE, TRX_TIER_LDS(PRUNE, LONG)>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0,
+                                                 thead);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
                         kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
@@ -1297,6 +1339,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 for (int s0 = 0; __any(s0 < nodes || (ST && s0 == 0 && centre)); s0 += per) {
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
+                    TRX_CENSUS_ADD(kCenPass, 1);
                     const int extra = (ST && s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
                     // (first sweep: at most 9 nodes + the centre per cell -- four ballots; contact cells: up to S)
                     int total;
@@ -1311,13 +1354,15 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     // LDS unit takes them in lane order: node order, bit-repeatable)
                     for (int p0 = 0; p0 < total; p0 += 64) {
                         const int p = p0 + lane;
+                        TRX_CENSUS_ADD(kCenPairTrip, 1);
+                        TRX_CENSUS_ADD(kCenPairLanes, (unsigned long long)(total - p0 < 64 ? total - p0 : 64));
                         if (p < total) {
                             const int d = (int)pdesc[p];
                             const int h = d & 63;
                             const bool at_centre = ST && (d >> 6) == kCentreNode;
                             const int s = at_centre ? 0 : s0 + (d >> 6);
                             const unsigned meta = cs.meta[h];
-                            const RowC& c = LONG ? cu : rows[meta & 0xffu];
+                            const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[meta & 0xffu];
                             const int ht = (int)((meta >> 8) & 0xffu) - 1;
                             double sE = cs.sE[h], cE = cs.cE[h];
                             if (!at_centre) {
@@ -1327,7 +1372,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                                 const double dM = c.nmot * (a.exptime * frac);
                                 bool have = false;
                                 if (STEP && (meta & 0x10000u)) have = kepler_step<PRUNE>(dM, c.e, sE, cE);
-                                if (!have) kepler_full(c.nmot * ((cs.t[h] + a.exptime * frac) - c.t0) + c.Mtr, c.e, sE, cE);
+                                if (!have) {
+                                    TRX_CENSUS_ADD(kCenKeplerFullPair, 1);
+                                    kepler_full(c.nmot * ((cs.t[h] + a.exptime * frac) - c.t0) + c.Mtr, c.e, sE, cE);
+                                }
                             }
                             const double ce = cE - c.e;
                             const double X = fma(c.ax, ce, c.bx * sE);
@@ -1338,7 +1386,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             double f = 1.0;
                             if (Y >= 0.0 && z2 < opp * opp) {
                                 const Limb L{c.cle, c.cld, c.ced};
-                                f = disc_flux<FP32>(sqrt_fast(z2), c.k, L, atab);
+                                f = disc_flux<FP32, TRX_ATAN_TAB(PRUNE, LONG)>(sqrt_fast(z2), c.k, L, atab);
                             } else if (z2 != z2) {
                                 f = z2;
                             }
@@ -1361,7 +1409,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     const int spent = nodes + ((ST && centre) ? 1 : 0);
                     if (spent > 0) atomicAdd(&a.out[(size_t)base * n_time + cell], (double)spent);
                 } else if (valid && owned) {
-                    const RowC& c = LONG ? cu : rows[rr];
+                    const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
                     double fsum = cs.facc[lane];
                     if (ST && st) {
                         // the S-point average of the interpolant through the 2 kStM + 1 centre values
@@ -1409,7 +1457,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (LONG) {
                     double lb = 0.5 * wave_sum(lacc);
                     lb -= fma(1e-9, fabs(lb), 1e-9);                       // summation order
-                    const double lp0 = __shfl(lp_row, 0, 64);
+                    const double lp0 = hlp[0];
                     long_dead = hmout[0] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp0) < xmax_run - 90.0;
                     if (long_dead) {
                         if (lane == 0) a.out[base] = lb;
@@ -1418,7 +1466,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     }
                 } else {
                     bool dead = false;
-                    if (lane < nb && !((skipmask >> lane) & 1ull)) {
+                    if (lane < nb && !mask_bit(skipmask, lane)) {
                         double lb = 0.5 * (flat_sum + hacc[lane] - hrem[lane]);
                         lb -= fma(1e-9, fabs(lb) + flat_sum, 1e-9);        // cancellation between the three sums
                         dead = hmout[lane] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp_row) < xmax_run - 90.0;
@@ -1464,12 +1512,12 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 if (lane < nb) {
                     h = (hmout[lane] == 1.0 || n_time == 0) ? 0.5 * (flat_sum + hacc[lane]) : NAN;
                     if (a.model == TRX_MODEL_EB && rows[lane].excl != 0.0) h = INFINITY;  // :535-538
-                    if (PRUNE && ((deadmask >> lane) & 1ull)) h = hrem[lane];
+                    if (PRUNE && mask_bit(deadmask, lane)) h = hrem[lane];
                     a.out[rowid] = h;
                 }
                 if (PRUNE && (probing || a.part == 1 || a.part == 3)) {
                     // the batch's best finished row tightens the launch's running bounds (one wave, one update)
-                    const bool fin = lane < nb && !((deadmask >> lane) & 1ull) && h < INFINITY;      // (false for NaN)
+                    const bool fin = lane < nb && !mask_bit(deadmask, lane) && h < INFINITY;      // (false for NaN)
                     double hb = fin ? h : INFINITY, xb = fin ? a.prune_c0 - h + lp_row : -INFINITY;
                     if (!(xb == xb)) xb = -INFINITY;
 #pragma unroll
@@ -1491,6 +1539,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         __syncthreads();
         for (int i = threadIdx.x; i < nk; i += 64 * W) a.surv_list[wg_at + i] = wg_keep[i];
     }
+#undef lp_row
     if (lane == 0) {
         add_row_stat(0, n_skipped);
         add_row_stat(1, n_pruned);
@@ -2406,9 +2455,9 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     // then per wave [rows, accumulators | pair table | in-window list | cell state (| stencil state)]
     static_assert((kCellsPairs + kCellsWindowLong) % 4 == 0 && (kCellsPairs + kCellsWindowBatch) % 4 == 0 &&
                   sizeof(CellState) % 8 == 0 && sizeof(StencilState) % 8 == 0, "8-byte alignment of the LDS arrays");
-    const size_t tables = (size_t)(2 * kTiers * kTierMaxNodes + kAtanRanges * kAtanCols) * sizeof(double);
+    const size_t tables = (size_t)(2 * kTiers * kTierMaxNodes + kAtanRanges * kAtanCols + kTierHeadDoubles) * sizeof(double);
     auto wave_bytes = [&](bool long_variant) -> size_t {
-        return (size_t)a.B * (kRowDoubles + 3) * sizeof(double)
+        return (size_t)a.B * (kRowDoubles + 4) * sizeof(double)
              + (kCellsPairs + cells_window(long_variant)) * sizeof(unsigned short) + sizeof(CellState)
              + (long_variant ? sizeof(StencilState) : 0);
     };
@@ -3109,6 +3158,19 @@ int trx_set_debug_node_counts(int on)
     g_debug_nodes = on ? 1 : 0;
     return TRX_OK;
 }
+
+#ifdef TRX_CENSUS
+int trx_debug_census(unsigned long long* out32, int reset)
+{
+    TRX_HIP(hipDeviceSynchronize());
+    if (out32) TRX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(trx::g_census), 32 * sizeof(unsigned long long)));
+    if (reset) {
+        static const unsigned long long zeros[32] = {};
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(trx::g_census), zeros, sizeof(zeros)));
+    }
+    return TRX_OK;
+}
+#endif
 
 #ifdef TRX_PHASE_TIMERS
 /* debug builds only: read (and clear) the phase cycle counters */
