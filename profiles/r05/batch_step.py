@@ -18,6 +18,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 jobs = synth.toi_jobs(tois, n_time=200, N=N, seed=synth.SEED, trilegal_fname=os.path.join(GOLD, "trilegal_synth.csv"),
                       contrast_curve_file=os.path.join(GOLD, "contrast_curve_synth.csv"))
 triceratops_amd.set_sampling("device")
+if os.environ.get("NOGC"):
+    import gc
+    gc.disable()
 for s in range(steps + 1):
     torch.manual_seed(s)
     torch.cuda.synchronize()

@@ -132,7 +132,7 @@ def test_rows_never_written_are_reported_not_read(chain):
     two counts fell on different sides of a step of batch_rows, the last batches were never written, the stale chi^2 of
     the stream's previous call read as a result, and the 75-scenario blend's FPP came out as 1.  trx_set_debug_bug(1)
     switches that exit rule back on.  TOI-411.02 (a 166 ppm signal: the pilot's verdict is "probing does not pay") at
-    N = 3e5 has scenarios on such a step (profiles/r05/scan_debug_bug.txt: 26 of 27 values of N between 1.5e5 and 4.1e5
+    N = 3e5 has scenarios on such a step (profiles/r05/scan_debug_bug.txt: 18 of 27 values of N between 1.5e5 and 4.1e5
     do): the run must now FAIL with TrxError -- record status 1, a row still carries rowc_kernel's mark -- instead of
     returning numbers, through the chain and call by call."""
     import anchors

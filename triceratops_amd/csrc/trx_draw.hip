@@ -705,17 +705,35 @@ __global__ __launch_bounds__(256) void draw_kernel_star(const trx_draw_args* __r
 // writing the columns and the prior.  A draw passes at most one of the two masks of a binary scenario.  Draw 0 is
 // always filled: it stands in for the best draw of a branch no draw passed.
 constexpr int kFillList = 128;
+#ifndef TRX_FILL_WAVES
+#define TRX_FILL_WAVES 4
+#endif
+// hand-over between the lanes of ONE wave through LDS (its operations are performed in order: a compiler fence is enough)
+__device__ __forceinline__ void fill_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// W waves per workgroup, each with draw workgroups of its own (chunk = blockIdx.x * W + wave); they share the staged
+// tables (10.5 KB of LDS, staged once per workgroup instead of once per wave) and nothing else.
+template <int W>
 __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long per, int groups, int gper,
                                                   const int* __restrict__ blk_cnt, int* __restrict__ idx0,
                                                   int* __restrict__ idx1, long* __restrict__ n_out)
 {
     __shared__ Tables T;
-    __shared__ int hits[kFillList];
-    const int br = blockIdx.y, lane = threadIdx.x;
+    __shared__ int hits_all[W][kFillList];
+    const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int br = blockIdx.y, lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    int* hits = hits_all[wave];
     const unsigned char* mask = br ? a.mask_twin : a.mask;
     int* idx = br ? idx1 : idx0;
     const int* cnt = blk_cnt + (long)br * groups;
-    const int g0 = blockIdx.x * gper, g1 = (g0 + gper < groups) ? g0 + gper : groups;
+    const int chunk = (int)blockIdx.x * W + wave;
+    int g0 = chunk * gper, g1 = (g0 + gper < groups) ? g0 + gper : groups;
+    if (g0 > groups) g0 = g1 = groups;                       // (a wave beyond the last chunk: nothing of its own)
     long at = 0;
     for (int j = lane; j < g0; j += 64) at += cnt[j];
 #pragma unroll
@@ -724,10 +742,11 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
     for (int j = g0 + lane; j < g1; j += 64) mine += cnt[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-    if (g1 == groups && lane == 0) n_out[br] = at + mine;
-    const bool first = blockIdx.x == 0 && br == 0;          // this workgroup also fills draw 0
+    if (g1 == groups && g0 < groups && lane == 0) n_out[br] = at + mine;
+    const bool first = chunk == 0 && br == 0;               // this wave also fills draw 0
+    if (W == 1 && mine == 0 && !first) return;
+    stage_tables(a, T);                                      // (every thread of the workgroup: it ends with the barrier)
     if (mine == 0 && !first) return;
-    stage_tables(a, T);
     const bool parallel = a.parallel != 0;
     const long N = a.N;
     const long end = ((long)g1 * per < N) ? (long)g1 * per : N;
@@ -759,16 +778,19 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
             zero_done = true;
         }
         if (nh == 0) break;
-        __syncthreads();
+        fill_wave_sync();
         const int take = nh < 64 ? nh : 64;
         if (lane < take) {
             bool h0, h1;
             draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1);
         }
-        __syncthreads();
-        if (lane < nh - take) hits[lane] = hits[take + lane];
+        fill_wave_sync();
+        int carry = 0;
+        if (lane < nh - take) carry = hits[take + lane];
+        fill_wave_sync();
+        if (lane < nh - take) hits[lane] = carry;
         nh -= take;
-        __syncthreads();
+        fill_wave_sync();
     }
 }
 
@@ -776,22 +798,23 @@ __global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long 
                                                           const int* __restrict__ blk_cnt, int* __restrict__ idx0,
                                                           int* __restrict__ idx1, long* __restrict__ n_out)
 {
-    compact_fill_body(a, per, groups, gper, blk_cnt, idx0, idx1, n_out);
+    compact_fill_body<1>(a, per, groups, gper, blk_cnt, idx0, idx1, n_out);
 }
 
-// chain: grid = (draw workgroups, 2 branches, calls); a planet call has one branch and one draw workgroup per wave
+// chain: grid = (draw workgroups / kFillWaves, 2 branches, calls); a planet call has one branch and one draw workgroup per wave
 struct FillTab {
     trx::ChainFill f[trx::kChainMaxCalls];
 };
-__global__ __launch_bounds__(64) void compact_fill_kernel_star(const trx_draw_args* __restrict__ tab, FillTab ft, long per, int groups,
-                                                               const int* __restrict__ blk_cnt_all)
+constexpr int kFillWaves = TRX_FILL_WAVES;
+__global__ __launch_bounds__(64 * kFillWaves) void compact_fill_kernel_star(const trx_draw_args* __restrict__ tab, FillTab ft, long per,
+                                                                           int groups, const int* __restrict__ blk_cnt_all)
 {
     const trx_draw_args& a = tab[blockIdx.z];
     const int gper = a.planet ? 1 : 2;
     if (a.planet && blockIdx.y) return;
-    if ((int)blockIdx.x * gper >= groups) return;
+    if ((int)blockIdx.x * kFillWaves * gper >= groups) return;
     const trx::ChainFill& f = ft.f[blockIdx.z];
-    compact_fill_body(a, per, groups, gper, blk_cnt_all + (long)blockIdx.z * 2 * trx::kDrawMaxGroups, f.idx0, f.idx1, f.n_dev);
+    compact_fill_body<kFillWaves>(a, per, groups, gper, blk_cnt_all + (long)blockIdx.z * 2 * trx::kDrawMaxGroups, f.idx0, f.idx1, f.n_dev);
 }
 
 }  // namespace
@@ -883,8 +906,8 @@ int trx::draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab
     const int groups = (int)((N + per - 1) / per);
     if (pretest) hipLaunchKernelGGL(draw_kernel_star<2>, dim3((unsigned)groups, (unsigned)n_calls), dim3(256), 0, st, dev_tab, blk_cnt, per);
     else         hipLaunchKernelGGL(draw_kernel_star<1>, dim3((unsigned)groups, (unsigned)n_calls), dim3(256), 0, st, dev_tab, blk_cnt, per);
-    hipLaunchKernelGGL(compact_fill_kernel_star, dim3((unsigned)groups, 2u, (unsigned)n_calls), dim3(64), 0, st, dev_tab, ft, per, groups,
-                       (const int*)blk_cnt);
+    hipLaunchKernelGGL(compact_fill_kernel_star, dim3((unsigned)((groups + kFillWaves - 1) / kFillWaves), 2u, (unsigned)n_calls),
+                       dim3(64 * kFillWaves), 0, st, dev_tab, ft, per, groups, (const int*)blk_cnt);
     *per_out = per;
     *groups_out = groups;
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;

@@ -408,8 +408,11 @@ __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.
 // evaluated to the end -- they give the launch's running bounds their first values, so that the bound bites from the
 // first wave of the later passes on, and they tell whether probing pays at all: pilot_stats_kernel switches it off
 // (header slot kHdrProbe) when few pilot rows lie far above the pilot's best.
+// (1024 since round 5: with the calls of a target in one launch chain the pilot is a launch of 18 x kPilotRows one-row waves
+// that nothing overlaps; 512 / 1024 / 2048 / 4096 rows: 64-TOI step 0.139 / 0.139 / 0.144 / 0.155 s, 75-scenario
+// calc_probs 17.6 / 17.6 / 18.0 / 18.6 ms -- profiles/r05/ab_pilot_rows.txt)
 #ifndef TRX_PILOT_ROWS
-#define TRX_PILOT_ROWS 2048
+#define TRX_PILOT_ROWS 1024
 #endif
 constexpr long kPilotRows = TRX_PILOT_ROWS;
 // Light curves shorter than this are evaluated in full: with fewer than three stamps per probe cell there is nothing to

@@ -54,6 +54,9 @@ last_seed_bases = None
 # what the schedule of the last run_units gave every rank: lnZ_* calls, distinct (job, star)s and distinct jobs
 last_share = {"calls": [0], "stars": [0], "jobs": [0]}
 _warned_bases = False
+# True: the first device pass calls gc.freeze() once (see _run_units); set to False to leave the collector alone
+freeze_gc = True
+_gc_frozen = False
 # The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
 # their scratch together stays near this many draws' worth (6 streams at N = 1e6, 2 at N >= 3e6)
 scratch_budget_draws = 6_000_000
@@ -169,9 +172,13 @@ def run_units(units, verbose=0):
                        [units[k][8] for k in live] if all(len(units[k]) > 8 for k in live) else None)
         owner = {k: own[i] for i, k in enumerate(live)}
     global last_share
-    last_share = {"calls": [sum(1 for k in live if owner[k] == r) for r in range(world)],
-                  "stars": [len({_star_of(units[k]) for k in live if owner[k] == r}) for r in range(world)],
-                  "jobs": [len({_job_of(units[k]) for k in live if owner[k] == r}) for r in range(world)]}
+    calls, stars, jobs = [0] * world, [set() for _ in range(world)], [set() for _ in range(world)]
+    for k in live:                          # (one pass over the units: this runs on every rank for ALL units)
+        r = owner[k]
+        calls[r] += 1
+        stars[r].add(_star_of(units[k]))
+        jobs[r].add(_job_of(units[k]))
+    last_share = {"calls": calls, "stars": [len(x) for x in stars], "jobs": [len(x) for x in jobs]}
     # calc_probs keeps the best draw of every scenario only: with the device generator the fused
     # path then selects it with one argmin instead of a top-100 sort (fused.TABLE_ROWS)
     from . import fused as _fused
@@ -300,6 +307,21 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
         _fused.begin_deferred(len(mine_k))
         drained = False
+        # The cyclic garbage collector is held off while the calls are enqueued and awaited: a pass builds a few thousand
+        # small objects (argument blocks, closures, Pending records; no reference cycles among them), which now and then
+        # tips the collector into a FULL collection -- 75 ms in a process that has imported torch and pandas, inside a
+        # 140 ms step (every fourth 64-target step: profiles/r05/gc_pause.txt).  Reference counting frees the pass's
+        # objects as before; the collector is switched back on (if it was on) when the pass is over.
+        import gc
+        global _gc_frozen
+        if freeze_gc and not _gc_frozen:
+            # (once: the objects alive now -- torch, pandas, the star tables -- move to the collector's permanent
+            # generation, so the full collection that follows a held-off pass looks at the pass's objects only)
+            gc.collect()
+            gc.freeze()
+            _gc_frozen = True
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             import time
             t0 = time.perf_counter()
@@ -335,6 +357,8 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                     st.synchronize()
             pending.clear()
             _fused.end_deferred()
+            if gc_was_on:
+                gc.enable()
     else:
         import queue
         import threading
