@@ -420,6 +420,7 @@ constexpr long kPilotRows = TRX_PILOT_ROWS;
 // probe pass then declined to probe while the third pass waited for its list -- rows behind the pilot were never
 // written whenever the pilot's verdict was "probing pays".  tests/test_gpu_bounded.py::test_very_short_light_curves...)
 constexpr int kProbeMinPoints = 48;
+constexpr int kProbeCells = 16;
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
 // Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
@@ -2448,7 +2449,9 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
                        (long_rows || (long)a.B * a.n_time <= (long)kCellsWindowBatch) &&
                        a.n_time >= kProbeMinPoints;
     a.prune = prune ? 1 : 0;
-    a.pstride = prune ? a.n_time / 16 : 1;
+    // probe cells per row: every (n_time / kProbeCells)-th stamp (TRX_PROBE_CELLS in the environment: experiments)
+    static const int probe_cells = getenv("TRX_PROBE_CELLS") ? atoi(getenv("TRX_PROBE_CELLS")) : kProbeCells;
+    a.pstride = prune ? (a.n_time / probe_cells > 1 ? a.n_time / probe_cells : 2) : 1;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
     a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
