@@ -15,9 +15,10 @@
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null
  *     stream) and the call returns without synchronising: safe to call concurrently on
  *     different streams / devices.  The entry points that evaluate the light-curve model
- *     (trx_lnl_batch, trx_flux_grid, trx_lnz_scenario, trx_scenario_evidence) keep scratch per
+ *     (trx_lnl_batch, trx_flux_grid, trx_lnz_scenario, trx_scenario_evidence, trx_star_enqueue) keep scratch per
  *     (device, stream) inside the library -- 152 B per row for the per-row constants, the draw
- *     block of trx_scenario_evidence (~0.36 GB per stream at N = 1e6 draws) -- which serves call after call on that stream and only
+ *     block of trx_scenario_evidence (~0.36 GB per stream at N = 1e6 draws), the arena of a launch chain of
+ *     trx_star_enqueue (that much per call of the chain) -- which serves call after call on that stream and only
  *     grows (the stream is synchronised before a buffer is replaced by a larger one);
  *     trx_release_scratch() frees it all.  Two host threads that enqueue on ONE stream take turns (a
  *     per-stream lock is held while a call enqueues its kernels; the stream's order does the rest).

@@ -101,6 +101,7 @@ struct RowsArgs {
     // Bounded evaluation (trx_scenario_evidence only; cells_kernel<..., PRUNE>): see cells_body
     int prune;         // 1: rows that provably carry no weight in the evidence and cannot be its best draw are abandoned
     int pstride;       // every pstride-th time stamp of a row is a probe cell (evaluated first)
+    int pstride3;      // the survivors' pass of batches (part 3): its own first phase, every pstride3-th stamp; 0 = one phase
     double prune_c0;   // -ln(2 pi)/2 - ln sigma: log-weight of a row = prune_c0 - chi^2/2 + lnprior
     const double* prune_lp;   // lnprior per DRAW (indexed through src_idx), or null
     int part;          // PRUNE: 1 = the pilot rows [0, min(n, kPilotRows)), 2 = the rows behind them, 0 = all rows;
@@ -421,6 +422,7 @@ constexpr long kPilotRows = TRX_PILOT_ROWS;
 // written whenever the pilot's verdict was "probing pays".  tests/test_gpu_bounded.py::test_very_short_light_curves...)
 constexpr int kProbeMinPoints = 48;
 constexpr int kProbeCells = 16;
+constexpr int kThirdStride = 0;          // (0: the survivors' pass in one phase; see cells_body)
 static_assert(kHdrStW + 2 * kStM + 1 <= kHdrDoubles, "launch header");
 
 // Undecided-row list of the secondary-eclipse scan, in FRONT of the row blocks in scratch (a place that does not
@@ -1037,7 +1039,15 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     }
     // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes, nor
     // does the pass over the listed rows)
-    const bool probing = PRUNE && a.pstride > 1 && (a.part == 0 || a.part == 2) && hdr[kHdrProbe] != 0.0;
+    // The survivors' pass of the batched variant (part 3) looks at the bound once more: a row survives the probe pass
+    // whenever its ~16 probe cells and its out-of-window cells do not prove it negligible -- the unprobed in-window
+    // cells are taken to fit perfectly -- and nine survivors in ten are still far from the best (profiles/
+    // r03_f_prune_potential.txt: 4.6 % of TOI-465.01's rows survive 16 cells, 0.5 % lie within 90 of the best).  Its first
+    // phase takes every a.pstride3-th stamp (a quarter of the row), the verdict drops what that proves negligible, the
+    // second phase finishes the rest.
+    const int pstride = (PRUNE && !LONG && a.part == 3 && a.pstride3 > 1) ? a.pstride3 : a.pstride;
+    const bool probing = PRUNE && pstride > 1 && hdr[kHdrProbe] != 0.0 &&
+                         (a.part == 0 || a.part == 2 || (!LONG && a.part == 3 && a.pstride3 > 1));
     if (PRUNE && a.split && a.part == 2 && !probing) return;       // nothing to probe: part 3 takes the rows directly
     // (one row per wave: nothing to taper -- an XCD's waves take consecutive rows of its eighth)
     // (a row count read from the device is wave-uniform, which the compiler cannot know: the plan belongs in scalar
@@ -1230,7 +1240,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                             __hip_atomic_fetch_add(&hrem[rr], (d * d) * rs2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (nphase == 2) {
-                            const bool probe = (j % a.pstride) == (a.pstride >> 1);
+                            const bool probe = (j % pstride) == (pstride >> 1);
                             inw = inw && (probe == (phase_no == 0));
                         }
                     }
@@ -2452,6 +2462,8 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     // probe cells per row: every (n_time / kProbeCells)-th stamp (TRX_PROBE_CELLS in the environment: experiments)
     static const int probe_cells = getenv("TRX_PROBE_CELLS") ? atoi(getenv("TRX_PROBE_CELLS")) : kProbeCells;
     a.pstride = prune ? (a.n_time / probe_cells > 1 ? a.n_time / probe_cells : 2) : 1;
+    static const int third_stride = getenv("TRX_THIRD_STRIDE") ? atoi(getenv("TRX_THIRD_STRIDE")) : kThirdStride;
+    a.pstride3 = (prune && third_stride > 1 && a.n_time >= 4 * third_stride) ? third_stride : 0;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
                      g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
     a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
