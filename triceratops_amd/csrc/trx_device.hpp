@@ -1004,6 +1004,9 @@ constexpr int kScenTies = 16, kScenStatus = 17;
 struct ScenFinal {
     const int* idx;                   // the branch's list of masked draws
     const double* cols;               // [ncol][N]
+    const double* cols0;              // dense: [ncol] draw 0's columns (no draw passed the mask)
+    int dense;                        // the masked draws' columns sit densely in `cols` (compact_fill_kernel): row r at
+                                      // position r (branch 1: N - 1 - r); 0: at their draw index idx[r]
     long N, n_total;
     int ncol, branch, last_branch;
     double* res;                      // this branch's record
@@ -1053,8 +1056,13 @@ __device__ __forceinline__ void scenario_final(const ScenFinal& f, const double*
     else if (t.pinf & 1) lnz = INFINITY;                          // _numerics.py:46-47
     else if (t.m == -INFINITY) lnz = -INFINITY;                   // :49-50
     else lnz = log(t.s) + t.m - log((double)f.n_total);           // :51
-    const long best = (bi >= 0) ? (long)f.idx[bi] : 0;
-    if (lane < f.ncol) f.res[lane] = f.cols[(long)lane * f.N + best];
+    if (f.dense) {
+        const long best = f.branch ? f.N - 1 - bi : bi;
+        if (lane < f.ncol) f.res[lane] = (bi >= 0) ? f.cols[(long)lane * f.N + best] : f.cols0[lane];
+    } else {
+        const long best = (bi >= 0) ? (long)f.idx[bi] : 0;
+        if (lane < f.ncol) f.res[lane] = f.cols[(long)lane * f.N + best];
+    }
     if (lane == f.ncol) f.res[f.ncol] = lnz;
     if (lane == f.ncol + 1) f.res[f.ncol + 1] = (double)n;
     if (lane == 62) {

@@ -415,11 +415,16 @@ __device__ __forceinline__ bool may_transit(const trx_draw_args& a, const Tables
 //            column is written: 90-95 % of the draws fail the geometry and are never looked at again
 //   PHASE 2  the columns and the prior of a draw that passed (compact_fill_kernel): the same
 //            code on the same counter-based random numbers, hence the same values
+//            Where a draw's columns go: PHASE 0 at its own index of the [ncol][N] block (every draw has a place);
+//            PHASE 2 where the caller says (col_at, col_stride, prior_at): compact_fill_kernel stores the masked draws
+//            DENSELY, in list order -- the likelihood kernels then read coalesced runs instead of one 64-byte line per
+//            column and row (the masked draws are one in ten: read in place they cost 700 MB of traffic per target)
 template <int PHASE>
 __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T, const long i, const bool parallel,
-                                         bool& hit, bool& hit_twin)
+                                         bool& hit, bool& hit_twin, double* col_at = nullptr, long col_stride = 0,
+                                         double* prior_at = nullptr)
 {
-    const long N = a.N;
+    const long N = (PHASE == 2) ? col_stride : a.N;
     hit = hit_twin = false;
     Uniforms rnd(a.seed, i);
     double dP = 0.0, dQc = 0.0, dRp = 0.0, dQ = 0.0, dEcc = 0.0, dIdx = 0.0, dBeta = 0.0;
@@ -480,7 +485,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
     const double sinw = sin(w * kPi / 180.0);
     double ecc, lnprior = 0.0, dm = 0.0;
     bool dm_set = false;
-    double* col = a.cols + i;
+    double* col = (PHASE == 2) ? col_at : a.cols + i;
     if (a.planet) {
         if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
         else {
@@ -592,8 +597,10 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
         lnprior = (lnprior > 0.0) ? 0.0 : lnprior;     // clamp_max: NaN stays NaN
         if (dm > 0.0) lnprior = -INFINITY;
     }
-    if (PHASE != 1 && a.lnprior) a.lnprior[i] = lnprior;
-    if (PHASE != 1 && a.dump) {
+    if (PHASE == 0 && a.lnprior) a.lnprior[i] = lnprior;
+    if (PHASE == 2 && prior_at) *prior_at = lnprior;
+    if (PHASE == 0 && a.dump) {
+        const long N = a.N;
         double* dd = a.dump + i;
         dd[0 * N] = dP; dd[1 * N] = dQc; dd[2 * N] = dRp; dd[3 * N] = dInc; dd[4 * N] = dQ;
         dd[5 * N] = dEcc; dd[6 * N] = dW; dd[7 * N] = (double)k; dd[8 * N] = dBeta;
@@ -718,16 +725,21 @@ __device__ __forceinline__ void fill_wave_sync()
 
 // W waves per workgroup, each with draw workgroups of its own (chunk = blockIdx.x * W + wave); they share the staged
 // tables (10.5 KB of LDS, staged once per workgroup instead of once per wave) and nothing else.
+// Where the masked draws' columns go (dense layout): row r of branch 0 at position r of the [ncol][N] block, row r of the
+// twin branch at position N - 1 - r (a draw passes at most one of the two masks, so the two runs never meet); the
+// prior likewise.  Draw 0 -- the stand-in for the best draw of a branch no draw passed -- goes to `cols0` [ncol].
 template <int W>
 __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long per, int groups, int gper,
                                                   const int* __restrict__ blk_cnt, int* __restrict__ idx0,
-                                                  int* __restrict__ idx1, long* __restrict__ n_out)
+                                                  int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0)
 {
     __shared__ Tables T;
     __shared__ int hits_all[W][kFillList];
+    __shared__ int hpos_all[W][kFillList];
     const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int br = blockIdx.y, lane = W > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     int* hits = hits_all[wave];
+    int* hpos = hpos_all[wave];
     const unsigned char* mask = br ? a.mask_twin : a.mask;
     int* idx = br ? idx1 : idx0;
     const int* cnt = blk_cnt + (long)br * groups;
@@ -767,13 +779,13 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
             if (hit) {
                 idx[at + below] = (int)i;
                 hits[nh + below] = (int)i;
+                hpos[nh + below] = (int)(at + below);
             }
-            zero_done = zero_done || (i0 == 64 && (m & 1ull));          // (draw 0 is lane 0 of the first trip)
             at += __popcll(m);
             nh += __popcll(m);
         }
-        if (i0 >= end && !zero_done) {     // draw 0 failed this mask: filled all the same
-            if (lane == 0) hits[nh] = 0;
+        if (i0 >= end && !zero_done) {     // draw 0 once more, for the stand-in record (position -1: cols0)
+            if (lane == 0) { hits[nh] = 0; hpos[nh] = -1; }
             ++nh;
             zero_done = true;
         }
@@ -782,13 +794,17 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
         const int take = nh < 64 ? nh : 64;
         if (lane < take) {
             bool h0, h1;
-            draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1);
+            const int pos = hpos[lane];
+            const long at_col = br ? (N - 1 - (long)pos) : (long)pos;
+            double* col_at = (pos < 0) ? cols0 : a.cols + at_col;
+            double* prior_at = (pos < 0 || !a.lnprior) ? nullptr : a.lnprior + at_col;
+            draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1, col_at, (pos < 0) ? 1L : N, prior_at);
         }
         fill_wave_sync();
-        int carry = 0;
-        if (lane < nh - take) carry = hits[take + lane];
+        int carry = 0, carry_pos = 0;
+        if (lane < nh - take) { carry = hits[take + lane]; carry_pos = hpos[take + lane]; }
         fill_wave_sync();
-        if (lane < nh - take) hits[lane] = carry;
+        if (lane < nh - take) { hits[lane] = carry; hpos[lane] = carry_pos; }
         nh -= take;
         fill_wave_sync();
     }
@@ -796,9 +812,9 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
 
 __global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long per, int groups, int gper,
                                                           const int* __restrict__ blk_cnt, int* __restrict__ idx0,
-                                                          int* __restrict__ idx1, long* __restrict__ n_out)
+                                                          int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0)
 {
-    compact_fill_body<1>(a, per, groups, gper, blk_cnt, idx0, idx1, n_out);
+    compact_fill_body<1>(a, per, groups, gper, blk_cnt, idx0, idx1, n_out, cols0);
 }
 
 // chain: grid = (draw workgroups / kFillWaves, 2 branches, calls); a planet call has one branch and one draw workgroup per wave
@@ -814,7 +830,8 @@ __global__ __launch_bounds__(64 * kFillWaves) void compact_fill_kernel_star(cons
     if (a.planet && blockIdx.y) return;
     if ((int)blockIdx.x * kFillWaves * gper >= groups) return;
     const trx::ChainFill& f = ft.f[blockIdx.z];
-    compact_fill_body<kFillWaves>(a, per, groups, gper, blk_cnt_all + (long)blockIdx.z * 2 * trx::kDrawMaxGroups, f.idx0, f.idx1, f.n_dev);
+    compact_fill_body<kFillWaves>(a, per, groups, gper, blk_cnt_all + (long)blockIdx.z * 2 * trx::kDrawMaxGroups, f.idx0, f.idx1, f.n_dev,
+                                  f.cols0);
 }
 
 }  // namespace
@@ -873,14 +890,14 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
 // reference's priors -- two waves of fills): 27-39 us for the planet scenarios (profiles/r04_j_draw_kernel.txt; with
 // 2048 draw workgroups of 512 draws it was 23-31, and the draw kernel 4 us slower: trx_internal.hpp).
 int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
-                      hipStream_t st)
+                      double* cols0, hipStream_t st)
 {
-    if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || groups < 1) return TRX_ERR_ARG;
+    if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || !cols0 || groups < 1) return TRX_ERR_ARG;
     // (binary scenarios: two branches scan the same draws, half as many masked draws each -- two draw workgroups per wave)
     const int gper = a.planet ? 1 : 2;
     const int chunks = (groups + gper - 1) / gper;
     hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks, a.planet ? 1u : 2u), dim3(64), 0, st, a, per, groups, gper,
-                       blk_cnt, idx0, idx1, n_dev);
+                       blk_cnt, idx0, idx1, n_dev, cols0);
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }
 
@@ -897,7 +914,7 @@ int trx::draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab
     for (int i = 0; i < n_calls; ++i) {
         if (host_args[i].N != N) return TRX_ERR_ARG;
         if (int rc = check_draw_args(host_args[i])) return rc;
-        if (!fills[i].idx0 || !fills[i].n_dev || (!host_args[i].planet && !fills[i].idx1)) return TRX_ERR_ARG;
+        if (!fills[i].idx0 || !fills[i].n_dev || !fills[i].cols0 || (!host_args[i].planet && !fills[i].idx1)) return TRX_ERR_ARG;
         pretest = pretest && host_args[i].pretest;
         ft.f[i] = fills[i];
     }

@@ -97,6 +97,8 @@ struct RowsArgs {
     const int* src_idx;
     long src_stride;
     int twin_cols;     // EB_TWIN rows of the draw kernel's block: P = 2 * column 2, a = column 11
+    int dense;         // the draw kernel's block holds the masked draws DENSELY (compact_fill_kernel): row r of the block is
+                       // column position r (twin rows: src_stride - 1 - r), not draw src_idx[r]; the prior per draw likewise
     int forced_B;      // trx_set_rows_per_wave
     // Bounded evaluation (trx_scenario_evidence only; cells_kernel<..., PRUNE>): see cells_body
     int prune;         // 1: rows that provably carry no weight in the evidence and cannot be its best draw are abandoned
@@ -167,6 +169,13 @@ __device__ __forceinline__ bool mask_bit(unsigned long long m, int i)
 {
     const unsigned w = (i & 32) ? (unsigned)(m >> 32) : (unsigned)m;
     return ((w >> (i & 31)) & 1u) != 0u;
+}
+
+// where row `row` of a launch sits in its parameter block / prior array (RowsArgs::params, prune_lp)
+__device__ __forceinline__ long row_pos(const RowsArgs& a, long row)
+{
+    if (a.dense) return a.twin_cols ? a.src_stride - 1 - row : row;
+    return a.src_idx ? (long)a.src_idx[row] : row;
 }
 
 // number of set bits of `m` below this lane
@@ -472,8 +481,8 @@ __device__ __forceinline__ void row_constants(const RowsArgs& a, const long n, c
     const bool is_host = (a.flags & TRX_FLAG_COMPANION_IS_HOST) != 0;
     const bool scalar_k = (a.flags & TRX_FLAG_SCALAR_K) != 0;
     // row r = column r of the [n_param][n] block, or draw src_idx[r] of a [n_param][src_stride] one
-    const double* p = a.params + (a.src_idx ? (long)a.src_idx[row] : row);
-    const long ps = a.src_idx ? a.src_stride : n;
+    const double* p = a.params + row_pos(a, row);
+    const long ps = (a.dense || a.src_idx) ? a.src_stride : n;
     double u1, u2;
     ysec = 0.0;
     fdil = 0.0;
@@ -1128,7 +1137,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         // PRUNE: lnprior of this lane's row (lanes = rows) and the rows abandoned so far
         unsigned long long deadmask = 0;
         bool long_dead = false;
-        if (PRUNE && lane < nb) hlp[lane] = a.prune_lp ? a.prune_lp[a.src_idx ? a.src_idx[rowid] : rowid] : 0.0;
+        if (PRUNE && lane < nb) hlp[lane] = a.prune_lp ? a.prune_lp[row_pos(a, rowid)] : 0.0;
 #define lp_row (hlp[lane < nb ? lane : 0])
         bool probe_done = false;           // split, part 2: the batch ends with the verdict
         const unsigned long long exclmask = skipmask;       // the rows the EB secondary rule excludes (+inf)
@@ -1830,7 +1839,17 @@ __device__ __forceinline__ void lme_partial_body(const double* __restrict__ logw
                 j = (j < nv) ? j : (nv - 1);
                 a[u] = __builtin_nontemporal_load(&src[j]);
                 if (SCEN) {
-                    if (lnprior) { p[u].x = lnprior[src_idx[2 * j]]; p[u].y = lnprior[src_idx[2 * j + 1]]; }
+                    if (lnprior) {
+                        // the prior of rows 2 j, 2 j + 1: dense (one 16-byte read; the twin branch's run is stored from
+                        // the top down), or by draw index through the list
+                        if (fin.dense) {
+                            if (fin.branch) { p[u].x = lnprior[fin.N - 1 - 2 * j]; p[u].y = lnprior[fin.N - 2 - 2 * j]; }
+                            else { p[u].x = lnprior[2 * j]; p[u].y = lnprior[2 * j + 1]; }
+                        } else {
+                            p[u].x = lnprior[src_idx[2 * j]];
+                            p[u].y = lnprior[src_idx[2 * j + 1]];
+                        }
+                    }
                 } else if (pri) p[u] = __builtin_nontemporal_load(&pri[j]);
             }
         };
@@ -1912,7 +1931,7 @@ __device__ __forceinline__ void lme_partial_body(const double* __restrict__ logw
                 argmin_merge(amin_v, amin_i, amin_c, hv, n - 1, 1);
                 unwritten = unwritten || (unsigned long long)__double_as_longlong(hv) == kUnwrittenBits;
                 double x = c0 - hv;
-                if (lnprior) x += lnprior[src_idx[n - 1]];
+                if (lnprior) x += lnprior[fin.dense ? (fin.branch ? fin.N - n : n - 1) : (long)src_idx[n - 1]];
                 if (x < floor_x) x = -INFINITY;
                 lme_fold4(st, x, -INFINITY, -INFINITY, -INFINITY);
             } else {
@@ -2359,7 +2378,7 @@ __device__ __forceinline__ void depth_screen_body(const RowsArgs& a)
                 // (a row the EB secondary rule excludes stays on the list: the probe pass reports its +inf and counts it)
                 if (!(excl_rule && c.excl != 0.0)) {
                     lb = depth_screen(tab - kHdrGrid, depth_bound(c));
-                    const double lp = a.prune_lp ? a.prune_lp[a.src_idx ? (long)a.src_idx[row] : row] : 0.0;
+                    const double lp = a.prune_lp ? a.prune_lp[row_pos(a, row)] : 0.0;
                     // (an unocculted cell must read exactly 1: a degenerate flux ratio makes it NaN, and so the row's chi^2)
                     const double m1 = fma(-(1.0 - 1.0), c.rdil, 1.0);
                     shallow = m1 == 1.0 && lb > hmin && (a.prune_c0 - lb + lp) < xmax - 90.0;
@@ -2804,6 +2823,7 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
     a.model = br[0].model; a.flags = br[0].flags; a.time = time; a.flux = br[0].flux; a.n_time = n_time; a.sigma = br[0].sigma;
     a.params = br[0].cols; a.n = N; a.exptime = exptime; a.S = S; a.out = br[0].h;
     a.n_dev = br[0].n_dev; a.src_idx = br[0].src_idx; a.src_stride = N; a.twin_cols = br[0].twin;
+    a.dense = 1;
     a.prune = 1;
     const bool batches = n_time > 0 && n_time < g_cells_below.load(std::memory_order_relaxed);
     CellsPlan P;
@@ -2866,6 +2886,7 @@ int lnl_draws(int model, int flags, const double* time, const double* flux, int 
     a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
     a.params = cols; a.n = n_upper; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
     a.n_dev = n_dev; a.src_idx = src_idx; a.src_stride = src_stride; a.twin_cols = twin;
+    a.dense = 1;              // compact_fill_kernel stored the masked draws' columns and priors densely, in list order
     // the caller keeps only lnZ and the best draw of these rows: bounded evaluation (cells_body, PRUNE)
     a.prune = 1;
     a.prune_c0 = -0.5 * log(kTwoPi) - lnsigma;

@@ -88,7 +88,8 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
     const size_t o_state = A.reserve(trx::kScratchZeroed);     // persistent: finished-block counter, the draw kernel's flag
     const size_t o_cols = A.reserve(sizeof(double) * ncol * N), o_mask = A.reserve(N), o_mask2 = A.reserve(planet ? 0 : N),
                  o_prior = A.reserve(s->want_prior ? sizeof(double) * N : 0),
-                 o_n = A.reserve(2 * sizeof(long)), o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1)),
+                 o_n = A.reserve(2 * sizeof(long)), o_cols0 = A.reserve(sizeof(double) * 16),
+                 o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1)),
                  o_ws = A.reserve(sizeof(double) * 2 * 3 * kLmeParts), o_pv = A.reserve(sizeof(double) * 2 * kLmeParts),
                  o_pi = A.reserve(sizeof(long) * 2 * 2 * kLmeParts), o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups),
                  o_idx0 = A.reserve(sizeof(int) * N), o_idx1 = A.reserve(planet ? 0 : sizeof(int) * N),
@@ -113,7 +114,7 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         (void)hipMemsetAsync(state, 0, trx::kScratchZeroed, st);
         return rc;
     };
-    if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, st)) return bail(rc);
+    if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, A.at<double>(o_cols0), st)) return bail(rc);
     if (g_poison.load(std::memory_order_relaxed))          // tests: an unwritten row must show (include/trx.h)
         for (int b = 0; b < nbr; ++b) TRXS_HIP(hipMemsetAsync(h[b], 0, sizeof(double) * (size_t)N, st));
     for (int b = 0; b < nbr; ++b) {
@@ -125,6 +126,8 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         trx::ScenFinal fin{};
         fin.idx = idx[b];
         fin.cols = d.cols;
+        fin.cols0 = A.at<double>(o_cols0);
+        fin.dense = 1;
         fin.N = N;
         fin.n_total = N;
         fin.ncol = ncol;
@@ -172,12 +175,13 @@ int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, doubl
     const size_t o_head = A.reserve(trx::kScratchZeroed);
     const size_t o_tab = A.reserve(sizeof(trx_draw_args) * (size_t)n);
     const size_t o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups * (size_t)n);
-    struct CallOff { size_t cols, mask, mask2, prior, n, res, ws, pv, pi, idx[2], h[2]; };
+    struct CallOff { size_t cols, cols0, mask, mask2, prior, n, res, ws, pv, pi, idx[2], h[2]; };
     CallOff co[trx::kChainMaxCalls];
     for (int i = 0; i < n; ++i) {
         const trx_scenario_args& s = calls[which[i]];
         const int planet = s.draw->planet != 0, ncol = planet ? 11 : 14;
         co[i].cols = A.reserve(sizeof(double) * ncol * N);
+        co[i].cols0 = A.reserve(sizeof(double) * 16);
         co[i].mask = A.reserve(N);
         co[i].mask2 = A.reserve(planet ? 0 : N);
         co[i].prior = A.reserve(s.want_prior ? sizeof(double) * N : 0);
@@ -230,7 +234,7 @@ int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, doubl
         d.dump = nullptr;
         stage[i] = d;
         long* n_dev = A.at<long>(co[i].n);
-        fills[i] = trx::ChainFill{A.at<int>(co[i].idx[0]), planet ? nullptr : A.at<int>(co[i].idx[1]), n_dev};
+        fills[i] = trx::ChainFill{A.at<int>(co[i].idx[0]), planet ? nullptr : A.at<int>(co[i].idx[1]), n_dev, A.at<double>(co[i].cols0)};
         for (int b = 0; b < nbr; ++b, ++b_at) {
             char* head = A.base + o_head + (size_t)b_at * kBranchHead;
             trx::ChainBranch& c = br[b_at];
@@ -254,6 +258,8 @@ int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, doubl
             f = trx::ScenFinal{};
             f.idx = c.src_idx;
             f.cols = d.cols;
+            f.cols0 = A.at<double>(co[i].cols0);
+            f.dense = 1;
             f.N = N;
             f.n_total = N;
             f.ncol = ncol;
