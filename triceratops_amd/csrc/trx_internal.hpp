@@ -36,11 +36,13 @@ private:
     void* mu_;
 };
 
-// The likelihood of the draws that passed a geometry mask, read in place from the draw kernel's
-// [n_param][src_stride] block: row r = draw src_idx[r], r < *n_dev (both left on the device by earlier
-// kernels of the stream; n_upper bounds the count).  twin: the EB_TWIN rows (2 P, a of 2 P).
-// The caller reduces the rows to lnZ (with lnprior per draw, or null) and the best draw only, which
-// allows the bounded evaluation of cells_kernel<PRUNE>: a row that can neither carry weight nor be the
+// The likelihood of the draws that passed a geometry mask.  compact_fill_kernel stored their columns DENSELY in the
+// [n_param][src_stride] block, in list order: row r at column position r, the twin branch's rows from the top down
+// (src_stride - 1 - r); r < *n_dev (left on the device by earlier kernels of the stream; n_upper bounds the count).
+// (Until round 5 the columns sat at their draw index and were read through src_idx: one 64-byte line per column and
+// row, 700 MB of traffic per target in rowc_kernel alone.)  twin: the EB_TWIN rows (2 P, a of 2 P).
+// The caller reduces the rows to lnZ (with lnprior per masked draw, stored like the columns, or null) and the best draw
+// only, which allows the bounded evaluation of cells_kernel<PRUNE>: a row that can neither carry weight nor be the
 // best draw reports a lower bound of its chi^2/2 instead of the value.  *bounds_base then points at the row
 // blocks of the launch, behind which its header keeps the largest log-weight (lme_draws reads it; the
 // pointer stays valid for work enqueued on this stream); null when every row was evaluated to the end.

@@ -92,8 +92,8 @@ struct RowsArgs {
     // the rows-per-wave of the batched variant and the batch count follow from the count on the device
     // (same rule as on the host: batch_rows), `B` being the LDS layout's maximum.
     const long* n_dev;
-    // Row r of the block is draw src_idx[r] of a [n_param][src_stride] block (the draw kernel's columns):
-    // the masked draws are read in place instead of being gathered into a block of their own.
+    // Row r of the block is draw src_idx[r] of a [n_param][src_stride] block (the draw kernel's columns by draw index;
+    // see `dense` for the layout the scenario path has used since round 5).
     const int* src_idx;
     long src_stride;
     int twin_cols;     // EB_TWIN rows of the draw kernel's block: P = 2 * column 2, a = column 11

@@ -10,10 +10,11 @@
 //                        and appends the indices of its own masked draws, ascending (the order numpy's / torch's
 //                        nonzero gives) -> idx[branch][], n[branch] -- and, in the same kernel, the parameter columns
 //                        and the prior of those draws (the 5-10 % that passed), recomputed from the same counter-based
-//                        random numbers
-//   rowc_kernel          } the likelihood of the masked draws, read IN PLACE from the draw kernel's columns through idx
-//   (sec_scan_kernel)    } (no gathered parameter block); the row count is read from n[branch] on the device and the
-//   cells_kernel         } grids are sized for a guess (trx_kernels.hip)
+//                        random numbers and stored DENSELY, in list order (branch 0 from position 0 up, the twin branch
+//                        from position N - 1 down: a draw passes at most one of the two masks)
+//   rowc_kernel          } the likelihood of the masked draws: coalesced reads of those dense columns; the row count
+//   (sec_scan_kernel)    } is read from n[branch] on the device and the grids are sized for a guess
+//   cells_kernel         } (trx_kernels.hip)
 //   lme_partial_kernel   first pass of the log-mean-exp and of the search for the smallest chi^2 in one pass; the block
 //                        that finishes LAST folds the partials into the record: the evidence, the best draw (first of
 //                        equals, NaN first: numpy's / torch's argmin), its columns, the masked count and the
