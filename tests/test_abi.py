@@ -76,3 +76,29 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read().lower()
                 assert "oracle" not in src, f
+
+
+def test_record_status_and_ties_are_checked_on_the_host():
+    """record slot 17 = 1 ("a row no kernel wrote") must raise, whichever branch reports it; slot 16 (exact ties at the
+    minimum) only matters to the seeded numpy modes"""
+    import numpy as np
+    import pytest
+    from triceratops_amd import _lib, fused
+    recs = np.zeros((3, fused.RECORD))
+    fused._check_status(recs, [True, False, False])
+    recs[1, fused.SCENARIO_OUT + fused.SCEN_STATUS] = 1.0          # branch 1 of a binary call
+    with pytest.raises(_lib.TrxError, match="no kernel wrote"):
+        fused._check_status(recs, [True, False, False])
+    recs[:] = 0.0
+    recs[0, fused.SCENARIO_OUT + fused.SCEN_STATUS] = 1.0          # "branch 1" of a PLANET call: not a record
+    fused._check_status(recs, [True, False, False])
+    recs[0, fused.SCEN_STATUS] = 1.0
+    with pytest.raises(_lib.TrxError):
+        fused._check_status(recs, [True, False, False])
+
+
+def test_hw_queues_report():
+    import triceratops_amd
+    q = triceratops_amd.hw_queues()
+    assert set(q) == {"value", "set_by", "in_effect"} and q["set_by"] in ("user", "package")
+    assert q["value"] == 8 or q["set_by"] == "user"

@@ -369,3 +369,23 @@ def test_schedule_deals_like_sized_tois_eight_to_a_rank():
     owner = sharding.schedule(costs, 8, groups)
     load = np.bincount(owner, weights=costs, minlength=8)
     assert load.max() / load.mean() < 1.10 and len(set(owner[:10])) > 1
+
+
+def test_pieces_are_contiguous_runs_of_one_target():
+    """what one rank hands to its streams (sharding._pieces): whole targets when there are at least as many as streams,
+    else a target's calls in a few contiguous runs balanced by cost -- every unit exactly once, order kept"""
+    keys = ["TP", "EB", "PTP", "PEB", "STP", "SEB", "DTP", "DEB", "BTP", "BEB"]
+    units = [(0, (), 1, 1, 1, k, 1.0, 1, (0, 0)) for k in keys]
+    for i in range(1, 21):
+        units += [(0, (), 1, 1, 1, "NTP", 1.0, 1, (0, i)), (0, (), 1, 1, 1, "NEB", 1.0, 1, (0, i))]
+    mine = list(range(len(units)))
+    pieces = sharding._pieces(units, mine, 4)
+    assert [k for p in pieces for k in p] == mine and 4 <= len(pieces) <= 8
+    assert max(len(p) for p in pieces) <= 16                      # (the library chains up to 16 calls)
+    many = []
+    for j in range(6):
+        many += [(0, (), 1, 1, 1, k, 1.0, 1, (j, 0)) for k in keys] + [(0, (), 1, 1, 1, "NTP", 1.0, 1, (j, 1)),
+                                                                      (0, (), 1, 1, 1, "NEB", 1.0, 1, (j, 1))]
+    pieces = sharding._pieces(many, list(range(len(many))), 4)
+    assert [len(p) for p in pieces] == [12] * 6                   # one run (one launch chain) per target
+    assert sharding._pieces(units[:1], [0], 4) == [[0]] and sharding._pieces(units, [], 4) == []
