@@ -148,9 +148,10 @@ def test_host_path_of_a_rank_shrinks_with_the_world_size():
     The gate is STRUCTURAL -- what the schedule hands a rank (whole targets, an eighth of them, an eighth of the
     calls) -- plus one RATIO of host times measured in this very test on this very box (the best of five steps on
     either side; round 4 asserted an absolute 0.035 s chosen on another machine, and a slower host failed it).
-    Measured on the builder's leases: ratio 0.24 (idle box) and 0.28 (eight busy-loop processes beside the suite:
-    profiles/r05/suite_on_a_busy_box.txt) -- listing the units of all 64 targets and filling all 64 tables is done by
-    every rank, so it is not 1/8 --; the bar is twice that.  The seconds are printed, not judged."""
+    Measured on the builder's leases: ratio 0.18 (0.24 before the records were turned into rows while the GPU works, 0.28
+    then with eight busy-loop processes beside the suite: profiles/r05/suite_on_a_busy_box.txt) -- listing the units of
+    all 64 targets and filling all 64 tables is done by every rank, so it is not 1/8 --; the bar is twice the measured
+    ratio and more.  The seconds are printed, not judged."""
     one = _batch_line(1)
     eight = _batch_line(8, ("--debug-single-device",))
     pr1, pr8 = one["config"]["per_rank"], eight["config"]["per_rank"]
@@ -163,4 +164,4 @@ def test_host_path_of_a_rank_shrinks_with_the_world_size():
     print("\nhost path per step (best of 5): 1 rank %.4f s, 8 ranks (max) %.4f s, ratio %.3f; mean host path %.4f / %.4f; "
           "enqueue of the 8 ranks %s (max/min %.2f)" % (h1, h8, h8 / h1, pr1["host_path_s"][0], max(pr8["host_path_s"]),
                                                        ["%.4f" % v for v in e8], max(e8) / max(min(e8), 1e-9)))
-    assert h8 <= 0.55 * h1, (h1, h8)
+    assert h8 <= 0.45 * h1, (h1, h8)

@@ -151,14 +151,16 @@ def _as_dicts(rec):
     return tuple({c: rec[i, j] for j, c in enumerate(RECORD_COLS)} for i in range(rec.shape[0]))
 
 
-def run_units(units, verbose=0):
+def run_units(units, verbose=0, as_rows=False):
     """Evaluate the work units of one calc_probs.
 
     units: list of (first_row, names, star_num, ID, thunk_or_None, key[, weight, draws, (job, star)]); weight scales
     the scenario cost of `key` in the schedule (units of differently sized jobs, calc_probs_many), (job, star) lets
     the schedule deal whole TOIs and whole stars.
     Returns, per unit, None (dropped scenario) or a tuple of per-scenario dicts
-    {column: best value, 'lnZ': float}."""
+    {column: best value, 'lnZ': float} -- with as_rows, the (branches, 15) array of RECORD_COLS instead (what
+    target._finish reads: building a dict per scenario and taking it apart again cost 4 ms of a 64-target step, on
+    every rank)."""
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
@@ -187,7 +189,7 @@ def run_units(units, verbose=0):
         base = _draw_base()
     _fused.TABLE_ROWS = 1
     try:
-        return _run_units(units, live, owner, base, dist, world, rank, verbose)
+        return _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows)
     finally:
         _fused.TABLE_ROWS = _fused.N_BEST
 
@@ -250,7 +252,7 @@ def _job_of(u):
     return u[8][0] if len(u) > 8 else 0
 
 
-def _run_units(units, live, owner, base, dist, world, rank, verbose):
+def _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows=False):
     rows = {k: len(units[k][1]) for k in live}
     offs, total = {}, 0
     for k in live:
@@ -330,6 +332,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
             # to the streams in PIECES -- contiguous runs of one target's calls, ~chain_calls each -- and a piece to
             # the stream with the least work queued so far (by the schedule's cost weights); one library call per piece.
             load = [0.0] * len(pool)
+            done_marks = []                # (event behind a piece, number of pending calls up to and including it)
             t_build = t_lib = 0.0          # of enqueue_s: Python building the argument blocks / inside trx_star_enqueue
             for piece in _pieces(units, mine_k, len(pool)):
                 j = min(range(len(pool)), key=lambda i: (load[i], i))
@@ -342,13 +345,32 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
                 _fused.flush()
                 t_build += t_b - t_a
                 t_lib += time.perf_counter() - t_b
+                ev = torch.cuda.Event()
+                ev.record(pool[j])
+                done_marks.append((ev, len(pending)))
             timing["build_s"], timing["library_s"] = t_build, t_lib
             timing["enqueue_s"] = time.perf_counter() - t0
+            # The records are turned into table rows piece by piece, as the pieces finish, while the GPU works on the
+            # later ones (the host is idle for most of the wait: until round 5 it slept through it and converted all
+            # records afterwards, 3-5 ms of every step and of every rank).  Pieces on one stream finish in order;
+            # across streams the order of enqueueing is a good guess and a wrong one only waits a little longer.
+            at = 0
+            t_wait = 0.0
+            for ev, upto in done_marks:
+                t_w = time.perf_counter()
+                ev.synchronize()
+                t_wait += time.perf_counter() - t_w
+                if upto > at:
+                    for k, rec in _fused.records_to_rows(pending[at:upto]).items():
+                        table[offs[k]:offs[k] + rows[k]] = rec
+                    at = upto
             for st in pool:
                 st.synchronize()
             drained = True
-            timing["wait_s"] = time.perf_counter() - t0 - timing["enqueue_s"]
-            resolve()
+            timing["wait_s"] = t_wait
+            if at < len(pending):
+                for k, rec in _fused.records_to_rows(pending[at:]).items():
+                    table[offs[k]:offs[k] + rows[k]] = rec
         finally:
             if not drained:
                 # a call failed after others were enqueued: their kernels and record copies still use the
@@ -441,5 +463,9 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose):
 
     out = []
     for k, u in enumerate(units):
-        out.append(None if u[4] is None else _as_dicts(table[offs[k]:offs[k] + rows[k]]))
+        if u[4] is None:
+            out.append(None)
+        else:
+            rec = table[offs[k]:offs[k] + rows[k]]
+            out.append(rec if as_rows else _as_dicts(rec))
     return out

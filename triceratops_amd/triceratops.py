@@ -192,7 +192,7 @@ class target:
         units, book = self._prepare(time, flux_0, flux_err_0, P_orb, contrast_curve_file, filt, N,
                                     parallel, drop_scenario, flatpriors, exptime, nsamples,
                                     molusc_file)
-        self._finish(units, sharding.run_units(units, verbose=verbose), book)
+        self._finish(units, sharding.run_units(units, verbose=verbose, as_rows=True), book)
         return
 
     def _prepare(self, time, flux_0, flux_err_0, P_orb, contrast_curve_file=None, filt="TESS",
@@ -232,8 +232,19 @@ class target:
         scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
         best = {c: np.zeros(n_scen) for c in _COLS}
         lnZ = np.zeros(n_scen)
+        rec_tab = None
         for u, res in zip(units, results):
             j0, names, snum, ID = u[:4]
+            if isinstance(res, np.ndarray):
+                # (sharding.run_units(as_rows=True): the unit's (branches, 15) block of sharding.RECORD_COLS)
+                if rec_tab is None:
+                    rec_tab = np.zeros((n_scen, len(sharding.RECORD_COLS)))
+                nb = len(names)
+                rec_tab[j0:j0 + nb] = res
+                targets[j0:j0 + nb], star_num[j0:j0 + nb] = ID, snum
+                scenarios[j0:j0 + nb] = names
+                lnZ[j0:j0 + nb] = res[:, -1]
+                continue
             for off, name in enumerate(names):
                 j = j0 + off
                 targets[j], star_num[j], scenarios[j] = ID, snum, name
@@ -244,6 +255,9 @@ class target:
                 for c in _COLS:
                     best[c][j] = r[c]
                 lnZ[j] = r["lnZ"]
+        if rec_tab is not None:
+            for i, c in enumerate(sharding.RECORD_COLS[:-1]):
+                best[c] = best[c] + rec_tab[:, i]         # (rows of dict-valued or dropped units stay as filled above)
 
         relative_probs, status = _normalize_probabilities(lnZ)
         if status == 'anomaly':
@@ -360,7 +374,7 @@ def calc_probs_many(jobs, verbose: int = 0):
         prepared.append((tg,) + tg._prepare(job=job, **kw))
     flat = [u for _, units, _ in prepared for u in units]
     t1 = _time.perf_counter()
-    results = sharding.run_units(flat, verbose=verbose)
+    results = sharding.run_units(flat, verbose=verbose, as_rows=True)
     t2 = _time.perf_counter()
     at = 0
     for tg, units, n_scen in prepared:
