@@ -281,6 +281,10 @@ __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows
 #ifndef TRX_LONG_ROWS_IN_LDS
 #define TRX_LONG_ROWS_IN_LDS 0
 #endif
+// 1: a chunk hands the cells whose pairs would leave its last trip mostly empty to the next chunk (cells_body)
+#ifndef TRX_CARRY_CELLS
+#define TRX_CARRY_CELLS 1
+#endif
 #ifndef TRX_CELLS_WAVES_PER_EU
 #define TRX_CELLS_WAVES_PER_EU 4
 #endif
@@ -840,6 +844,8 @@ struct CellState {
     double t[64];                           // exposure centre
     double facc[64];                        // the cell's sum over its nodes
     unsigned meta[64];                      // row | (tier + 1) << 8 | anchored << 16 (tier -1 = all S sub-exposures): one read per pair
+                                            // (| valid << 17 | node count << 18: what a carried cell's next chunk needs, cells_body)
+    unsigned short rel[64];                 // the cell's entry in the window's list
 };
 // centre-value stencil (LONG only): the chunk's centre fluxes and the launch's weights
 struct StencilState {
@@ -938,6 +944,9 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 {
     static_assert(!PRUNE || (MODE == MODE_LNL && !ST), "bounded evaluation: likelihood mode, no stencil");
     extern __shared__ double lds_all[];
+    // (not in the diagnostic instantiations that solve Kepler's equation per pair; not with one row per wave: 2000 irregular
+    // stamps -0.5 %, and the stencil instantiation, which never carries, -2.3 % for the registers the code costs)
+    constexpr bool kCarry = TRX_CARRY_CELLS && STEP && !LONG;
     constexpr int W = cells_waves(LONG);
     const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // (scalar: so is all that follows from it)
     // shared by the workgroup's waves: node tables, atan constants, (short curves) the light curve
@@ -1276,12 +1285,28 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             // same summation order)
             const bool halo = ST && sweep == 0 && st_radius > 0.0;
             int carry_rel = 0;
-            for (int w0 = 0, step = 64; w0 < count; w0 += step) {
+            // Carried cells (no stencil).  A chunk's pairs are dealt to the lanes 64 at a time and the last trip is
+            // half empty on average -- 54 of 64 lanes per trip at 100 points, and the pair loop is three quarters of
+            // the kernel there.  So a chunk with more cells behind it processes only the cells whose pairs fill whole
+            // trips (up to the last cell that ends before the last multiple of 64) and hands the cells behind those --
+            // planned, not evaluated -- to the next chunk, where they take the first lanes and the list fills the
+            // rest: every trip but a chunk's last is full, and that one lacks at most one cell's pairs.  Cells are
+            // still finalised in list order (the carried ones sit in front of the new ones), so a row's chi^2
+            // terms are added in the same order as before: same bits.
+            // (their plans stay where they are, in the last slots of the cell state, and the next chunk's first lanes read
+            // them from there: nothing but the count crosses the loop's back edge -- the batched instantiations have
+            // no register to spare)
+            int ncarry = 0;                       // cells carried into this chunk: lanes [0, ncarry)
+            for (int w0 = 0, step = 64; w0 < count || (kCarry && ncarry > 0); w0 += step) {
                 TRX_TICK(t_plan);
                 TRX_CENSUS_ADD(sweep ? kCenChunk1 : kCenChunk0, 1);
                 bool owned = true;
-                bool valid = (w0 + lane) < count;
-                int rel = (int)winlist[valid ? (w0 + lane) : (count - 1)];
+                const bool carried = kCarry && lane < ncarry;
+                if (kCarry) step = 64 - ncarry;
+                const int csrc = (lane + 64 - ncarry) & 63;                    // a carried cell's slot in the previous chunk's state
+                const unsigned cmeta = carried ? cs.meta[csrc] : 0u;
+                bool valid = carried ? (cmeta & 0x20000u) != 0 : (w0 + lane - ncarry) < count;
+                int rel = (int)*(carried ? &cs.rel[csrc] : &winlist[valid ? (w0 + lane - ncarry) : (count - 1)]);
                 if (ST && halo) {
                     const bool last_chunk = w0 + 64 >= count;
                     const int lo = (w0 > 0) ? kStM : 0, hi = last_chunk ? 64 : 64 - kStM;
@@ -1304,7 +1329,11 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 double fobs = 0.0;
                 if (LONG && MODE == MODE_LNL) fobs = fl[j];          // in flight during the chunk
                 CellPlan pl;
-                if (valid) {
+                if (carried) {
+                    pl.n = (int)(cmeta >> 18); pl.tier = (int)((cmeta >> 8) & 0xffu) - 1;
+                    pl.sE = cs.sE[csrc]; pl.cE = cs.cE[csrc];
+                    pl.anchored = (cmeta & 0x10000u) != 0;
+                } else if (valid) {
                     const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
 #ifndef TRX_PLAN_FULL_SOLVE
                     // (one row per wave only: in the batched variant the second code path costs more -- measured
@@ -1348,15 +1377,19 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     centre = valid && ((dil >> lane) & 1ull);
                     if (st) nodes = 0;
                 }
+                if (kCarry) wave_sync();        // (the carried cells' reads of the previous chunk's slots are through)
                 cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
                 cs.t[lane] = t;
                 cs.facc[lane] = 0.0;
-                cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u);
+                cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u) |
+                                (valid ? 0x20000u : 0u) | ((unsigned)pl.n << 18);
+                if (kCarry) cs.rel[lane] = (unsigned short)rel;
                 TRX_TOCK(2, t_plan);
                 TRX_TICK(t_a);
                 // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
                 // takes as many nodes of every cell as fit the pair table (a first-sweep chunk in
                 // one pass; 64 contact cells x S = 20 sub-exposures in two).
+                int ldone = 64;                    // lanes [0, ldone) are done with this chunk, the others are carried on
                 const int ncells = __popcll(__ballot(nodes > 0 || (ST && centre)));
                 int per = ncells > 0 ? kCellsPairs / ncells - (ST ? 1 : 0) : kCellsPairs;
                 per = per > 1000 ? 1000 : (per < 1 ? 1 : per);
@@ -1372,6 +1405,17 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
                     if (extra) pdesc[off + cnt] = (unsigned short)(lane | (kCentreNode << 6));
                     wave_sync();
+                    // (carried cells: with more of the list to come and every cell's pairs in this one pass, the cells
+                    // whose pairs end within the whole trips are processed, the others handed on -- when the last trip's
+                    // empty lanes outnumber the cells that then have to wait)
+                    if (kCarry && !(ST && halo) && s0 == 0 && w0 + step < count && total >= 64 && !__any(nodes > per)) {
+                        const int whole = total & ~63;
+                        const int l0 = __popcll(__ballot(off + cnt + extra <= whole));      // (a prefix of the lanes: off ascends)
+                        if (l0 >= 1 && l0 < 64 && (64 - (total - whole)) > (64 - l0)) {
+                            ldone = l0;
+                            total = __builtin_amdgcn_readlane(off, l0);
+                        }
+                    }
                     // one pair per lane: the orbit stepped from the cell's centre solution (|dM| <=
                     // half an exposure), the Mandel-Agol flux, and the node's term added to the
                     // cell's sum in LDS (ds_add_f64; a cell's pairs sit in consecutive lanes and the
@@ -1431,8 +1475,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     // bench / test knob: the model evaluations every cell cost, its own and those a
                     // neighbouring chunk spent on its centre value (the cells were zeroed by pass 1)
                     const int spent = nodes + ((ST && centre) ? 1 : 0);
-                    if (spent > 0) atomicAdd(&a.out[(size_t)base * n_time + cell], (double)spent);
-                } else if (valid && owned) {
+                    if (spent > 0 && lane < ldone) atomicAdd(&a.out[(size_t)base * n_time + cell], (double)spent);
+                } else if (valid && owned && lane < ldone) {
                     const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
                     double fsum = cs.facc[lane];
                     if (ST && st) {
@@ -1469,6 +1513,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         }
                     }
                 }
+                if (kCarry) ncarry = 64 - ldone;          // the cells handed on (read from this chunk's slots by the next)
                 TRX_TOCK(5, t_rest);
             }
             }
