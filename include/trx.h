@@ -208,6 +208,10 @@ int trx_set_debug_poison(int on);
 /*    trx_set_debug_bug(1) (tests): re-enables a bug of round 4 (the third pass of the bounded evaluation skipped its last
  *    batches when nothing was probed), so that a test can show the "never written" status of the record catching it. */
 int trx_set_debug_bug(int on);
+/*    trx_set_probe_rows(n) (tests, A/B runs; TRX_PROBE_ROWS in the environment): rows per wave of the probe pass of the
+ *    bounded evaluation of batched light curves: 0 = as many as its LDS layout holds (default), 1 = as many as the other
+ *    passes take, n > 1 = n (at most 22).  Results do not depend on it. */
+int trx_set_probe_rows(int rows);
 int trx_pruned_rows(unsigned long long* out, int reset);
 int trx_set_supersample_tiers(int on);
 int trx_set_stencil(int on);

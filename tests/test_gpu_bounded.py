@@ -122,3 +122,43 @@ def test_batches_that_span_several_window_passes_are_evaluated_in_full(n_time, r
         L.trx_set_debug_bounded_lnl(0)
         L.trx_set_rows_per_wave(0)
         L.trx_set_cell_packing_below(_lib.CELL_PACKING_BELOW)
+
+
+@pytest.mark.parametrize("chain", [0, 1])
+@pytest.mark.parametrize("n_time,rows", [(200, 16), (200, 0), (150, 0), (150, 10), (100, 0), (64, 22)])
+def test_probe_pass_with_its_own_rows_per_wave(n_time, rows, chain):
+    """The probe pass of the batched bounded evaluation files only ~16 probe cells per row, so it takes more rows per
+    wave than the passes that hold a batch's every cell (its own LDS layout; plan_cells, listed_pass_rows in
+    csrc/trx_kernels.hip).  Which rows a WORKGROUP has (cells_entry's exit rule) and which rows its waves take
+    (cells_body) must come from one rule: with the first version of this pass the two halved different starting values
+    (16 -> 8 -> 4 -> 2 against 3 -> 2) and, call by call, landed on 2 and 3 rows per wave for ~12 000 listed rows -- the
+    last batches had no workgroup, and the "never written" status of the record said so at once.  Several N so that
+    the listed counts cross the steps of the rule; the records must be those of the pass at the other passes' rows per
+    wave, bit for bit (results do not depend on how rows are grouped: the bounded instantiations freeze settled lanes)."""
+    import triceratops_amd
+    from triceratops_amd import _lib, sharding, synth
+    from helpers import GOLD
+    import os
+    import torch
+    L = _lib.lib()
+    tri, cc = os.path.join(GOLD, "trilegal_synth.csv"), os.path.join(GOLD, "contrast_curve_synth.csv")
+    saved = sharding.streams
+    triceratops_amd.set_sampling("device")
+    try:
+        L.trx_set_star_chain(chain)
+        sharding.streams = 2
+        for N in (120_000, 260_000, 1_000_000):
+            out = []
+            for r in (1, rows):
+                assert L.trx_set_probe_rows(r) == 0
+                jobs = synth.toi_jobs(2, n_time=n_time, N=N, seed=3, trilegal_fname=tri, contrast_curve_file=cc)
+                torch.manual_seed(5)
+                triceratops_amd.calc_probs_many(jobs)          # (TrxError if a row was never written)
+                out.append([np.concatenate([tg.lnZ, [tg.FPP, tg.NFPP]]) for tg, _ in jobs])
+            for x, y in zip(*out):
+                assert np.array_equal(x, y, equal_nan=True), (n_time, rows, N)
+    finally:
+        L.trx_set_probe_rows(0)
+        L.trx_set_star_chain(1)
+        sharding.streams = saved
+        triceratops_amd.set_sampling("numpy")

@@ -132,9 +132,11 @@ def test_rows_never_written_are_reported_not_read(chain):
     two counts fell on different sides of a step of batch_rows, the last batches were never written, the stale chi^2 of
     the stream's previous call read as a result, and the 75-scenario blend's FPP came out as 1.  trx_set_debug_bug(1)
     switches that exit rule back on.  TOI-411.02 (a 166 ppm signal: the pilot's verdict is "probing does not pay") at
-    N = 3e5 has scenarios on such a step (profiles/r05/scan_debug_bug.txt: 18 of 27 values of N between 1.5e5 and 4.1e5
-    do): the run must now FAIL with TrxError -- record status 1, a row still carries rowc_kernel's mark -- instead of
-    returning numbers, through the chain and call by call."""
+    N = 3e5 has scenarios on such a step call by call (profiles/r05/scan_debug_bug.txt: 18 of 27 values of N between
+    1.5e5 and 4.1e5 do; the rule asks for 3200 waves a launch), and at N = 3e4 in a launch chain (every N from 1e4 to 9e4:
+    a chain's rule asks for 3200 / branches waves a branch).  The run must now FAIL with TrxError -- record status 1, a
+    row still carries rowc_kernel's mark -- instead of returning numbers, through the chain and call by call."""
+    N = 30_000 if chain else 300_000
     import anchors
     from triceratops_amd import _lib, sharding
     L = _lib.lib()
@@ -142,12 +144,12 @@ def test_rows_never_written_are_reported_not_read(chain):
     try:
         L.trx_set_star_chain(chain)
         sharding.streams = 4
-        good = anchors.run("toi411", 7, N=300_000, sampling="device")
+        good = anchors.run("toi411", 7, N=N, sampling="device")
         L.trx_set_debug_bug(1)
         with pytest.raises(_lib.TrxError, match="no kernel wrote"):
-            anchors.run("toi411", 7, N=300_000, sampling="device")
+            anchors.run("toi411", 7, N=N, sampling="device")
         L.trx_set_debug_bug(0)
-        again = anchors.run("toi411", 7, N=300_000, sampling="device")
+        again = anchors.run("toi411", 7, N=N, sampling="device")
         assert np.array_equal(good[0], again[0], equal_nan=True) and good[2] == again[2]
     finally:
         L.trx_set_debug_bug(0)

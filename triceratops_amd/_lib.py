@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "trx_lnl_batch", "trx_flux_grid", "trx_chi2_grid", "trx_workspace_bytes",
     "trx_log_mean_exp", "trx_lnz_scenario", "trx_lnz_from_halfchi2", "trx_lnl_batch_host", "trx_flux_grid_host",
     "trx_log_mean_exp_host", "trx_set_rows_per_wave", "trx_debug_batch_plan", "trx_set_supersample_tiers", "trx_set_stencil", "trx_set_skip_excluded", "trx_skipped_rows",
-    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_set_debug_poison", "trx_set_debug_bug", "trx_set_star_chain", "trx_pruned_rows", "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_star_enqueue", "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error",
+    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_set_debug_poison", "trx_set_debug_bug", "trx_set_probe_rows", "trx_set_star_chain", "trx_pruned_rows", "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_star_enqueue", "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error",
     "trx_device_count",
 )
 
@@ -127,6 +127,8 @@ def lib():
     L.trx_set_debug_bug.argtypes = [c_int]
     L.trx_set_star_chain.restype = c_int
     L.trx_set_star_chain.argtypes = [c_int]
+    L.trx_set_probe_rows.restype = c_int
+    L.trx_set_probe_rows.argtypes = [c_int]
     L.trx_pruned_rows.restype = c_int
     L.trx_pruned_rows.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), c_int]
     L.trx_set_stencil.restype = c_int

@@ -84,6 +84,9 @@ struct RowsArgs {
     int* memo;         // rowc_kernel: where to leave the verdict for later launches on this light curve (or null)
     int tl_off;        // cells_kernel: offset (in doubles) of the staged light curve in LDS (shared by the workgroup's waves)
     int wave_off, wave_doubles;   // cells_kernel: offset of the first wave's own LDS block and the size of one (in doubles)
+    int probe_rows;    // cells_kernel, probe pass of a split launch: rows per wave its LDS layout holds (0: as the other passes)
+    int wave_floor;    // ... the fewest waves the few-rows rule leaves the probe pass (chains: per branch)
+    int wave_floor3;   // ... and the survivors' pass
     double* rowc;      // cells_kernel: row constant blocks [n][kRowDoubles] written by rowc_kernel
     int* scan_list;                      // rowc_kernel -> sec_scan_kernel: the rows whose secondary-eclipse verdict is open
     unsigned long long* scan_count;      // ... and their number
@@ -316,13 +319,13 @@ constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pas
 // points are 3 for 10 000 rows and 6 from 20 000 on, profiles/r04_few_rows_sweep.txt; until then the rule asked for
 // 10 000 waves and 30 000 rows ran 6 % slower at 3 per wave than at 4-6).  `n` < 0: the largest value any n gives
 // (LDS layout).
-__host__ __device__ inline int batch_rows(long n, int n_time, int forced)
+__host__ __device__ inline int batch_rows(long n, int n_time, int forced, int floor = 3200)
 {
     int B = (640 + n_time / 2) / (n_time > 0 ? n_time : 1);
     B = B < 1 ? 1 : (B > kCellsMaxRows ? kCellsMaxRows : B);
     if (forced > 0) return forced > kCellsMaxRows ? kCellsMaxRows : forced;
     if (n >= 0)
-        while (B > 1 && n / B < 3200) B = (B + 1) / 2;
+        while (B > 1 && n / B < floor) B = (B + 1) / 2;
     return B;
 }
 
@@ -926,6 +929,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Rows per wave of the passes of the bounded evaluation over LISTED rows (batched variant: the probe pass, part 2, and
+// the survivors' pass, part 3).  ONE rule for cells_entry -- which workgroups have batches at all -- and cells_body --
+// which rows they are: two copies of it that drift apart leave batches that no workgroup evaluates (round 4's "rows
+// never written"; round 5 nearly repeated it when the probe pass got its own rows per wave, and the guard of
+// lme_partial_kernel said so at once).  `rows`: the pass's row count, from the device.
+__device__ __forceinline__ int listed_pass_rows(const RowsArgs& a, long rows, int part)
+{
+    // few rows: fewer per wave, by the host's rule for a launch of that many rows
+    int B = batch_rows(rows, a.n_time, a.forced_B, part == 3 ? a.wave_floor3 : 3200);
+    B = B < a.B ? B : a.B;
+    // the probe pass: as many as its own LDS layout holds -- only the probe cells are filed --, halved by the same rule
+    if (part == 2 && a.probe_rows > 1) {
+        B = a.probe_rows;
+        while (B > 1 && rows / B < a.wave_floor) B = (B + 1) / 2;
+    }
+    return B;
+}
+
 // PRUNE (trx_scenario_evidence; MODE_LNL, no stencil): bounded evaluation.  The evidence is a sum of
 // exp(c0 - chi^2/2 + lnprior) over the rows and the reduction drops every term more than 80 below the
 // largest (lme_partial_kernel: it cannot change an fp64 sum that is >= 1); the best draw is the row with
@@ -1046,11 +1067,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         }
         else if (hdr[kHdrProbe] != 0.0) { rlist = surv_list; row1 = (long)*surv_count; }
         else row0 = np;                // (no probe pass was run: every row behind the pilot, as they come)
-        if (!LONG && (a.part == 3 || (a.part == 2 && rlist))) {
-            // few rows left: fewer per wave, by the host's rule for a launch of that many rows
-            B = batch_rows(row1 - row0, n_time, a.forced_B);
-            B = B < Bl ? B : Bl;
-        }
+        if (!LONG && (a.part == 3 || (a.part == 2 && rlist))) B = listed_pass_rows(a, row1 - row0, a.part);
         // the pilot's rows one per wave: six per wave were 683 waves on 256 CUs for 4096 rows, each a serial chain of a
         // whole batch -- 108 us before the launch proper could start (TOI-465.01, 100 points); short waves fill the chip
         if (!LONG && a.part == 1 && a.split) B = 1;
@@ -1218,8 +1235,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         const unsigned long long rowsmask = (nb >= 64) ? ~0ull : ((1ull << nb) - 1ull);
         const bool all_settled = PRUNE && !LONG && (skipmask & rowsmask) == rowsmask;
         const int ncell = all_settled ? 0 : nb * n_time;
-        for (int win0 = 0; win0 < ncell; win0 += kCellsWindow) {
-            const int win1 = (win0 + kCellsWindow < ncell) ? (win0 + kCellsWindow) : ncell;
+        // (the probe pass of a split launch files the probe cells only: its window is the whole batch)
+        const int wstep = (PRUNE && !LONG && a.part == 2 && a.probe_rows > 1) ? (ncell > kCellsWindow ? ncell : kCellsWindow) : kCellsWindow;
+        for (int win0 = 0; win0 < ncell; win0 += wstep) {
+            const int win1 = (win0 + wstep < ncell) ? (win0 + wstep) : ncell;
             for (int phase_no = 0; phase_no < nphase; ++phase_no) {
             // pass 1: window test, 64 cells at a time across row boundaries (PRUNE: phase 0 files the probe
             // cells, phase 1 the other cells of the rows still alive)
@@ -1653,8 +1672,7 @@ __device__ __forceinline__ void cells_entry(const RowsArgs& a)
             if (!LONG && a.part == 2 && a.split) {
                 // (the probe pass: the rows depth_screen_kernel listed -- none when nothing is probed)
                 rows_here = a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0 ? (long)*a.probe_count : 0;
-                B = batch_rows(rows_here, a.n_time, a.forced_B);
-                B = B < a.B ? B : a.B;
+                B = listed_pass_rows(a, rows_here, 2);
             }
             if (a.part == 3) {
                 // (the rows of the third pass: the listed ones, or all behind the pilot; its rows per wave follow from
@@ -1663,10 +1681,8 @@ __device__ __forceinline__ void cells_entry(const RowsArgs& a)
                 // (a.debug_bug, trx_set_debug_bug(1): round 4's first version of this rule, which took the rows per wave from
                 // the whole row count when nothing was probed -- the last batches of the third pass were then never
                 // written; kept as a switch so that a test can show the "never written" guard catching it)
-                if (!LONG && (!a.debug_bug || a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0)) {
-                    B = batch_rows(rows_here, a.n_time, a.forced_B);
-                    B = B < a.B ? B : a.B;
-                }
+                if (!LONG && (!a.debug_bug || a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0)) B = listed_pass_rows(a, rows_here, 3);
+                else if (!LONG) B = listed_pass_rows(a, nd, 3);             // (the bug: the rule applied to the WHOLE row count)
             }
         }
         // (the first batch index of this workgroup's first wave, see cells_body)
@@ -2121,6 +2137,8 @@ __global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict_
 // Process-wide diagnostics switches (include/trx.h, "Diagnostics"): read once per enqueue, relaxed
 // atomics so that a concurrent setter is a data-race-free (if unordered) change of mode.
 std::atomic<int> g_rows_per_wave{0};  // 0 = auto
+// rows per wave of the probe pass of a split launch: 0 = as many as its LDS holds, 1 = as the other passes (A/B, tests), n = n
+std::atomic<int> g_probe_rows{getenv("TRX_PROBE_ROWS") ? atoi(getenv("TRX_PROBE_ROWS")) : 0};
 std::atomic<int> g_step{1};           // sub-exposure Kepler stepping (0 = full solve per sub-exposure)
 
 int n_params(int model)
@@ -2491,6 +2509,9 @@ struct CellsPlan {
     unsigned grid_scan;        // sec_scan_kernel<8>
     unsigned grid_screen;      // depth_screen_kernel
     bool passes;               // prune: there may be rows behind the pilot (pilot_stats_kernel and the later passes run)
+    int probe_B;               // split: rows per wave of the probe pass (its own LDS layout: probe_lds, probe_wave_doubles)
+    size_t probe_lds;
+    int probe_wave_doubles;
 };
 
 std::atomic<int> g_debug_bug{0};      // trx_set_debug_bug (tests)
@@ -2562,6 +2583,33 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     const bool split = prune && !long_rows;
 #endif
     a.split = split ? 1 : 0;
+    // The probe pass of a split launch looks at ~16 cells of a row: with the 3 rows per wave that 200 points allow the
+    // other passes, a batch has ~24 in-window probe cells -- one chunk on a third of its lanes, two trips of pairs two
+    // thirds full (SQ_THREAD_CYCLES_VALU: 0.48 of the lanes active over the pass, profiles/r05/pmc_chain.sh).  Only the
+    // probe cells are filed, so the pass needs no room for a batch's every cell in the in-window list: it takes as many
+    // rows per wave as the LDS of five waves per SIMD has room for row blocks (9 at 200 points, 11 at 100), its "window"
+    // is the whole batch, and its chunks and trips fill up.
+    P.probe_B = a.B;
+    P.probe_lds = lds;
+    P.probe_wave_doubles = a.wave_doubles;
+    a.probe_rows = 0;
+    a.wave_floor = a.wave_floor3 = 3200;
+    if (split && g_probe_rows.load(std::memory_order_relaxed) != 1) {
+        const int forced = g_probe_rows.load(std::memory_order_relaxed);
+        const int per_row = a.n_time / a.pstride + 1;                      // probe cells of a row
+        const size_t fixed = (kCellsPairs + cells_window(false)) * sizeof(unsigned short) + sizeof(CellState);
+        const size_t room = (32 * 1024 - shared) / cells_waves(false);       // five workgroups per CU
+        int B2 = room > fixed ? (int)((room - fixed) / ((kRowDoubles + 4) * sizeof(double))) : a.B;
+        if (forced > 1) B2 = forced;
+        if (B2 > kCellsMaxRows) B2 = kCellsMaxRows;
+        if (B2 * per_row > cells_window(false)) B2 = cells_window(false) / per_row;
+        if ((long)B2 * a.n_time > 65535) B2 = 65535 / a.n_time;               // (list entries are 16-bit cell numbers)
+        if (B2 > a.B) {
+            P.probe_B = B2;
+            P.probe_wave_doubles = (int)(((size_t)B2 * (kRowDoubles + 4) * sizeof(double) + fixed) / sizeof(double));
+            P.probe_lds = shared + cells_waves(false) * (size_t)P.probe_wave_doubles * sizeof(double);
+        }
+    }
     P.long_rows = long_rows;
     P.prune = prune;
     P.split = split;
@@ -2681,7 +2729,13 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
                                a.probe_count);
             if (split) hipLaunchKernelGGL(depth_screen_kernel, dim3(P.grid_screen), dim3(256), 0, st, a);
             ap.part = 2;
-            launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+            if (split && P.probe_B > a.B) {
+                RowsArgs a2 = ap;
+                a2.B = P.probe_B; a2.probe_rows = P.probe_B; a2.wave_doubles = P.probe_wave_doubles;
+                launch_pruned<MODE>(a2, st, long_rows, fp32, g2, P.probe_lds);
+            } else {
+                launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+            }
             if (split) {
                 // batches of short light curves: the launch above was the probe pass; the rows it left alive, compacted
                 // across workgroups, are evaluated to the end here
@@ -2900,13 +2954,28 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
     const unsigned y = (unsigned)nbr;
     hipLaunchKernelGGL(rowc_kernel_star, dim3(P.grid_rowc, y), dim3(64), 0, st, a, bt);
     if (any_sec) hipLaunchKernelGGL(sec_scan_kernel_star, dim3(P.grid_scan, y), dim3(64), 0, st, a, bt);
+    // (the few-rows rule of the listed passes asks for ~3200 waves a launch: a chain's launch is all its branches'.  The
+    // survivors' pass of a 64-target step ran one row per wave in most branches under the per-launch rule -- lanes 0.65
+    // active: same job, 0.114 -> 0.107-0.109 s per step with the floor divided; any value from 1 to 300 does the same,
+    // profiles/r05/ab_probe_rows.txt.  Environment: experiments.)
+    static const int floor_env = getenv("TRX_WAVE_FLOOR") ? atoi(getenv("TRX_WAVE_FLOOR")) : 0;
+    static const int floor3_env = getenv("TRX_WAVE_FLOOR3") ? atoi(getenv("TRX_WAVE_FLOOR3")) : 0;
+    a.wave_floor = floor_env > 0 ? floor_env : (3200 / nbr > 256 ? 3200 / nbr : 256);
+    a.wave_floor3 = floor3_env > 0 ? floor3_env : a.wave_floor;
     auto cells = [&](unsigned grid, int part) {
         if (P.long_rows) {
             if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, true>), dim3(grid, y), dim3(64), P.lds, st, a, bt, part);
             else        hipLaunchKernelGGL((cells_kernel_star<false, true>), dim3(grid, y), dim3(64), P.lds, st, a, bt, part);
         } else {
-            if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, false>), dim3(grid, y), dim3(64 * kBatchWaves), P.lds, st, a, bt, part);
-            else        hipLaunchKernelGGL((cells_kernel_star<false, false>), dim3(grid, y), dim3(64 * kBatchWaves), P.lds, st, a, bt, part);
+            // (the probe pass of a split launch: more rows per wave, its own LDS layout -- plan_cells)
+            RowsArgs ax = a;
+            size_t lds = P.lds;
+            if (part == 2 && P.split && P.probe_B > a.B) {
+                ax.B = P.probe_B; ax.probe_rows = P.probe_B; ax.wave_doubles = P.probe_wave_doubles;
+                lds = P.probe_lds;
+            }
+            if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, false>), dim3(grid, y), dim3(64 * kBatchWaves), lds, st, ax, bt, part);
+            else        hipLaunchKernelGGL((cells_kernel_star<false, false>), dim3(grid, y), dim3(64 * kBatchWaves), lds, st, ax, bt, part);
         }
     };
     cells(P.grid_pilot, 1);
@@ -3203,6 +3272,14 @@ int trx_set_bounded_evaluation(int mode)
 int trx_set_debug_bug(int on)
 {
     g_debug_bug = on ? 1 : 0;
+    return TRX_OK;
+}
+
+/* tests, A/B runs (include/trx.h): rows per wave of the probe pass of a split launch */
+int trx_set_probe_rows(int rows)
+{
+    if (rows < 0 || rows > kCellsMaxRows) return fail(TRX_ERR_ARG, "probe rows must be 0 (automatic) .. 22%s (got %ld)", "", (long)rows);
+    g_probe_rows = rows;
     return TRX_OK;
 }
 
