@@ -464,10 +464,10 @@ __host__ __device__ inline void set_scratch(RowsArgs& a, double* scratch)
     a.rowc = scratch + list_doubles * (split ? 3 : 1);
 }
 // the arguments of branch blockIdx.y of a chain (see BranchArgs): the common block patched with the branch's own
-__device__ __forceinline__ RowsArgs star_args(const RowsArgs& common, const BranchTab& bt, int part)
+__device__ __forceinline__ RowsArgs star_args(const RowsArgs& common, const BranchTab& bt, int part, int branch = -1)
 {
     RowsArgs a = common;
-    const BranchArgs& b = bt.b[blockIdx.y];
+    const BranchArgs& b = bt.b[branch < 0 ? (int)blockIdx.y : branch];
     a.model = b.model; a.flags = b.flags; a.twin_cols = b.twin_cols; a.need_sec = b.need_sec;
     a.flux = b.flux; a.sigma = b.sigma; a.s2 = b.s2; a.rs2 = b.rs2; a.prune_c0 = b.prune_c0;
     a.params = b.params; a.out = b.out; a.n_dev = b.n_dev; a.src_idx = b.src_idx; a.prune_lp = b.prune_lp;
@@ -833,9 +833,14 @@ __global__ __launch_bounds__(64) void sec_scan_kernel(RowsArgs a)
     sec_scan_body<E>(a);
 }
 
-__global__ __launch_bounds__(64) void sec_scan_kernel_star(RowsArgs common, BranchTab bt)
+// (the grid's second dimension runs over the branches that HAVE a secondary-eclipse rule -- six of a target's eighteen:
+// launched over all of them, two thirds of the kernel's 70 000 workgroups had nothing to do but be dispatched)
+struct BranchMap {
+    unsigned char id[TRX_CHAIN_MAX_BRANCHES];
+};
+__global__ __launch_bounds__(64) void sec_scan_kernel_star(RowsArgs common, BranchTab bt, BranchMap map)
 {
-    const RowsArgs a = star_args(common, bt, 0);
+    const RowsArgs a = star_args(common, bt, 0, (int)map.id[blockIdx.y]);
     if (!a.need_sec) return;
     sec_scan_body<8>(a);
 }
@@ -1081,9 +1086,10 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // r03_f_prune_potential.txt: 4.6 % of TOI-465.01's rows survive 16 cells, 0.5 % lie within 90 of the best).  Its first
     // phase takes every a.pstride3-th stamp (a quarter of the row), the verdict drops what that proves negligible, the
     // second phase finishes the rest.
-    const int pstride = (PRUNE && !LONG && a.part == 3 && a.pstride3 > 1) ? a.pstride3 : a.pstride;
+    const bool third_two = PRUNE && !LONG && a.part == 3 && a.pstride3 > 1;
+    const int pstride = third_two ? a.pstride3 : a.pstride;
     const bool probing = PRUNE && pstride > 1 && hdr[kHdrProbe] != 0.0 &&
-                         (a.part == 0 || a.part == 2 || (!LONG && a.part == 3 && a.pstride3 > 1));
+                         (a.part == 0 || a.part == 2 || third_two);
     if (PRUNE && a.split && a.part == 2 && !probing) return;       // nothing to probe: part 3 takes the rows directly
     // (one row per wave: nothing to taper -- an XCD's waves take consecutive rows of its eighth)
     // (a row count read from the device is wave-uniform, which the compiler cannot know: the plan belongs in scalar
@@ -2655,13 +2661,23 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
         P.passes = a.n_dev || a.n > kPilotRows;
     }
     {
+        // (with the row count on the device the grids are guesses, and a workgroup that finds nothing to do still costs
+        // its dispatch: a chain's rowc_kernel_star was 70 000 one-wave workgroups for 15 000 blocks of rows -- capped,
+        // the workgroups stride: 149 -> 106 us per chain at 512 per branch (1024: 116, 256: 110, 160: 124).  The scan
+        // of the open rows is the opposite case: serial chains of ~1000 fp64 instructions, eight rows a workgroup -- 61 us
+        // with the guessed grid, 123 at 512 workgroups a branch, 373 at 128 (profiles/r05/trace_env.sh).  Environment:
+        // experiments.)
+        static const long rowc_cap = getenv("TRX_ROWC_CAP") ? atol(getenv("TRX_ROWC_CAP")) : 512;
+        static const long scan_cap = getenv("TRX_SCAN_CAP") ? atol(getenv("TRX_SCAN_CAP")) : 1L << 30;
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
+        if (a.n_dev && rb > rowc_cap) rb = rowc_cap;
         P.grid_rowc = (unsigned)rb + 1;
         // every row when the depth is asked for; else the open rows, ~3 % of the rows of a likelihood call (which
         // are themselves ~10 % of `n` when that is only the upper bound): workgroups stride over the list
         long sb = (a.n + 63) / 64;
         if (!a.out_sec && a.n_dev) sb = (sb + 3) / 4;
+        if (!a.out_sec && a.n_dev && sb > scan_cap) sb = scan_cap;
         P.grid_scan = (unsigned)(sb < 64 ? 64 : (sb > 8192 ? 8192 : sb));
         // the depth screen of the rows behind the pilot, lanes = rows; what it leaves goes to the probe pass
         long sg = (a.n + kScreenRows - 1) / kScreenRows;
@@ -2953,7 +2969,13 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
     }
     const unsigned y = (unsigned)nbr;
     hipLaunchKernelGGL(rowc_kernel_star, dim3(P.grid_rowc, y), dim3(64), 0, st, a, bt);
-    if (any_sec) hipLaunchKernelGGL(sec_scan_kernel_star, dim3(P.grid_scan, y), dim3(64), 0, st, a, bt);
+    if (any_sec) {
+        BranchMap map{};
+        unsigned n_sec = 0;
+        for (int i = 0; i < nbr; ++i)
+            if (bt.b[i].need_sec) map.id[n_sec++] = (unsigned char)i;
+        hipLaunchKernelGGL(sec_scan_kernel_star, dim3(P.grid_scan, n_sec), dim3(64), 0, st, a, bt, map);
+    }
     // (the few-rows rule of the listed passes asks for ~3200 waves a launch: a chain's launch is all its branches'.  The
     // survivors' pass of a 64-target step ran one row per wave in most branches under the per-launch rule -- lanes 0.65
     // active: same job, 0.114 -> 0.107-0.109 s per step with the floor divided; any value from 1 to 300 does the same,
