@@ -295,10 +295,12 @@ __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows
 #define TRX_CELLS_PAIRS 640
 #endif
 #ifndef TRX_CELLS_WINDOW
-#define TRX_CELLS_WINDOW 1024
+#define TRX_CELLS_WINDOW 2048
 #endif
 constexpr int kCellsMaxRows = 22;
-// cells per window pass (in-window list in LDS): 1024 with one row per wave; 768 for batches, whose
+// cells per window pass (in-window list in LDS): 2048 with one row per wave (1024 until round 5: a 2000-point row was two
+// window passes, and the cells next to the seam lost their stencil neighbours -- 5.28 -> 5.14 ms per launch of config 1,
+// irregular stamps +1.6 %, 1536: half of that; sixteen one-wave workgroups of 9.9 KB still fit a CU); 768 for batches, whose
 // ~640 cells fit one window -- the smaller list lets one more wave onto a CU at 200-300 points
 // (18.5 -> 17.5 ms per 18 launches at 200 points; 1000-point rows lose 2 % with it)
 #ifndef TRX_CELLS_WINDOW_BATCH
