@@ -859,7 +859,7 @@ struct CellState {
 };
 // centre-value stencil (LONG only): the chunk's centre fluxes and the launch's weights
 struct StencilState {
-    double fc[64];
+    double fc[64 + 8];                      // [kStM + h]: the centre flux of lane h; [0, kStM): the previous chunk's last owned cells'
     double stw[16];
 };
 constexpr int kCentreNode = 1023;           // pair table: "the exposure centre itself" in the node field
@@ -1304,14 +1304,15 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
             int nheavy = 0;
             for (int sweep = 0; sweep < 2; ++sweep) {
             const int count = sweep ? nheavy : nw;
-            // With the centre-value stencil the chunks of the first sweep overlap by 2 kStM cells: a
-            // chunk finalises its lanes [lo, hi) and only lends the centre values of the kStM lanes on
-            // either side, so the cells at a chunk's edges find their neighbours in the next one.
+            // With the centre-value stencil the chunks of the first sweep overlap by kStM cells: a chunk finalises
+            // its first 64 - kStM lanes and only lends the centre values of the last kStM, which the next chunk owns;
+            // what a chunk's first cells need from their left is carried over from the previous one (see below).
             // (a launch sent here by a stale memo -- the address now holds a light curve without a uniform grid --
             // finds radius 0 and walks the list exactly like the instantiation without the stencil: same chunks,
             // same summation order)
             const bool halo = ST && sweep == 0 && st_radius > 0.0;
-            int carry_rel = 0;
+            int carry_j = 0;                       // stencil: the time indices of the previous chunk's lanes
+            unsigned long long carry_ok = 0;       // ... and which of them were planned cells (no contact cell)
             // Carried cells (no stencil).  A chunk's pairs are dealt to the lanes 64 at a time and the last trip is
             // half empty on average -- 54 of 64 lanes per trip at 100 points, and the pair loop is three quarters of
             // the kernel there.  So a chunk with more cells behind it processes only the cells whose pairs fill whole
@@ -1334,16 +1335,20 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 const unsigned cmeta = carried ? cs.meta[csrc] : 0u;
                 bool valid = carried ? (cmeta & 0x20000u) != 0 : (w0 + lane - ncarry) < count;
                 int rel = (int)*(carried ? &cs.rel[csrc] : &winlist[valid ? (w0 + lane - ncarry) : (count - 1)]);
+                bool last_chunk = false;
                 if (ST && halo) {
-                    const bool last_chunk = w0 + 64 >= count;
-                    const int lo = (w0 > 0) ? kStM : 0, hi = last_chunk ? 64 : 64 - kStM;
-                    step = last_chunk ? 64 : hi - kStM;
-                    owned = lane >= lo && lane < hi;
-                    // the leading halo lanes are the previous chunk's last owned cells, whose list entries
-                    // the contact cells filed since may have overwritten: taken from that chunk's lanes
-                    const int prev_rel = __shfl(carry_rel, 64 - 2 * kStM + lane, 64);
-                    if (w0 > 0 && lane < kStM) rel = prev_rel;
-                    carry_rel = rel;
+                    // One-sided halo (round 5): a chunk owns its first 64 - kStM lanes and only lends the centre values
+                    // of the last kStM -- the next chunk's first cells.  What its own first cells need from the left --
+                    // the centre values, time indices and "planned, not a contact cell" bits of the previous chunk's last
+                    // owned cells -- is carried over instead of planning and evaluating those cells a second time
+                    // (until then a chunk owned lanes [kStM, 64 - kStM): 52 new cells per plan trip and per 64 centre
+                    // pairs; now 58).  The contact cells filed so far are at most the cells owned so far = the next
+                    // chunk's first list entry: no entry still to be read is overwritten.
+                    last_chunk = w0 + 64 >= count;
+                    step = last_chunk ? 64 : 64 - kStM;
+                    owned = lane < step;
+                    if (w0 > 0 && lane < kStM) ss.fc[lane] = ss.fc[kStM + (64 - 2 * kStM) + lane];
+                    wave_sync();
                 }
                 const int cell = win0 + rel;
                 int rr = 0, j = cell;
@@ -1391,18 +1396,33 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 // Gauss nodes; every cell within kStM of such a cell adds its centre to its own pairs.
                 bool st = false, centre = false;
                 if (ST && sweep == 0) {
-                    const int jm = __shfl(j, lane - kStM, 64), jp = __shfl(j, lane + kStM, 64);
+                    // (the kStM cells to the left of this chunk's first: lanes 64 - 2 kStM .. 64 - kStM - 1 of the previous one)
+                    // (both shuffles by every lane: a shuffle under a divergent mask reads 0 from the lanes that sit it out)
+                    const int jleft = __shfl(carry_j, 64 - 2 * kStM + lane, 64), jhere = __shfl(j, lane - kStM, 64);
+                    const int jm = (lane < kStM) ? jleft : jhere;
+                    const int jp = __shfl(j, lane + kStM, 64);
                     const unsigned long long mok = __ballot(valid);
-                    const bool inner = lane >= kStM && lane + kStM < 64;
-                    const unsigned long long need = ((1ull << (2 * kStM + 1)) - 1ull) << (inner ? lane - kStM : 0);
+                    const unsigned long long left = (carry_ok >> (64 - 2 * kStM)) & ((1ull << kStM) - 1ull);
+                    const bool inner = (lane >= kStM || (halo && w0 > 0)) && lane + kStM < 64;
+                    constexpr unsigned long long kAll = (1ull << (2 * kStM + 1)) - 1ull;
+                    // the 2 kStM + 1 "planned cell" bits around the lane (the lowest ones from the previous chunk)
+                    const unsigned long long field = (lane >= kStM) ? (mok >> (lane - kStM)) : (((mok << kStM) | left) >> lane);
                     st = inner && owned && valid && pl.n > 0 && pl.st_ok && jm == j - kStM && jp == j + kStM &&
-                         (mok & need) == need;
+                         (field & kAll) == kAll;
                     const unsigned long long mst = __ballot(st);
                     unsigned long long dil = mst;
 #pragma unroll
                     for (int i = 1; i <= kStM; ++i) dil |= (mst << i) | (mst >> i);
                     centre = valid && ((dil >> lane) & 1ull);
+                    // (the next chunk's first cells may take their stencil through this one's last owned cells; one whose
+                    // exposure is off the disc altogether has the value 1 without an evaluation)
+                    if (halo && !last_chunk && valid && !centre && lane >= 64 - 2 * kStM && lane < 64 - kStM) {
+                        if (pl.n > 0) centre = true;
+                        else ss.fc[kStM + lane] = 1.0;
+                    }
                     if (st) nodes = 0;
+                    carry_j = j;
+                    carry_ok = mok;
                 }
                 if (kCarry) wave_sync();        // (the carried cells' reads of the previous chunk's slots are through)
                 cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
@@ -1486,7 +1506,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                                 f = z2;
                             }
                             if (at_centre) {
-                                ss.fc[h] = f;
+                                ss.fc[kStM + h] = f;
                             } else {
                                 const double term = (ht < 0) ? f : tier_xw[2 * (ht * kTierMaxNodes + s) + 1] * (1.0 - f);
                                 if (ht < 0 || term != 0.0)
@@ -1510,7 +1530,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         // the S-point average of the interpolant through the 2 kStM + 1 centre values
                         fsum = 0.0;
 #pragma unroll
-                        for (int i = -kStM; i <= kStM; ++i) fsum = fma(ss.stw[i + kStM], 1.0 - ss.fc[lane + i], fsum);
+                        for (int i = -kStM; i <= kStM; ++i) fsum = fma(ss.stw[i + kStM], 1.0 - ss.fc[kStM + lane + i], fsum);
                     }
                     // the cell's flux deficit: nothing, 1 - mean of the S sub-exposures, or the Gauss rule's weighted sum
                     const double deficit = (pl.n == 0) ? 0.0 : ((tier < 0) ? 1.0 - fsum / a.dS : fsum);
