@@ -1416,7 +1416,12 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     centre = valid && ((dil >> lane) & 1ull);
                     // (the next chunk's first cells may take their stencil through this one's last owned cells; one whose
                     // exposure is off the disc altogether has the value 1 without an evaluation)
-                    if (halo && !last_chunk && valid && !centre && lane >= 64 - 2 * kStM && lane < 64 - kStM) {
+                    // -- and only a cell that a stencil cell of the next chunk can reach: lane 64 - 2 kStM + k is within
+                    // kStM of the next chunk's cells 0 .. k, this chunk's lanes 64 - kStM .. 64 - kStM + k, which can take
+                    // the stencil only where their own plan allows it)
+                    const unsigned long long mnext = __ballot(valid && pl.n > 0 && pl.st_ok) >> (64 - kStM);
+                    const int kk = lane - (64 - 2 * kStM);
+                    if (halo && !last_chunk && valid && !centre && kk >= 0 && kk < kStM && (mnext & ((2ull << kk) - 1ull)) != 0) {
                         if (pl.n > 0) centre = true;
                         else ss.fc[kStM + lane] = 1.0;
                     }
