@@ -151,7 +151,7 @@ def _as_dicts(rec):
     return tuple({c: rec[i, j] for j, c in enumerate(RECORD_COLS)} for i in range(rec.shape[0]))
 
 
-def run_units(units, verbose=0, as_rows=False):
+def run_units(units, verbose=0, as_rows=False, job_done=None):
     """Evaluate the work units of one calc_probs.
 
     units: list of (first_row, names, star_num, ID, thunk_or_None, key[, weight, draws, (job, star)]); weight scales
@@ -160,7 +160,10 @@ def run_units(units, verbose=0, as_rows=False):
     Returns, per unit, None (dropped scenario) or a tuple of per-scenario dicts
     {column: best value, 'lnZ': float} -- with as_rows, the (branches, 15) array of RECORD_COLS instead (what
     target._finish reads: building a dict per scenario and taking it apart again cost 4 ms of a 64-target step, on
-    every rank)."""
+    every rank).
+    job_done(job, results_of_its_units): called as soon as every unit of a job (the first element of a unit's
+    (job, star)) has its records -- while the GPU still works on later jobs -- on one rank with the calls enqueued
+    from one host thread; elsewhere never (the caller finishes what is left)."""
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
@@ -189,7 +192,7 @@ def run_units(units, verbose=0, as_rows=False):
         base = _draw_base()
     _fused.TABLE_ROWS = 1
     try:
-        return _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows)
+        return _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows, job_done if not dist else None)
     finally:
         _fused.TABLE_ROWS = _fused.N_BEST
 
@@ -252,7 +255,7 @@ def _job_of(u):
     return u[8][0] if len(u) > 8 else 0
 
 
-def _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows=False):
+def _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows=False, job_done=None):
     rows = {k: len(units[k][1]) for k in live}
     offs, total = {}, 0
     for k in live:
@@ -356,14 +359,33 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows=Fal
             # across streams the order of enqueueing is a good guess and a wrong one only waits a little longer.
             at = 0
             t_wait = 0.0
+            # (a job whose units all have their rows is handed to the caller at once -- its table is filled while
+            # the GPU works on the later jobs instead of after the last kernel)
+            left, members = {}, {}
+            if job_done is not None:
+                for k, u in enumerate(units):
+                    members.setdefault(_job_of(u), []).append(k)
+                for k in mine_k:
+                    left[_job_of(units[k])] = left.get(_job_of(units[k]), 0) + 1
+                for k in set(mine_k) - {k for k, _ in pending}:         # (calls that returned their records at once)
+                    left[_job_of(units[k])] -= 1
             for ev, upto in done_marks:
                 t_w = time.perf_counter()
                 ev.synchronize()
                 t_wait += time.perf_counter() - t_w
                 if upto > at:
-                    for k, rec in _fused.records_to_rows(pending[at:upto]).items():
+                    got = _fused.records_to_rows(pending[at:upto])
+                    for k, rec in got.items():
                         table[offs[k]:offs[k] + rows[k]] = rec
                     at = upto
+                    if job_done is not None:
+                        for k in got:
+                            j = _job_of(units[k])
+                            left[j] -= 1
+                            if left[j] == 0:
+                                job_done(j, [None if units[m][4] is None else
+                                             (table[offs[m]:offs[m] + rows[m]] if as_rows else _as_dicts(table[offs[m]:offs[m] + rows[m]]))
+                                             for m in members[j]])
             for st in pool:
                 st.synchronize()
             drained = True

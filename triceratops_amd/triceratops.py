@@ -374,14 +374,26 @@ def calc_probs_many(jobs, verbose: int = 0):
         prepared.append((tg,) + tg._prepare(job=job, **kw))
     flat = [u for _, units, _ in prepared for u in units]
     t1 = _time.perf_counter()
-    results = sharding.run_units(flat, verbose=verbose, as_rows=True)
+    # (one rank: a target's table is filled as soon as its last record is in, while the GPU works on the later targets)
+    finished = set()
+    t_fin = [0.0]
+
+    def job_done(job, res):
+        t_a = _time.perf_counter()
+        tg, units, n_scen = prepared[job]
+        tg._finish(units, res, n_scen)
+        finished.add(job)
+        t_fin[0] += _time.perf_counter() - t_a
+
+    results = sharding.run_units(flat, verbose=verbose, as_rows=True, job_done=job_done)
     t2 = _time.perf_counter()
     at = 0
-    for tg, units, n_scen in prepared:
-        tg._finish(units, results[at:at + len(units)], n_scen)
+    for job, (tg, units, n_scen) in enumerate(prepared):
+        if job not in finished:
+            tg._finish(units, results[at:at + len(units)], n_scen)
         at += len(units)
     # every rank lists the units of all targets (cheap: no argument is built before a unit's owner calls it)
     # and fills every target's table from the gathered records; both are a few ms for 64 targets
     sharding.timing["prepare_s"] = t1 - t0
-    sharding.timing["finish_s"] = _time.perf_counter() - t2
+    sharding.timing["finish_s"] = _time.perf_counter() - t2 + t_fin[0]
     return [tg for tg, _ in jobs]
