@@ -82,3 +82,32 @@ def test_calc_depths_pixel_integrals_equal_numerical_integration_of_gauss2d():
                     for (mx, my), A in zip(tg.pix_coords[0], amp)])
     assert np.allclose(tg.stars["fluxratio"].values, rel / rel.sum(), rtol=0, atol=1e-8)
     assert abs(tg.stars["fluxratio"].sum() - 1) < 1e-14
+
+
+def test_prepare_lists_the_same_units_for_a_star_table_with_a_text_column():
+    """target._prepare takes the star table's numeric columns in ONE float64 conversion (eleven pandas column reads
+    were 30 us of every target's preparation, on every rank of a batch); a table that holds a non-numeric column --
+    string IDs, a user's notes -- cannot be converted whole and takes its columns one by one as before.  Both ways
+    must list the same units: same rows, names, star numbers, IDs, weights, (job, star) tags, the same table size
+    (triceratops.py:673-735: the star filter and table sizes of calc_probs)."""
+    from triceratops_amd.triceratops import target
+    stars = pd.DataFrame({
+        "ID": [101, 102, 103], "Tmag": [10.0, 13.0, 14.0], "Jmag": [9.2, 12.1, 13.0], "Hmag": [8.8, 11.6, 12.5],
+        "Kmag": [8.7, 11.5, 12.4], "ra": [10.0, 10.004, 10.01], "dec": [-5.0, -5.003, -5.01],
+        "mass": [1.0, 0.6, np.nan], "rad": [1.0, 0.6, np.nan], "Teff": [5700, 4000, 3900], "plx": [10.0, 2.0, 1.0],
+        "fluxratio": [0.9, 0.07, 0.03], "tdepth": [0.0011, 0.014, 0.0]})
+    t = np.linspace(-0.2, 0.2, 60)
+    f = 1.0 - 0.001 * (np.abs(t) < 0.05)
+    f[7] = np.nan                                                  # (the reference's NaN filter, :673-676)
+    kw = dict(time=t, flux_0=f, flux_err_0=5e-4, P_orb=3.0, N=1000, job=3)
+    tri = os.path.join(GOLD, "trilegal_synth.csv")
+    a = target(101, np.array([1]), stars=stars.copy(), trilegal_fname=tri)
+    with_text = stars.copy()
+    with_text["note"] = ["target", "neighbour", "faint"]
+    b = target(101, np.array([1]), stars=with_text, trilegal_fname=tri)
+    ua, na = a._prepare(**kw)
+    ub, nb = b._prepare(**kw)
+    assert na == nb == 3 * 2 + 12 and len(ua) == len(ub) == 10 + 2
+    for x, y in zip(ua, ub):
+        assert x[:4] == y[:4] and x[5:] == y[5:] and (x[4] is None) == (y[4] is None)
+    assert [u[8] for u in ua] == [(3, 0)] * 10 + [(3, 1), (3, 1)]
