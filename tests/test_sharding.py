@@ -389,3 +389,74 @@ def test_pieces_are_contiguous_runs_of_one_target():
     pieces = sharding._pieces(many, list(range(len(many))), 4)
     assert [len(p) for p in pieces] == [12] * 6                   # one run (one launch chain) per target
     assert sharding._pieces(units[:1], [0], 4) == [[0]] and sharding._pieces(units, [], 4) == []
+
+
+def _four_jobs():
+    a = _two_jobs()
+    b = _two_jobs()
+    for tg, _ in b:
+        tg.stars["ID"] = tg.stars["ID"] + 5000
+    return a + b
+
+
+def _defer_worker(rank, world, port, q):
+    import pytest as _pytest
+    import triceratops_amd
+    triceratops_amd.set_sampling("numpy")
+    from helpers import install_cpu_device_fakes
+    from triceratops_amd.triceratops import calc_probs_many
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mp_ = _pytest.MonkeyPatch()
+    install_cpu_device_fakes(mp_)
+    jobs = _four_jobs()
+    for tg, _ in jobs:
+        tg.FPP = "stale"                      # (a result of an earlier call must not survive a deferred table)
+    np.random.seed(77)
+    calc_probs_many(jobs)
+    pending = [tg.__dict__.get("_pending_finish") is not None for tg, _ in jobs]
+    has_fpp = ["FPP" in tg.__dict__ for tg, _ in jobs]
+    own = sorted(sharding.last_own_jobs)
+    q.put((rank, _tables(jobs), pending, has_fpp, own))
+    dist.barrier()
+    dist.destroy_process_group()
+    mp_.undo()
+
+
+def test_tables_of_other_ranks_targets_are_filled_on_first_read(monkeypatch):
+    """calc_probs_many on several ranks: after the all_gather every rank holds every record, fills the tables of the
+    targets it evaluated itself at once and the others' when one of their results is first read (target.__getattr__:
+    filling all 64 tables of a batch was a quarter of a rank's host path on eight ranks).  Four targets on two ranks:
+    a target no unit of which the rank evaluated is pending until read, holds no result of an earlier call, and
+    reads the same as everywhere else and as in one process."""
+    from helpers import install_cpu_device_fakes
+    from triceratops_amd.triceratops import calc_probs_many
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_defer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owns = [set(g[4]) for g in got]
+    # (the two larger targets are dearer than 3/4 of a rank's share and are dealt star by star: both ranks hold part of them)
+    assert owns[0] | owns[1] == {0, 1, 2, 3} and all(len(o) < 4 for o in owns)
+    for r, (_, tables, pending, has_fpp, _own) in enumerate(got):
+        assert pending == [j not in owns[r] for j in range(4)]
+        assert has_fpp == [j in owns[r] for j in range(4)]
+        for a, b in zip(got[0][1], tables):
+            assert np.array_equal(a, b, equal_nan=True)
+    install_cpu_device_fakes(monkeypatch)
+    jobs = _four_jobs()
+    np.random.seed(77)
+    sharding.per_unit_seed = True
+    try:
+        calc_probs_many(jobs)
+    finally:
+        sharding.per_unit_seed = False
+    for a, b in zip(got[0][1], _tables(jobs)):
+        assert np.array_equal(a, b, equal_nan=True)

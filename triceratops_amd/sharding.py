@@ -53,6 +53,7 @@ timing = {"enqueue_s": 0.0, "wait_s": 0.0, "gather_s": 0.0, "prepare_s": 0.0, "f
 last_seed_bases = None
 # what the schedule of the last run_units gave every rank: lnZ_* calls, distinct (job, star)s and distinct jobs
 last_share = {"calls": [0], "stars": [0], "jobs": [0]}
+last_own_jobs = set()
 _warned_bases = False
 # True: the first device pass calls gc.freeze() once (see _run_units); set to False to leave the collector alone
 freeze_gc = True
@@ -184,6 +185,8 @@ def run_units(units, verbose=0, as_rows=False, job_done=None):
         stars[r].add(_star_of(units[k]))
         jobs[r].add(_job_of(units[k]))
     last_share = {"calls": calls, "stars": [len(x) for x in stars], "jobs": [len(x) for x in jobs]}
+    global last_own_jobs
+    last_own_jobs = jobs[rank]              # (calc_probs_many: the targets whose tables this rank fills at once)
     # calc_probs keeps the best draw of every scenario only: with the device generator the fused
     # path then selects it with one argmin instead of a top-100 sort (fused.TABLE_ROWS)
     from . import fused as _fused

@@ -129,7 +129,15 @@ class target:
         units = []
         ok = True
         keep, stars, column = filtered
-        col = {c: column(c)[keep] for c in ("fluxratio", "mass", "rad", "Teff", "Tmag", "Jmag", "Hmag", "Kmag", "plx")}
+        cache = {}
+
+        def col(c):
+            """column c of the stars that can host the signal, on first use (a rank that does not own the target never
+            asks for most of them)"""
+            v = cache.get(c)
+            if v is None:
+                v = cache[c] = column(c)[keep]
+            return v
         tail = (N, parallel, self.mission, flatpriors, exptime, nsamples)
         trilegal = self.trilegal_fname
         fns = {"TP": lnZ_TTP, "EB": lnZ_TEB, "PTP": lnZ_PTP, "PEB": lnZ_PEB, "STP": lnZ_STP, "SEB": lnZ_SEB,
@@ -138,8 +146,8 @@ class target:
         def star_args(i, cache={}):
             """(time, flux, flux_err, P_orb, M_s, R_s, Teff) of star i, built on first use"""
             if i not in cache:
-                flux, flux_err = renorm_flux(flux_0, flux_err_0, col["fluxratio"][i])
-                M_s, R_s, Teff = col["mass"][i], col["rad"][i], col["Teff"][i]
+                flux, flux_err = renorm_flux(flux_0, flux_err_0, col("fluxratio")[i])
+                M_s, R_s, Teff = col("mass")[i], col("rad")[i], col("Teff")[i]
                 if i > 0:      # nearby star: unknown properties default to solar values
                     Teff = 5777 if np.isnan(Teff) else Teff
                     M_s = 1.0 if np.isnan(M_s) else M_s
@@ -152,8 +160,8 @@ class target:
             if key in ("TP", "EB"):
                 return fns[key](*b, Z, *tail)
             if key in ("PTP", "PEB", "STP", "SEB"):
-                return fns[key](*b, Z, col["plx"][0], contrast_curve_file, filt, *tail, molusc_file)
-            mags = (col["Tmag"][0], col["Jmag"][0], col["Hmag"][0], col["Kmag"][0])
+                return fns[key](*b, Z, col("plx")[0], contrast_curve_file, filt, *tail, molusc_file)
+            mags = (col("Tmag")[0], col("Jmag")[0], col("Hmag")[0], col("Kmag")[0])
             field = mags + (trilegal, contrast_curve_file, filt) + tail
             if key in ("DTP", "DEB"):
                 return fns[key](*b, Z, *field)
@@ -164,8 +172,8 @@ class target:
 
         for i, ID in enumerate(stars["ID"].to_numpy()[keep]):
             if i == 0:
-                if (np.isnan(col["mass"][0]) or np.isnan(col["rad"][0]) or np.isnan(col["Teff"][0])
-                        or np.isnan(col["plx"][0])):
+                if (np.isnan(col("mass")[0]) or np.isnan(col("rad")[0]) or np.isnan(col("Teff")[0])
+                        or np.isnan(col("plx")[0])):
                     print("Insufficient information to validate " + str(ID)
                           + ". Please ensure a stellar mass (in M_Sun), radius (in R_Sun), Teff "
                           + "(in K), and plx (in mas) are provided in the .stars dataframe.")
@@ -238,6 +246,7 @@ class target:
         (triceratops.py:1430-1485).  Plain arrays here; the `.probs` DataFrame of the reference is put
         together when it is first read (a batch of 64 targets spent as long building 64 DataFrames nobody
         had asked for yet as waiting for the GPU)."""
+        self.__dict__["_pending_finish"] = None
         targets = np.zeros(n_scen, dtype=np.dtype("i8"))
         star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
         scenarios = np.zeros(n_scen, dtype=np.dtype('U6'))
@@ -303,6 +312,27 @@ class target:
         self.FPP = 1 - (prob[0] + prob[3] + prob[9])
         self.NFPP = np.sum(prob[15:]) if len(prob) > 15 else 0.0
         return
+
+    # what _finish sets: a target whose table is still to be filled (calc_probs_many on several ranks) has none of them
+    _RESULTS = ("lnZ", "star_num", "u1", "u2", "fluxratio_EB", "fluxratio_comp", "FPP", "NFPP", "FPP_degenerate",
+                "_probs_columns", "_probs")
+
+    def _defer_finish(self, units, results, n_scen):
+        """the table of this target is filled when one of its results is first read"""
+        d = self.__dict__
+        for name in self._RESULTS:
+            d.pop(name, None)                # (results of an earlier calc_probs must not be read as this one's)
+        d["_pending_finish"] = (units, results, n_scen)
+
+    def __getattr__(self, name):
+        # (only reached when normal lookup fails)
+        d = object.__getattribute__(self, "__dict__")
+        pend = d.get("_pending_finish")
+        if pend is not None and name in type(self)._RESULTS:
+            d["_pending_finish"] = None
+            self._finish(*pend)
+            return object.__getattribute__(self, name)
+        raise AttributeError("'%s' object has no attribute '%s'" % (type(self).__name__, name))
 
     @property
     def probs(self):
@@ -399,9 +429,16 @@ def calc_probs_many(jobs, verbose: int = 0):
     results = sharding.run_units(flat, verbose=verbose, as_rows=True, job_done=job_done)
     t2 = _time.perf_counter()
     at = 0
+    # Several ranks: every rank holds every record after the all_gather, and a rank fills the tables of the targets it
+    # evaluated itself at once; the others' are filled when one of their results is first read (target.__getattr__) --
+    # filling all 64 tables of a batch on each of eight ranks was a quarter of a rank's host path.
+    many_ranks = sharding._dist() is not None
     for job, (tg, units, n_scen) in enumerate(prepared):
         if job not in finished:
-            tg._finish(units, results[at:at + len(units)], n_scen)
+            if many_ranks and job not in sharding.last_own_jobs:
+                tg._defer_finish(units, results[at:at + len(units)], n_scen)
+            else:
+                tg._finish(units, results[at:at + len(units)], n_scen)
         at += len(units)
     # every rank lists the units of all targets (cheap: no argument is built before a unit's owner calls it)
     # and fills every target's table from the gathered records; both are a few ms for 64 targets
