@@ -428,20 +428,155 @@ def test_entry_points_capture_into_a_hip_graph_and_replay():
         rows = synth.tp_rows(rng, 2000, True)
         rows_d.copy_(_lib.dev(rows))              # new inputs in the captured buffers
         h_d.zero_()
-        torch.cuda.synchronize()
+        if rep == 0:
+            torch.cuda.synchronize()              # (the second replay is enqueued behind work still in flight)
         g.replay()
         torch.cuda.synchronize()
         want_h = O.lnl_batch(0, t, flux, synth.SIGMA, rows)
-        got_h = h_d.cpu().numpy()
-        if not np.allclose(got_h, want_h, rtol=1e-6, atol=0, equal_nan=True):
-            # (seen once in ~20 runs of the whole suite and never in this file alone: say what the replay returned)
-            bad = np.flatnonzero(~np.isclose(got_h, want_h, rtol=1e-6, atol=0, equal_nan=True))
-            print("replay %d: %d of 2000 rows differ, first %s: got %s want %s; zeros in the output: %d"
-                  % (rep, bad.size, bad[:5], got_h[bad[:5]], want_h[bad[:5]], int((got_h == 0).sum())))
-        _cmp_h(got_h, want_h)
+        _cmp_h(h_d.cpu().numpy(), want_h)
         lnL = np.full(20000, -np.inf)
         lnL[:2000] = -0.5 * np.log(2 * np.pi) - np.log(synth.SIGMA) - want_h + prior_d.cpu().numpy()
         assert abs(float(lnz_d.cpu()[0]) - O.log_mean_exp(lnL, 20000)) < 1e-9
+
+
+def _graph_node_types(graph_handle):
+    """hipGraphNodeType of every node of a hipGraph_t, asked of the HIP runtime this process has loaded"""
+    import ctypes
+    path = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            path = line.split()[-1]
+            break
+    assert path, "no HIP runtime mapped"
+    hip = ctypes.CDLL(path)
+    n = ctypes.c_size_t(0)
+    assert hip.hipGraphGetNodes(ctypes.c_void_p(graph_handle), None, ctypes.byref(n)) == 0
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    assert hip.hipGraphGetNodes(ctypes.c_void_p(graph_handle), nodes, ctypes.byref(n)) == 0
+    types = []
+    for i in range(n.value):
+        ty = ctypes.c_int(-1)
+        assert hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(ty)) == 0
+        types.append(ty.value)
+    return types
+
+
+def test_a_captured_call_holds_no_graph_memory_nodes():
+    """Rounds 2-5 took the scratch of a captured call from graph memory nodes (hipMallocAsync on the capturing stream).
+    A replay then returned, once in ~30 000, rows evaluated on row blocks -- or a launch header -- that read as zero
+    from a page boundary of that allocation on (profiles/r06/graph_stress_mix_graphmem.txt; the once-in-twenty-suite-runs
+    failure of the test above).  A captured call now gets a buffer of its own that the GRAPH owns (trx::capture_scratch):
+    no memory-allocation node in the captured graph -- this test failed on the old library --, one buffer per captured
+    model call while an executable graph lives, handed back to the library's pool when it is gone."""
+    import ctypes
+    import gc
+    L = _lib.lib()
+    if not hasattr(L, "trx_debug_capture_buffers"):
+        pytest.skip("the library in use exports no trx_debug_* entry points")
+
+    def buffers():
+        a, b = ctypes.c_long(), ctypes.c_long()
+        assert L.trx_debug_capture_buffers(ctypes.byref(a), ctypes.byref(b)) == 0
+        return a.value, b.value
+
+    rng, t, flux = _lc(300)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    blocks = {0: synth.tp_rows(rng, 1500, True), 1: synth.eb_rows(rng, 1500, False, True)}
+    devs = {m: _lib.dev(b) for m, b in blocks.items()}
+    outs = {m: torch.empty(1500, dtype=torch.float64, device="cuda") for m in blocks}
+    for m in blocks:
+        _lib.lnl_batch(m, 0, t_d, f_d, synth.SIGMA, devs[m], synth.EXPTIME, 20, out=outs[m])        # warm-up
+    torch.cuda.synchronize()
+    live0, _ = buffers()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        for m in blocks:
+            _lib.lnl_batch(m, 0, t_d, f_d, synth.SIGMA, devs[m], synth.EXPTIME, 20, out=outs[m])
+    types = _graph_node_types(g.raw_cuda_graph())
+    assert 10 not in types and 11 not in types, types          # hipGraphNodeTypeMemAlloc / MemFree
+    assert types.count(0) >= 5                                  # the kernels are there (rowc, scan, cells ...)
+    g.instantiate()
+    assert buffers()[0] == live0 + 2                            # one buffer per captured model call, owned by the graph
+    for m in blocks:
+        outs[m].zero_()
+    g.replay()                                                  # (no synchronisation before it)
+    torch.cuda.synchronize()
+    for m, b in blocks.items():
+        _cmp_h(outs[m].cpu().numpy(), O.lnl_batch(m, t, flux, synth.SIGMA, b))
+    del g
+    gc.collect()
+    torch.cuda.synchronize()
+    live1, idle1 = buffers()
+    assert live1 == live0 and idle1 >= 2                        # handed back when the graphs are gone; reusable
+
+
+def test_replays_behind_work_in_flight_stay_correct():
+    """a short run of profiles/r06/graph_stress.py's sequence (the long runs: profiles/r06/graph_stress_*.txt): fresh
+    captures, replays with and without a host synchronisation in front, on the capture's stream and on another one,
+    compared bit for bit with plain calls on the same inputs"""
+    rng, t, flux = _lc(300)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    sets = [synth.tp_rows(rng, 2000, True) for _ in range(3)]
+    wants = []
+    for rows in sets:
+        h = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, _lib.dev(rows), synth.EXPTIME, 20)
+        wants.append(h.cpu().numpy().copy())
+    _cmp_h(wants[0], O.lnl_batch(0, t, flux, synth.SIGMA, sets[0]))
+    side = torch.cuda.Stream()
+    for cyc in range(60):
+        rows_d = _lib.dev(sets[0])
+        h_d = torch.empty(2000, dtype=torch.float64, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, out=h_d)
+        for rep in range(3):
+            k = (cyc + rep + 1) % 3
+            rows_d.copy_(_lib.dev(sets[k]))
+            h_d.zero_()
+            if cyc % 2:
+                torch.cuda.synchronize()
+            if cyc % 3 == 0:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g.replay()
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(h_d.cpu().numpy(), wants[k]), (cyc, rep)
+        del g
+
+
+def test_uploads_during_a_capture_are_refused_and_pending_ones_are_left_alone():
+    """_lib.wait_uploads queried upload events on every call: while a capture lasts that is an error that INVALIDATES the
+    capture (hipErrorStreamCaptureUnsupported; profiles/r06/graph_stress_a.txt, one capture in ~2700 -- whenever an upload
+    was still in flight at the call before the capture).  A captured call now leaves the list alone, and _lib.dev()
+    says so instead of uploading on another stream behind the capture's back."""
+    rng, t, flux = _lc(120)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    rows = synth.tp_rows(rng, 500, True)
+    rows_d = _lib.dev(rows)
+    h_d = torch.empty(500, dtype=torch.float64, device="cuda")
+    _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, out=h_d)
+    # an upload nobody has waited for or pruned: its event stays on the list into the capture
+    torch.cuda.synchronize()
+    keep = _lib.dev(np.zeros(1 << 20))
+    dev_index = keep.device.index
+    if not _lib._pending_uploads.get(dev_index):              # (it landed before dev() returned: list an event by hand)
+        ev = torch.cuda.Event()
+        ev.record()
+        with _lib._pending_lock:
+            seq = _lib._upload_seq[dev_index] = _lib._upload_seq.get(dev_index, 0) + 1
+            _lib._pending_uploads.setdefault(dev_index, []).append((seq, ev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows_d, synth.EXPTIME, 20, out=h_d)
+        with pytest.raises(_lib.TrxError, match="captured"):
+            _lib.dev(np.zeros(4))
+    h_d.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    _cmp_h(h_d.cpu().numpy(), O.lnl_batch(0, t, flux, synth.SIGMA, rows))
 
 
 @pytest.mark.parametrize("n_time", [200, 2000])

@@ -214,6 +214,11 @@ def dev(x, device=None):
     d = torch.device(device or "cuda")
     if d.type != "cuda" or not torch.cuda.is_available():
         return torch.as_tensor(a).to(d).contiguous()
+    if torch.cuda.is_current_stream_capturing():
+        # (an upload is eager work on another stream: a captured call would not be ordered behind it, and its event may
+        # neither be waited for nor queried while the capture lasts)
+        raise TrxError("triceratops_amd: host data cannot be uploaded while the current stream is being captured into "
+                       "a graph; stage the inputs with _lib.dev() before the capture begins")
     if d.index is None:
         d = torch.device("cuda", torch.cuda.current_device())
     up = upload_stream(d).stream
@@ -237,6 +242,13 @@ def wait_uploads(stream):
     go up on ONE stream, in order, so waiting for the newest pending one covers all before it"""
     pend = _pending_uploads.get(stream.device.index)
     if not pend:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        # Nothing may be asked of an event while a capture lasts: hipEventQuery fails with "operation not permitted when
+        # stream is capturing" AND invalidates the capture (found by profiles/r06/graph_stress.py: an upload still in
+        # flight at the warm-up call leaves its event on the list, and the captured call that follows queried it --
+        # one capture in ~2700).  A captured call is not executed now; torch.cuda.graph() synchronises the device before
+        # it begins the capture, so every upload issued before it has landed, and dev() refuses uploads during one.
         return
     # (keyed per device: the default stream is handle 0 on every device, and sequence numbers are per device too)
     key = (stream.device.index, stream.cuda_stream)

@@ -21,6 +21,11 @@ constexpr int kScratchSlots = 4;
 // after every growth (cleared on the stream): persistent counters that the kernels themselves leave at zero.
 constexpr size_t kScratchZeroed = 4096;
 hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out);
+// Scratch of a call that is being captured into a hipGraph on `st`: a buffer of its own, owned by the graph under
+// capture and handed back to a pool when that graph and its executables are gone (see trx_kernels.hip).
+hipError_t capture_scratch(hipStream_t st, size_t bytes, void** out);
+void capture_scratch_stats(long* live, long* idle);      // buffers graphs still own / buffers waiting for reuse
+hipError_t capture_scratch_release_idle();
 
 // Held while a call enqueues its kernels on `st`: two host threads that share a stream take turns, so
 // the kernels of one call (rowc_kernel -> cells_kernel -> reductions, all on the stream's scratch) are

@@ -33,6 +33,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "../../include/trx.h"
 #include "trx_device.hpp"
@@ -2736,11 +2737,16 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         if (verdict == 1 || verdict == 2) a.use_stencil = 2;
     }
     // the row constants: 152 B per row of the stream's scratch (+ the flat-model chi^2), filled 64 rows
-    // per wave.  While the stream is being captured into a hipGraph the scratch is a pair of graph
-    // memory nodes instead (the library's buffer must not be grown, nor baked into a graph).
+    // per wave.  While the stream is being captured into a hipGraph the scratch is a buffer of its own that the
+    // GRAPH owns (trx::capture_scratch: the stream's buffer must not be grown, nor baked into a graph).
     void* scratch = nullptr;
     const size_t scratch_bytes = launch_scratch_doubles(a.n, split) * sizeof(double);
+#ifdef TRX_CAPTURE_GRAPH_MEM
+    // (A/B builds only, profiles/r06/graph_stress.py: rounds 2-5 took a pair of graph memory nodes here)
     if (capturing) TRX_HIP(hipMallocAsync(&scratch, scratch_bytes, st));
+#else
+    if (capturing) TRX_HIP(trx::capture_scratch(st, scratch_bytes, &scratch));
+#endif
     else TRX_HIP(trx::stream_scratch(st, 0, scratch_bytes, &scratch));
     set_scratch(a, static_cast<double*>(scratch));
     // From here on a failure may leave the scan's counter non-zero in the stream's scratch (rowc_kernel<true> counts,
@@ -2751,7 +2757,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
     };
     if (a.need_sec) {
         // (the scan's counter is zero in the stream's scratch: cleared at allocation, then by every cells_kernel
-        // that follows a scan; graph memory nodes hold anything)
+        // that follows a scan; a captured call's own buffer holds anything)
         if (capturing) TRX_HIP(hipMemsetAsync(a.scan_count, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(rowc_kernel<true>, dim3(P.grid_rowc), dim3(64), 0, st, a);
         if (a.out_sec) hipLaunchKernelGGL(sec_scan_kernel<64>, dim3(P.grid_scan), dim3(64), 0, st, a);
@@ -2803,7 +2809,9 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
         else            hipLaunchKernelGGL((cells_kernel<MODE, true, false, false, false>), dim3(g2), dim3(64 * kBatchWaves), lds, st, a);
     }
     const hipError_t launched = hipGetLastError();
+#ifdef TRX_CAPTURE_GRAPH_MEM
     if (capturing) TRX_HIP(hipFreeAsync(scratch, st));
+#endif
     if (launched != hipSuccess) return fail_launch(launched);
     return TRX_OK;
 }
@@ -2897,6 +2905,119 @@ hipError_t stream_scratch(hipStream_t st, int slot, size_t bytes, void** out)
     }
     *out = en.p[slot];
     return hipSuccess;
+}
+
+// ---- scratch of a call captured into a hipGraph -----------------------------------------------------------------
+// Rounds 2-5 took graph memory nodes (hipMallocAsync / hipFreeAsync on the capturing stream).  On this stack (ROCm 7.2,
+// gfx950) a replay enqueued behind work still in flight then intermittently runs cells_kernel on row blocks that read as
+// ZERO from a 4-KiB page boundary of the node's allocation to its end -- the rows there come back with the flat-model
+// chi^2 (profiles/r06/graph_stress_*.txt: 1 replay in ~2000 without a host synchronisation before it, none with one;
+// the once-in-twenty-suite-runs failure of test_entry_points_capture_into_a_hip_graph_and_replay).  The runtime maps a
+// node's physical memory when the graph is launched, from the host, whatever the GPU is doing.  So a captured call now
+// gets a plain hipMalloc'ed buffer of its own -- allocated under the relaxed capture mode, like the node table of
+// tier_device -- that belongs to the graph being captured: a hipUserObject retained by that graph hands the buffer back
+// to the pool below when the last graph / executable graph that refers to it is destroyed (the callback may not call
+// HIP: it only files the buffer), and a later capture takes a filed buffer that is large enough before allocating.
+// trx_release_scratch() frees the filed ones.  If the runtime refuses the user object the buffer simply stays with the
+// library until trx_release_scratch().
+namespace {
+struct CaptureBuf {
+    void* p;
+    size_t bytes;
+    int dev;
+};
+std::mutex g_capture_mu;
+std::vector<CaptureBuf*> g_capture_idle;      // handed back by their graphs (or never owned by one): reusable
+std::vector<CaptureBuf*> g_capture_orphans;   // the runtime refused the user object: kept until trx_release_scratch()
+long g_capture_live = 0;                      // buffers that a graph still owns
+void capture_buf_release(void* ud)
+{
+    std::lock_guard<std::mutex> lock(g_capture_mu);
+    g_capture_idle.push_back(static_cast<CaptureBuf*>(ud));
+    --g_capture_live;
+}
+}  // namespace
+
+hipError_t capture_scratch(hipStream_t st, size_t bytes, void** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    hipGraph_t graph = nullptr;
+    unsigned long long id = 0;
+    if ((e = hipStreamGetCaptureInfo_v2(st, &status, &id, &graph, nullptr, nullptr)) != hipSuccess) return e;
+    if (status != hipStreamCaptureStatusActive || !graph) return hipErrorStreamCaptureInvalidated;
+    CaptureBuf* buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_capture_mu);
+        size_t best = 0;
+        for (size_t i = 0; i < g_capture_idle.size(); ++i) {
+            CaptureBuf* c = g_capture_idle[i];
+            if (c->dev == dev && c->bytes >= bytes && (!buf || c->bytes < buf->bytes)) { buf = c; best = i; }
+        }
+        if (buf) g_capture_idle.erase(g_capture_idle.begin() + (long)best);
+    }
+    if (!buf) {
+        // (legal while this thread captures in the global mode: nothing here touches the capturing stream)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        void* p = nullptr;
+        e = hipMalloc(&p, bytes);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) return e;
+        buf = new CaptureBuf{p, bytes, dev};
+    }
+    hipUserObject_t obj = nullptr;
+    bool owned = false;
+    if (hipUserObjectCreate(&obj, buf, capture_buf_release, 1, hipUserObjectNoDestructorSync) == hipSuccess) {
+        {
+            std::lock_guard<std::mutex> lock(g_capture_mu);
+            ++g_capture_live;
+        }
+        if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) == hipSuccess) owned = true;
+        else { (void)hipGetLastError(); (void)hipUserObjectRelease(obj, 1); }      // (the callback files the buffer)
+    } else {
+        (void)hipGetLastError();
+    }
+    if (!owned) {
+        // no owner: the buffer must outlive a graph whose lifetime the library cannot see -- it is kept out of the pool
+        // (never reused) until trx_release_scratch()
+        std::lock_guard<std::mutex> lock(g_capture_mu);
+        for (size_t i = 0; i < g_capture_idle.size(); ++i)
+            if (g_capture_idle[i] == buf) { g_capture_idle.erase(g_capture_idle.begin() + (long)i); break; }
+        g_capture_orphans.push_back(buf);
+    }
+    *out = buf->p;
+    return hipSuccess;
+}
+
+void capture_scratch_stats(long* live, long* idle)
+{
+    std::lock_guard<std::mutex> lock(g_capture_mu);
+    *live = g_capture_live;
+    *idle = (long)g_capture_idle.size();
+}
+
+hipError_t capture_scratch_release_idle()
+{
+    std::lock_guard<std::mutex> lock(g_capture_mu);
+    int cur = 0;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return e;
+    for (CaptureBuf* c : g_capture_idle) {
+        (void)hipSetDevice(c->dev);
+        (void)hipFree(c->p);
+        delete c;
+    }
+    g_capture_idle.clear();
+    for (CaptureBuf* c : g_capture_orphans) {
+        (void)hipSetDevice(c->dev);
+        (void)hipFree(c->p);
+        delete c;
+    }
+    g_capture_orphans.clear();
+    return hipSetDevice(cur);
 }
 
 int fail_hip(hipError_t e) { return fail(TRX_ERR_HIP, "%s (hip error %ld)", hipGetErrorString(e), (long)e); }
@@ -3395,6 +3516,16 @@ int trx_debug_phase_cycles(unsigned long long* out8)
 }
 #endif
 
+/* (tests) scratch buffers of captured calls: how many a live graph still owns, how many wait in the pool for reuse */
+int trx_debug_capture_buffers(long* live, long* idle)
+{
+    long a = 0, b = 0;
+    trx::capture_scratch_stats(&a, &b);
+    if (live) *live = a;
+    if (idle) *idle = b;
+    return TRX_OK;
+}
+
 /* frees every per-stream scratch buffer of the library (all devices); the streams must be idle */
 int trx_release_scratch(void)
 {
@@ -3412,6 +3543,7 @@ int trx_release_scratch(void)
     }
     trx::g_scratch.clear();
     TRX_HIP(hipSetDevice(cur));
+    TRX_HIP(trx::capture_scratch_release_idle());
     return TRX_OK;
 }
 
