@@ -93,6 +93,8 @@ def parse():
     # test hook for 1-GPU boxes: run the N>1 control flow (rendezvous, barrier, gather, max-reduce)
     # with every rank on cuda:0 and a gloo process group (RCCL refuses two ranks on one device)
     ap.add_argument("--debug-single-device", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-rccl-world1", action="store_true",
+                    help="one GPU: do not set up the one-rank RCCL group that sends one untimed batch step through the collective")
     ap.add_argument("--all-subexposures", action="store_true",
                     help="switch the reduced-node exposure average off for the timed steps")
     ap.add_argument("--fp32-model", action="store_true",
@@ -237,6 +239,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
+        if not args.no_rccl_world1 and (args.mode == "batch" or not args.no_batch_leg):
+            # a one-rank RCCL group: the batch leg sends one step through the collective branch (batch_leg)
+            try:
+                store = "/tmp/trx_bench_pg_%d" % os.getpid()
+                if os.path.exists(store):
+                    os.remove(store)
+                dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1,
+                                        device_id=torch.device("cuda", 0))
+            except Exception as exc:                  # noqa: BLE001  (the bench line does not depend on it)
+                sys.stderr.write("bench: one-rank RCCL group unavailable (%s: %s)\n" % (type(exc).__name__, exc))
     _lib.require_gpu()
     device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
     ctx = dict(args=args, world=world, rank=rank, device=device, debug_one=debug_one, extras=extras,
@@ -246,6 +258,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -599,7 +612,15 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
             torch.manual_seed(seed)          # ranks seeded alike: the run can be repeated (sharding's seed base)
             t0 = time.perf_counter()
             out = triceratops_amd.calc_probs_many(js)
-            return out, time.perf_counter() - t0
+            # Equal work at every world size (advisor, round 5): on several ranks calc_probs_many leaves the tables of
+            # the targets a rank did not evaluate to their first reader; the step ends when EVERY target's table exists
+            # where the results are read -- rank 0 -- as it does on one rank.  What that costs is `deferred_finish_s`.
+            t1 = time.perf_counter()
+            if rank == 0:
+                for tg in out:
+                    tg.FPP
+            t2 = time.perf_counter()
+            return out, t2 - t0, t2 - t1
 
         step(small, 1)                           # library load, tables, allocator
         for w in range(warmup):
@@ -607,16 +628,18 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
         _sync(ctx)
         if before_timed is not None:
             before_timed()
-        host = np.zeros(8)
+        host = np.zeros(9)
         best_path = np.inf                       # smallest host path of a single step (a ratio of two such is what
         t0 = time.perf_counter()                 # tests compare: the mean carries whatever else the box was doing)
+        gathers = sharding._dist() is not None   # (several ranks, or one rank sent through the collective: main())
         for s_ in range(steps):
-            out, dt = step(jobs, 100 + s_)
+            out, dt, dfin = step(jobs, 100 + s_)
             tm = sharding.timing
-            waits = tm["wait_s"] + (tm["gather_s"] if world > 1 else 0.0)
+            waits = tm["wait_s"] + (tm["gather_s"] if gathers else 0.0)
             best_path = min(best_path, dt - waits)
-            host[:7] += [tm["prepare_s"], tm["enqueue_s"], tm["wait_s"], tm["gather_s"] if world > 1 else 0.0,
-                         tm["finish_s"], dt, 0.0]
+            host[:7] += [tm["prepare_s"], tm["enqueue_s"], tm["wait_s"], tm["gather_s"] if gathers else 0.0,
+                         tm["finish_s"] + dfin, dt, 0.0]
+            host[8] += dfin
         _sync(ctx)
         elapsed = _max_over_ranks(ctx, time.perf_counter() - t0)
         host /= max(steps, 1)
@@ -628,7 +651,9 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
             allr = torch.empty(world * host.size, dtype=torch.float64, device=mine.device)
             dist.all_gather_into_tensor(allr, mine)
             per_rank = allr.cpu().numpy().reshape(world, -1)
-        names = ("prepare_s", "enqueue_s", "wait_s", "gather_s", "finish_s", "step_s", "other_s", "host_path_best_s")
+        # (finish_s includes deferred_finish_s: the tables rank 0 fills for the targets other ranks evaluated)
+        names = ("prepare_s", "enqueue_s", "wait_s", "gather_s", "finish_s", "step_s", "other_s", "host_path_best_s",
+                 "deferred_finish_s")
         timing = {k: [float(v) for v in per_rank[:, i]] for i, k in enumerate(names)}
         # what a rank's host does on the critical path of a step apart from waiting (for its GPU, for the others)
         timing["host_path_s"] = [float(per_rank[r, 0] + per_rank[r, 1] + per_rank[r, 4] + per_rank[r, 6])
@@ -636,6 +661,27 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
         timing["calls"] = sharding.last_share["calls"]
         timing["stars"] = sharding.last_share["stars"]
         timing["jobs"] = sharding.last_share["jobs"]
+        if world == 1 and dist.is_available() and dist.is_initialized():
+            # One rank has nothing to gather and the timed steps skip the collective.  So that the RCCL branch of
+            # sharding._run_units is executed on the hardware there is -- device tensors, header row, padding, through
+            # all_gather_into_tensor of the one-rank "nccl" group main() set up -- one more step goes through it, not
+            # timed as part of `value`, next to the same step without it (per-unit seeds on both sides: same tables).
+            twin = synth.toi_jobs(tois, n_time=n_time, N=N, seed=synth.SEED, trilegal_fname=tri, contrast_curve_file=cc)
+            sharding.per_unit_seed = True
+            try:
+                ref, dt_a, _ = step(twin, 999)
+                fa = [float(tg.FPP) for tg in ref]
+            finally:
+                sharding.per_unit_seed = False
+            sharding.collective_at_world_one = True
+            try:
+                got, dt_b, _ = step(twin, 999)
+                fb = [float(tg.FPP) for tg in got]
+                timing["rccl_world1"] = {"backend": dist.get_backend(), "gather_s": float(sharding.timing["gather_s"]),
+                                         "step_s": dt_b, "step_without_collective_s": dt_a, "tables_equal": fa == fb}
+                timing["gather_s"] = [float(sharding.timing["gather_s"])]
+            finally:
+                sharding.collective_at_world_one = False
         return elapsed, out, jobs, timing
     finally:
         triceratops_amd.set_sampling(prev)

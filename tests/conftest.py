@@ -18,7 +18,7 @@ def pytest_configure(config):
 _ORDER = [
     "test_gpu_kernels", "test_gpu_golden", "test_calc_probs_golden", "test_gpu_host_abi", "test_gpu_fused",
     "test_gpu_production_pin", "test_gpu_bounded", "test_gpu_batch", "test_gpu_star_chain", "test_toi465",
-    "test_toi1228", "test_target_ops", "test_sharding",
+    "test_toi1228", "test_target_ops", "test_sharding", "test_gpu_rccl_world1",
     "test_gpu_equivalence", "test_gpu_notebook_anchors",
     "test_bench_contract",
 ]

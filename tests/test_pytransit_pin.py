@@ -27,7 +27,7 @@ _spec.loader.exec_module(gen)
 
 def test_generator_uses_the_fuzz_rows_of_the_gpu_tests():
     pytest.importorskip("torch")
-    from tests.test_gpu_kernels import _raw_stress_rows
+    from test_gpu_kernels import _raw_stress_rows
     a = gen.raw_stress_rows(np.random.default_rng(7), 500)
     b = _raw_stress_rows(np.random.default_rng(7), 500)
     assert np.array_equal(a, b)

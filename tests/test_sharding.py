@@ -418,7 +418,22 @@ def _defer_worker(rank, world, port, q):
     pending = [tg.__dict__.get("_pending_finish") is not None for tg, _ in jobs]
     has_fpp = ["FPP" in tg.__dict__ for tg, _ in jobs]
     own = sorted(sharding.last_own_jobs)
-    q.put((rank, _tables(jobs), pending, has_fpp, own))
+    # a target whose table is still to be filled pickles and copies like any other (advisor, round 5: it used to hold the
+    # units' closures -- "Can't pickle local object" -- and views into the whole batch's table)
+    import copy
+    import pickle
+    portable = True
+    for k, (tg, _) in enumerate(jobs):
+        if pending[k]:
+            slim = tg.__dict__["_pending_finish"]
+            portable = portable and all(not callable(x) for u in slim[0] for x in u) and \
+                all(r is None or r.base is None for r in slim[1])
+            clone = pickle.loads(pickle.dumps(tg))
+            twin = copy.deepcopy(jobs[k][0])
+            portable = portable and clone.FPP == tg.FPP and twin.NFPP == tg.NFPP and \
+                np.array_equal(clone.lnZ, tg.lnZ, equal_nan=True)
+            break
+    q.put((rank, _tables(jobs), pending, has_fpp, own, portable))
     dist.barrier()
     dist.destroy_process_group()
     mp_.undo()
@@ -445,7 +460,8 @@ def test_tables_of_other_ranks_targets_are_filled_on_first_read(monkeypatch):
     owns = [set(g[4]) for g in got]
     # (the two larger targets are dearer than 3/4 of a rank's share and are dealt star by star: both ranks hold part of them)
     assert owns[0] | owns[1] == {0, 1, 2, 3} and all(len(o) < 4 for o in owns)
-    for r, (_, tables, pending, has_fpp, _own) in enumerate(got):
+    for r, (_, tables, pending, has_fpp, _own, portable) in enumerate(got):
+        assert portable
         assert pending == [j not in owns[r] for j in range(4)]
         assert has_fpp == [j in owns[r] for j in range(4)]
         for a, b in zip(got[0][1], tables):
@@ -460,3 +476,30 @@ def test_tables_of_other_ranks_targets_are_filled_on_first_read(monkeypatch):
         sharding.per_unit_seed = False
     for a, b in zip(got[0][1], _tables(jobs)):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_deferred_table_warns_where_it_is_deferred_not_where_it_is_read():
+    """the reference's RuntimeWarnings for degenerate evidences (triceratops.py:1466-1478) belong to the calc_probs call:
+    a table left to its first reader raises them when it is deferred, and reading it later raises nothing more"""
+    import warnings
+    from triceratops_amd.triceratops import target
+    tg = target.__new__(target)
+    from triceratops_amd.triceratops import _TARGET_CALLS
+    units = [(j0, names, snum, 42, None, key) for key, names, j0, snum in _TARGET_CALLS]
+    rec = [np.zeros((len(u[1]), len(sharding.RECORD_COLS))) for u in units]
+    for r in rec:
+        r[:, -1] = -np.inf
+    with pytest.warns(RuntimeWarning, match="All scenario log-evidences are -inf"):
+        tg._defer_finish(units, rec, 15)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert tg.FPP_degenerate is True and tg.FPP == 1.0
+    rec[1][0, -1] = np.nan
+    with pytest.warns(RuntimeWarning, match="Unexpected NaN"):
+        tg._defer_finish(units, rec, 15)
+    for r in rec:
+        r[:, -1] = -3.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tg._defer_finish(units, rec, 15)
+        assert tg.FPP_degenerate is False

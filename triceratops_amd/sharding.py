@@ -77,12 +77,19 @@ def _draw_base():
     return int(np.random.randint(0, 2 ** 31 - 1))
 
 
+# True: a process group of ONE rank takes the multi-rank path too -- schedule, per-unit seeds, the record table through
+# the group's all_gather_into_tensor (RCCL on the "nccl" backend: device tensors, header rows, padding) -- so that the
+# collective branch can be executed and timed on a single GPU (tests/test_gpu_rccl_world1.py; bench.py's `batch` object
+# reports its gather_s).  False (default): one rank has nothing to gather and skips it.
+collective_at_world_one = os.environ.get("TRX_COLLECTIVE_WORLD1", "0") == "1"
+
+
 def _dist():
     try:
         import torch.distributed as dist
     except Exception:  # pragma: no cover
         return None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or collective_at_world_one):
         return dist
     return None
 

@@ -241,11 +241,12 @@ class target:
         weight = float(N) * max(1, time.size)
         return [u[:6] + (weight, int(N), (job, u[6])) for u in units], n_scen
 
-    def _finish(self, units, results, n_scen):
+    def _finish(self, units, results, n_scen, warn=True):
         """Scenario table, normalised probabilities, FPP and NFPP from the per-unit results
         (triceratops.py:1430-1485).  Plain arrays here; the `.probs` DataFrame of the reference is put
         together when it is first read (a batch of 64 targets spent as long building 64 DataFrames nobody
-        had asked for yet as waiting for the GPU)."""
+        had asked for yet as waiting for the GPU).  warn = False: the caller has already raised the
+        reference's RuntimeWarnings for these evidences (_defer_finish)."""
         self.__dict__["_pending_finish"] = None
         targets = np.zeros(n_scen, dtype=np.dtype("i8"))
         star_num = np.zeros(n_scen, dtype=np.dtype("i8"))
@@ -280,21 +281,9 @@ class target:
                 best[c] = best[c] + rec_tab[:, i]         # (rows of dict-valued or dropped units stay as filled above)
 
         relative_probs, status = _normalize_probabilities(lnZ)
-        if status == 'anomaly':
-            warnings.warn(
-                "Unexpected NaN or +inf in scenario log-evidences. This indicates a numerical "
-                "anomaly unrelated to geometric exclusions. Inspect self.lnZ for diagnostics.",
-                RuntimeWarning, stacklevel=3)
-            self.FPP_degenerate = True
-        elif status == 'all_neginf':
-            warnings.warn(
-                "All scenario log-evidences are -inf: every MC draw was geometrically invalid. "
-                "FPP=1.0 reflects a failed computation, not a confident false positive. "
-                "Inspect self.lnZ for diagnostics.",
-                RuntimeWarning, stacklevel=3)
-            self.FPP_degenerate = True
-        else:
-            self.FPP_degenerate = False
+        if warn:
+            self._warn_status(status, stacklevel=4)
+        self.FPP_degenerate = status in ('anomaly', 'all_neginf')
 
         self._probs_columns = {
             "ID": targets, "scenario": scenarios, "M_s": best["M_s"], "R_s": best["R_s"],
@@ -313,26 +302,68 @@ class target:
         self.NFPP = np.sum(prob[15:]) if len(prob) > 15 else 0.0
         return
 
+    @staticmethod
+    def _warn_status(status, stacklevel):
+        """the reference's RuntimeWarnings for degenerate evidences (triceratops.py:1466-1478)"""
+        if status == 'anomaly':
+            warnings.warn(
+                "Unexpected NaN or +inf in scenario log-evidences. This indicates a numerical "
+                "anomaly unrelated to geometric exclusions. Inspect self.lnZ for diagnostics.",
+                RuntimeWarning, stacklevel=stacklevel)
+        elif status == 'all_neginf':
+            warnings.warn(
+                "All scenario log-evidences are -inf: every MC draw was geometrically invalid. "
+                "FPP=1.0 reflects a failed computation, not a confident false positive. "
+                "Inspect self.lnZ for diagnostics.",
+                RuntimeWarning, stacklevel=stacklevel)
+
     # what _finish sets: a target whose table is still to be filled (calc_probs_many on several ranks) has none of them
     _RESULTS = ("lnZ", "star_num", "u1", "u2", "fluxratio_EB", "fluxratio_comp", "FPP", "NFPP", "FPP_degenerate",
                 "_probs_columns", "_probs")
 
     def _defer_finish(self, units, results, n_scen):
-        """the table of this target is filled when one of its results is first read"""
+        """The table of this target is filled when one of its results is first read (calc_probs_many on several
+        ranks: the targets another rank evaluated).  What is kept is DATA only -- per unit (first row, names, star
+        number, ID) and a copy of its own records -- not the units' closures over light curves and star tables nor
+        views into the whole batch's gathered table: the target pickles and copies like any other (advisor, round 5;
+        __getstate__ fills the table first), and holds on to nothing of the batch.  The reference's RuntimeWarnings
+        for degenerate evidences are raised HERE, where calc_probs_many was called, not at some later read."""
         d = self.__dict__
         for name in self._RESULTS:
             d.pop(name, None)                # (results of an earlier calc_probs must not be read as this one's)
-        d["_pending_finish"] = (units, results, n_scen)
+        slim = [tuple(u[:4]) for u in units]
+        kept = [None if r is None else (np.array(r, copy=True) if isinstance(r, np.ndarray) else r) for r in results]
+        d["_pending_finish"] = (slim, kept, n_scen)
+        lnz = np.full(n_scen, 0.0)
+        for u, r in zip(slim, kept):
+            if r is None:
+                lnz[u[0]:u[0] + len(u[1])] = -np.inf
+            elif isinstance(r, np.ndarray):
+                lnz[u[0]:u[0] + len(u[1])] = r[:, -1]
+            else:
+                lnz[u[0]:u[0] + len(u[1])] = [x["lnZ"] for x in r]
+        if not np.all(np.isfinite(lnz)):      # (the common case costs one pass over ~20 numbers)
+            self._warn_status(_normalize_probabilities(lnz)[1], stacklevel=4)
+
+    def _finish_pending(self):
+        d = object.__getattribute__(self, "__dict__")
+        pend = d.get("_pending_finish")
+        if pend is not None:
+            d["_pending_finish"] = None
+            self._finish(*pend, warn=False)
 
     def __getattr__(self, name):
         # (only reached when normal lookup fails)
         d = object.__getattribute__(self, "__dict__")
-        pend = d.get("_pending_finish")
-        if pend is not None and name in type(self)._RESULTS:
-            d["_pending_finish"] = None
-            self._finish(*pend)
+        if d.get("_pending_finish") is not None and name in type(self)._RESULTS:
+            self._finish_pending()
             return object.__getattribute__(self, name)
         raise AttributeError("'%s' object has no attribute '%s'" % (type(self).__name__, name))
+
+    def __getstate__(self):
+        # (pickle, copy.copy and copy.deepcopy all come through here: a table still to be filled is filled first)
+        self._finish_pending()
+        return self.__dict__
 
     @property
     def probs(self):
