@@ -281,22 +281,18 @@ def _max_over_ranks(ctx, elapsed):
     return elapsed
 
 
-def census(rows_of, fams, t_d, n_sample=512):
+def census(rows_of, fams, t_d, n_sample=512, plan_flags=0):
     """per-cell statistics of the model kernel on a sample of every family's rows: the number of
-    model evaluations the kernel plans (debug knob of trx_flux_grid) and the occulted fraction"""
+    model evaluations the kernel spends (TRX_FLAG_COUNT_EVALUATIONS of trx_flux_grid) and the occulted fraction;
+    plan_flags: the result-neutral flags of the launches being priced (TRX_FLAG_ALL_SUBEXPOSURES / _NO_STENCIL)"""
     from triceratops_amd import _lib, synth
-    L_ = _lib.lib()
     evals, p_in = [], []
     for i, fam in enumerate(fams):
         blk = rows_of(i)[:, :n_sample].contiguous()
-        g, _ = _lib.flux_grid(fam[1], 0, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
+        g, _ = _lib.flux_grid(fam[1], plan_flags, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
         p_in.append(float((g < 1.0).double().mean()))
-        L_.trx_set_debug_node_counts(1)
-        try:
-            c, _ = _lib.flux_grid(fam[1], 0, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
-            evals.append(float(c.mean()))
-        finally:
-            L_.trx_set_debug_node_counts(0)
+        c, _ = _lib.flux_grid(fam[1], plan_flags | _lib.FLAG_COUNT_EVALUATIONS, t_d, blk, synth.EXPTIME, synth.NSAMPLES, False)
+        evals.append(float(c.mean()))
     return float(np.mean(evals)), float(np.mean(p_in))
 
 
@@ -394,8 +390,8 @@ def run_grid(ctx):
     # process-wide default -- skip them -- stays in force for the e2e leg below)
     EVAL_ALL = _lib.FLAG_EVALUATE_EXCLUDED
     args, world, rank, device = ctx["args"], ctx["world"], ctx["rank"], ctx["device"]
-    if args.all_subexposures:
-        _lib.lib().trx_set_supersample_tiers(0)
+    # result-neutral choices are per-call flags (include/trx.h): the production library has no switches
+    PLAN = _lib.FLAG_ALL_SUBEXPOSURES if args.all_subexposures else 0
 
     def gather(dst, src):
         if ctx["debug_one"]:                      # gloo moves host tensors
@@ -428,10 +424,10 @@ def run_grid(ctx):
 
     ev = [events() for _ in range(args.steps)]
 
-    def step(evs=None, collective=True):
+    def step(evs=None, collective=True, plan=PLAN):
         lnz = []
         for i, (name, model, is_host, has_comp) in enumerate(fams):
-            flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0) | EVAL_ALL
+            flags = (_lib.FLAG_COMPANION_IS_HOST if is_host else 0) | (_lib.FLAG_FP32_MODEL if args.fp32_model else 0) | EVAL_ALL | plan
             if evs is not None:
                 evs[i][0].record()
             _lib.lnl_batch(model, flags, t_d, f_d, synth.SIGMA, rows_d[i], synth.EXPTIME,
@@ -484,7 +480,7 @@ def run_grid(ctx):
     kernels = {}
     shapes = None
     if ctx["extras"]:
-        evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d)
+        evals_per_cell, p_in = census(lambda i: rows_d[i], fams, t_d, plan_flags=PLAN)
         flop_exec = evals_per_cell * (F_ORBIT + F_MA)
         achieved = flop_exec * cells_per_launch / mean_launch_s / 1e12
         plain_flop = synth.NSAMPLES * (F_ORBIT + p_in * F_MA)
@@ -497,31 +493,22 @@ def run_grid(ctx):
                      "plain_algorithm_equivalent_frac": plain_tf / FP64_VALU_PEAK_TF})
         # the same workload with every sub-exposure evaluated, timed here (one pass over the 18 families)
         if not args.all_subexposures and not args.fp32_model:
-            L_ = _lib.lib()
-            L_.trx_set_supersample_tiers(0)
-            try:
-                step(collective=False)          # rank 0 only from here on: no collective
-                torch.cuda.synchronize(device)
-                e2 = events()
-                step(e2, collective=False)
-                torch.cuda.synchronize(device)
-            finally:
-                L_.trx_set_supersample_tiers(1)
+            step(collective=False, plan=_lib.FLAG_ALL_SUBEXPOSURES)          # rank 0 only from here on: no collective
+            torch.cuda.synchronize(device)
+            e2 = events()
+            step(e2, collective=False, plan=_lib.FLAG_ALL_SUBEXPOSURES)
+            torch.cuda.synchronize(device)
             ms_all = float(np.mean([a.elapsed_time(b) for (a, b) in e2]))
             tf_all = plain_flop * cells_per_launch / (ms_all * 1e-3) / 1e12
             roof["all_subexposures"] = {"mean_launch_ms": ms_all, "tflops": tf_all, "frac": tf_all / FP64_VALU_PEAK_TF,
                                         "evals_per_s": cells_per_launch / (ms_all * 1e-3)}
             # ... and with the centre-value stencil off (Gauss nodes in every cell): its own census and time
-            L_.trx_set_stencil(0)
-            try:
-                ev_g, _ = census(lambda i: rows_d[i], fams, t_d)
-                step(collective=False)
-                torch.cuda.synchronize(device)
-                e3 = events()
-                step(e3, collective=False)
-                torch.cuda.synchronize(device)
-            finally:
-                L_.trx_set_stencil(1)
+            ev_g, _ = census(lambda i: rows_d[i], fams, t_d, plan_flags=_lib.FLAG_NO_STENCIL)
+            step(collective=False, plan=_lib.FLAG_NO_STENCIL)
+            torch.cuda.synchronize(device)
+            e3 = events()
+            step(e3, collective=False, plan=_lib.FLAG_NO_STENCIL)
+            torch.cuda.synchronize(device)
             ms_g = float(np.mean([a.elapsed_time(b) for (a, b) in e3]))
             tf_g = ev_g * (F_ORBIT + F_MA) * cells_per_launch / (ms_g * 1e-3) / 1e12
             roof["gauss_nodes_only"] = {"mean_launch_ms": ms_g, "model_evaluations_per_cell": ev_g, "tflops": tf_g,
@@ -778,16 +765,12 @@ def run_batch(ctx):
     kern_s = sum(a.elapsed_time(b) for (_, _, _, _, a, b, _) in trace) * 1e-3
     cells_rank0 = float(sum(n * nt for (_, _, n, nt, _, _, _) in trace))
     # census on the traced samples (first launches of this rank)
-    L_ = _lib.lib()
     ev_cells, tot = 0.0, 0.0
     for (model, flags, n, nt, _, _, blk) in trace:
         if blk is None or blk.shape[1] == 0:
             continue
-        L_.trx_set_debug_node_counts(1)
-        try:
-            c, _ = _lib.flux_grid(model, flags & 3, jobs_time(jobs, device), blk.contiguous(), 0.00139, 20, False)
-        finally:
-            L_.trx_set_debug_node_counts(0)
+        c, _ = _lib.flux_grid(model, (flags & 3) | _lib.FLAG_COUNT_EVALUATIONS, jobs_time(jobs, device), blk.contiguous(),
+                              0.00139, 20, False)
         ev_cells += float(c.sum())
         tot += float(c.numel())
     evals_per_cell = ev_cells / max(tot, 1.0)

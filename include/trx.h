@@ -23,12 +23,17 @@
  *     trx_release_scratch() frees it all.  Two host threads that enqueue on ONE stream take turns (a
  *     per-stream lock is held while a call enqueues its kernels; the stream's order does the rest).
  *     trx_lnl_batch, trx_flux_grid, trx_lnz_scenario and the reductions can be captured
- *     into a hipGraph (while `stream` is capturing, the scratch is a pair of graph memory nodes).
- *     The library's only other state is the stencil memo described under Diagnostics and
- *     (i) a mutex-guarded cache of the per-`nsupersample` node table (filled on first use,
- *     read-only afterwards) and (ii) the process-wide tuning / diagnostics switches declared
- *     at the end of this header (atomics read once per enqueue; meant for benchmarks and
- *     tests -- do not flip them while other threads are launching);
+ *     into a hipGraph: while `stream` is capturing, a model call takes a scratch buffer of its own that the
+ *     captured graph OWNS (a hipUserObject: it returns to the library's pool when the graph and its executable
+ *     graphs are destroyed; rounds 2-5 used graph memory nodes, which intermittently handed a replay zeroed
+ *     pages on this stack -- DESIGN.md 4.8).  Inputs must be resident before the capture begins.
+ *     NO process-wide mutable state: the library's behaviour is a function of a call's arguments.  What it
+ *     keeps besides the scratch are caches whose content cannot change a result -- a mutex-guarded table of the
+ *     Gauss nodes per `nsupersample` (filled on first use, read-only afterwards), its device copy, and a
+ *     per-light-curve hint whether the centre-value stencil applied (it only saves an empty launch) -- and the
+ *     two monotonic row counters of trx_skipped_rows / trx_pruned_rows (statistics).  The tuning and
+ *     diagnostics switches that rounds 1-5 exported from this library (trx_set_*) live in include/trx_debug.h
+ *     and exist only in the TESTING build, libtrx_testing.so (-DTRX_TESTING); per-call choices are TRX_FLAG_* bits;
  *   - return value: 0 = ok, TRX_ERR_* otherwise (never throws); trx_last_error()
  *     gives a thread-local message for the last non-zero return on this thread;
  *   - numerical exclusions travel in-band exactly as in the reference:
@@ -63,8 +68,32 @@ extern "C" {
                                         log-mean-exp accumulation; ~1e-7 absolute in flux */
 
 #define TRX_FLAG_EVALUATE_EXCLUDED   8 /* trx_lnl_batch / trx_lnz_scenario: evaluate the light curve of a draw that
-                                        lnL_EB_p's secondary-eclipse rule excludes anyway (+inf either way): per-call
-                                        form of trx_set_skip_excluded(0), for benchmarks that count every row */
+                                        lnL_EB_p's secondary-eclipse rule excludes anyway (+inf either way): for
+                                        benchmarks that count every row.  Default: such a row (half of the EB draws
+                                        of a typical run, likelihoods.py:535-538) is not evaluated at all;
+                                        trx_skipped_rows counts them */
+/* Result-neutral per-call choices (same numbers to rounding; for benchmarks and cross-checks): */
+#define TRX_FLAG_ALL_SUBEXPOSURES   16 /* every cell evaluates all `nsupersample` sub-exposures, the reference's literal
+                                        algorithm, instead of the 3-9 point Gauss rule of the same discrete measure
+                                        where the model is analytic over the exposure (agree to ~1e-13 in flux) */
+#define TRX_FLAG_NO_STENCIL         32 /* no centre-value stencil: on a uniform time grid of <= 0.3 exposures per cell
+                                        (light curves of 320 points and more) a cell far from every limb contact
+                                        otherwise takes its exposure average from the instantaneous flux at the
+                                        centres of its 13 nearest cells (one evaluation per cell, error bound 1e-15)
+                                        instead of 3-4 Gauss nodes (agree to ~2e-14 in flux) */
+#define TRX_FLAG_COUNT_EVALUATIONS  64 /* trx_flux_grid: out_flux receives the NUMBER of model evaluations each cell
+                                        cost instead of its flux (the census behind bench.py's roofline line) */
+#define TRX_FLAG_FULL_EVALUATION   128 /* trx_scenario_* / trx_star_enqueue: every masked draw is evaluated to the end.
+                                        Default: bounded evaluation -- a draw is abandoned once it is shown that it
+                                        can neither be the best draw (its chi^2 exceeds the smallest finished one) nor
+                                        carry weight in the evidence (its log-weight lies 90 below the largest
+                                        finished one; the reduction drops everything 80 below the largest): from its
+                                        constants alone when the model can never be as deep as the data, else from its
+                                        chi^2 over ~16 probe cells and every cell outside its transit window.  lnZ
+                                        agrees to rounding, the best draw is the same, results repeat bit for bit;
+                                        light curves of fewer than 48 points are always evaluated in full;
+                                        trx_pruned_rows counts the abandoned draws.  The per-row entry points
+                                        (trx_lnl_batch, trx_lnz_scenario ...) always return the full chi^2. */
 
 /* parameter-block rows, SoA [n_param][n] contiguous fp64 (reference argument order):
  *   TP  (10): R_p[R_earth] P_orb[d] inc[deg] a[cm] R_s[R_sun] u1 u2 ecc argp[deg] companion_fluxratio
@@ -152,78 +181,12 @@ int trx_flux_grid_host(int model, int flags,
                        double* out_flux, double* out_secdepth);
 int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out);
 
-/* Tuning knob for benchmarks/tests (process-wide, like the diagnostics below): rows staged per
- * wavefront of the batched variant (light curves below trx_set_cell_packing_below's threshold), 1..22;
- * 0 = automatic. */
-int trx_set_rows_per_wave(int rows);
-/* (tests; host only, touches no device) checks the plan by which the batched likelihood kernel deals `rows` rows to its
- * waves at `rows_per_wave` rows each -- tapered towards the end of the launch when `taper` is set -- : every row in
- * exactly one batch.  *positions: wave positions per XCD; *rows_min: the smallest batch. */
-int trx_debug_batch_plan(long rows, int rows_per_wave, int taper, long* positions, int* rows_min);
-
-/* Diagnostics (process-wide switches, default 1 / 1 / 1 / 1 / 0; no reference counterpart):
- *  - trx_set_supersample_tiers(0): every cell evaluates all nsupersample sub-exposures instead of
- *    taking the exposure average from the 3-9 point Gauss rule of the same measure where the
- *    model is analytic (the two agree to ~1e-13 in flux);
- *  - trx_set_stencil(0): no centre-value stencil -- on a uniform time grid of 1/7 .. 0.3 exposures per
- *    cell (stamps within 4 ulp of t0 + j dt, light curves of 320 points and more) a cell far from
- *    every limb contact takes its exposure average from the instantaneous flux at the centres of its
- *    13 nearest cells (one model evaluation per cell; error bound 1e-15, trx_kernels.hip) instead of
- *    3-4 Gauss nodes; the two agree to ~2e-14 in flux.  Whether a launch qualifies is decided on the
- *    device; the library keeps the verdict per light curve (time pointer, length, exposure) in a small
- *    pinned memo so that later launches enqueue one kernel instead of two (a hint only);
- *  - trx_set_skip_excluded(0): lnL_EB_p gives +inf to a draw whose secondary eclipse is deeper than
- *    1.5 sigma whatever its light curve (likelihoods.py:535-538); by default trx_lnl_batch /
- *    trx_lnz_scenario / trx_scenario_evidence do not evaluate the light curve of such a row (half of the
- *    EB draws of a typical run).  0 = evaluate it all the same (benchmarks that count every row).
- *    trx_skipped_rows(&n, reset) reads (and clears) the number of rows skipped on the current device
- *    (it synchronises the device);
- *  - trx_set_kepler_stepping(0): full Kepler solve at every node instead of Newton steps from the
- *    exposure centre's solution;
- *  - trx_set_debug_node_counts(1): trx_flux_grid writes the number of model evaluations planned
- *    for each cell instead of the flux. */
-/*  - trx_set_bounded_evaluation(mode): 0 = trx_scenario_evidence / trx_scenario_enqueue evaluate every masked
- *    draw to the end; 1 = bounded evaluation for light curves of trx_set_cell_packing_below's threshold and more
- *    (one row per wave), 2 (default since round 4) = for every light curve.  Bounded: a draw is abandoned once it is
- *    shown that it can neither be the best draw (its chi^2 exceeds the smallest finished chi^2) nor carry weight in
- *    the evidence (its log-weight lies 90 below the largest finished one; the reduction drops everything 80 below
- *    the largest) -- from its constants alone when the model can never be as deep as the data (a lower bound of
- *    chi^2 that depends on the light curve and the model's largest possible flux deficit only), else from its
- *    chi^2 over ~16 probe cells and every cell outside its transit window.  Short light curves (batches of rows per
- *    wave) take it in passes: the first 2048 rows to the end (they seed the bounds and decide whether probing pays:
- *    it does when >= 90 % of them lie 150 above the best), a probe pass over the rest, and the rows it leaves alive
- *    -- compacted across workgroups -- to the end.  lnZ agrees to rounding, the best draw is the same, results
- *    repeat bit for bit from run to run.  Light curves of fewer than 48 points are always evaluated in full.
- *    trx_pruned_rows(&n, reset) counts the abandoned rows (it synchronises the device).  The per-row entry points
- *    (trx_lnl_batch, trx_lnz_scenario, ...) always return the full chi^2. */
-int trx_set_bounded_evaluation(int mode);
-/*    trx_set_debug_bounded_lnl(1) (tests): trx_lnl_batch / trx_lnz_scenario treat their rows the same way, as
- *    for an evidence without prior: a row then holds its chi^2/2 or, if abandoned, a lower bound of it that
- *    exceeds the smallest chi^2/2 of the call by more than 90. */
-int trx_set_debug_bounded_lnl(int on);
-/*    trx_set_debug_poison(1) (tests): trx_scenario_enqueue / trx_star_enqueue fill the chi^2 arrays of a call with zeros
- *    before its likelihood kernels run, so that a row no kernel writes shows as a perfect fit (lnZ and the best draw
- *    jump) instead of as whatever the previous call on the stream left there. */
-int trx_set_debug_poison(int on);
-/*    trx_set_debug_bug(1) (tests): re-enables a bug of round 4 (the third pass of the bounded evaluation skipped its last
- *    batches when nothing was probed), so that a test can show the "never written" status of the record catching it. */
-int trx_set_debug_bug(int on);
-/*    trx_set_probe_rows(n) (tests, A/B runs; TRX_PROBE_ROWS in the environment): rows per wave of the probe pass of the
- *    bounded evaluation of batched light curves: 0 = as many as its LDS layout holds (default), 1 = as many as the other
- *    passes take, n > 1 = n (at most 22).  Results do not depend on it. */
-int trx_set_probe_rows(int rows);
-int trx_pruned_rows(unsigned long long* out, int reset);
-int trx_set_supersample_tiers(int on);
-int trx_set_stencil(int on);
-int trx_set_skip_excluded(int on);
+/* Statistics (monotonic device counters, current device; reading synchronises the device; reset != 0 clears the one
+ * read): rows of likelihood calls that were not evaluated because lnL_EB_p's secondary-eclipse rule excludes them
+ * anyway (see TRX_FLAG_EVALUATE_EXCLUDED), and draws the bounded evaluation abandoned (see TRX_FLAG_FULL_EVALUATION).
+ * They cannot change a result. */
 int trx_skipped_rows(unsigned long long* out, int reset);
-int trx_set_kepler_stepping(int on);
-int trx_set_debug_node_counts(int on);
-/*  - trx_set_cell_packing_below(n): light curves with fewer than n points (default 320) are
- *    processed in batches of rows per wave (the (row, time) cells of ~640 cells' worth of rows walked
- *    64 at a time across row boundaries, light curve staged in LDS), longer ones one row per wave;
- *    0 = never.  Model values agree to rounding between the two; chi^2 differs by summation order. */
-int trx_set_cell_packing_below(int n_time);
+int trx_pruned_rows(unsigned long long* out, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * The per-draw half of one scenario evidence as ONE kernel (no reference counterpart as a single
@@ -381,9 +344,7 @@ int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, double* const*
  * exptime, nsupersample and the precision flag are enqueued as one LAUNCH CHAIN: every kernel of the path once, with
  * the call / branch as a further grid dimension (up to 16 calls or 24 branches per chain; ~11 launches instead of
  * 9-17 per call).  Same records, bit for bit.  The calls of a chain run side by side: `out` of all of them is valid
- * once the stream has passed the call.  trx_set_star_chain(0) enqueues call by call as before (tests, A/B runs;
- * TRX_STAR_CHAIN=0 in the environment sets the initial value). */
-int trx_set_star_chain(int on);
+ * once the stream has passed the call.  (The testing library can switch chains off: trx_debug.h.) */
 
 /* Frees the per-stream scratch described above (every device); all streams must be idle. */
 int trx_release_scratch(void);

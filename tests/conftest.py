@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "testing_library: the test drives switches of include/trx_debug.h, which only "
+                                       "libtrx_testing.so exports (set automatically: see pytest_collection_modifyitems)")
 
 
 # Under `pytest -x` a failure hides everything collected after it, so the files run in the order of the evidence
@@ -32,6 +34,38 @@ def pytest_collection_modifyitems(session, config, items):
         return rank.get(stem, 0)
 
     items.sort(key=key)          # stable: the order inside a file is untouched
+    # A test that names a switch or probe of include/trx_debug.h (trx_set_*, trx_debug_*) -- itself or through a helper of
+    # its module -- runs on the TESTING library; every other test runs on the production library, libtrx.so, which
+    # exports none of them (tests/test_abi.py).  The parity tests proper are of the second kind.
+    import inspect
+    import re
+    pat = re.compile(r"trx_set_|trx_debug_")
+    helpers = {}
+    for item in items:
+        fn = getattr(item, "function", None)
+        if fn is None:
+            continue
+        mod = item.module
+        if mod not in helpers:
+            helpers[mod] = [n for n, f in vars(mod).items()
+                            if inspect.isfunction(f) and f.__module__ == mod.__name__ and not n.startswith("test_")
+                            and pat.search(inspect.getsource(f))]
+        src = inspect.getsource(fn)
+        if pat.search(src) or any(re.search(r"\b%s\(" % h, src) for h in helpers[mod]):
+            item.add_marker(pytest.mark.testing_library)
+
+
+@pytest.fixture(autouse=True)
+def _library_of_the_test(request):
+    if request.node.get_closest_marker("testing_library") is None:
+        yield
+        return
+    from triceratops_amd import _lib
+    _lib.use_testing_library(True)
+    try:
+        yield
+    finally:
+        _lib.use_testing_library(False)
 
 
 @pytest.fixture(scope="session", autouse=True)

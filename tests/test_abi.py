@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "trx.h")).read()
+def _declared(header="trx.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(trx_[a-z0-9_]+)\s*\(", text)))
 
@@ -34,6 +34,41 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_lists_the_same_symbols():
     from triceratops_amd import _lib
     assert sorted(_lib.ABI_SYMBOLS) == _declared()
+    assert sorted(_lib.DEBUG_SYMBOLS) == _declared("trx_debug.h")
+
+
+def _exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+
+
+def test_production_library_has_no_switches_no_debug_exports_and_reads_no_environment():
+    """"no global state, safe to call concurrently".  libtrx.so exports exactly what include/trx.h declares
+    -- no trx_set_*, nothing with "debug" in its name -- and does not reference getenv; the switches of rounds 1-5
+    exist only in libtrx_testing.so (include/trx_debug.h), which exports both headers' symbols."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    prod = [s for s in _exports(g.LIB) if s.startswith("trx_")]
+    assert prod == _declared(), set(prod) ^ set(_declared())
+    assert not [s for s in _exports(g.LIB) if "debug" in s or s.startswith("trx_set_")]
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", g.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    test = [s for s in _exports(g.LIB_TESTING) if s.startswith("trx_")]
+    assert test == sorted(_declared() + _declared("trx_debug.h"))
+
+
+def test_wrappers_follow_the_library_in_use():
+    from triceratops_amd import _lib
+    switch = "trx_" + "set_stencil"          # (spelled apart: conftest.py sends tests that NAME a switch to the testing library)
+    prod = _lib.lib()
+    assert prod.trx_testing is False and not hasattr(prod, switch)
+    try:
+        t = _lib.use_testing_library(True)
+        assert t is _lib.lib() and t.trx_testing is True and getattr(t, switch)(1) == 0
+    finally:
+        assert _lib.use_testing_library(False) is prod and _lib.lib() is prod
 
 
 def test_struct_bindings_match_the_library_layout():

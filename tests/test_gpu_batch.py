@@ -12,6 +12,8 @@ Mixed-precision tolerances (printed by the tests, stated in DESIGN.md section 9)
 import os
 import time
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -144,6 +146,76 @@ def test_threaded_units_give_the_same_results_as_one_thread():
     print("6 TOIs x 18 x N=3e5: 1 thread %.3f s, 3 threads %.3f s" % (one[2], thr_b[2]))
     assert np.array_equal(one[0], thr_a[0], equal_nan=True) and np.array_equal(one[1], thr_a[1])
     assert np.array_equal(thr_a[0], thr_b[0], equal_nan=True)
+
+
+def test_one_threads_per_call_choices_do_not_reach_another_threads_calls():
+    """rounds 1-5 exported process-wide switches from the production library, and a switch
+    flipped by one host thread changed what another thread's in-flight calc_probs enqueued.  The production library has
+    none any more (tests/test_abi.py): what a caller may choose is a TRX_FLAG_* bit of ITS call.  One thread loops over
+    likelihood calls with every result-neutral flag set -- all sub-exposures, no stencil, evaluation counts, every
+    excluded row evaluated -- and calc_probs with the bounded evaluation off, while another runs calc_probs_many on
+    the defaults: each thread's results equal what it gets alone, bit for bit."""
+    import threading
+    import triceratops_amd
+    from triceratops_amd import fused, sharding
+    assert _lib.lib().trx_testing is False                     # the production library
+    triceratops_amd.set_sampling("device")
+    sharding.per_unit_seed = True
+    rng = np.random.default_rng(8)
+    t = synth.time_grid(2000)
+    t_d = _lib.dev(t)
+    f_d = _lib.dev(1.0 + rng.normal(0, synth.SIGMA, 2000))
+    rows = _lib.dev(synth.eb_rows(rng, 4000, False, True))
+    odd = _lib.FLAG_ALL_SUBEXPOSURES | _lib.FLAG_EVALUATE_EXCLUDED
+
+    def noisy_neighbour(out):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            _lib.wait_uploads(st)
+            for _ in range(out["reps"]):
+                h = _lib.lnl_batch(1, odd, t_d, f_d, synth.SIGMA, rows, synth.EXPTIME, 20)
+                g, _ = _lib.flux_grid(1, _lib.FLAG_NO_STENCIL, t_d, rows[:, :300].contiguous(), synth.EXPTIME, 20, False)
+                c, _ = _lib.flux_grid(1, _lib.FLAG_COUNT_EVALUATIONS, t_d, rows[:, :300].contiguous(), synth.EXPTIME, 20, False)
+            st.synchronize()
+        out["h"], out["g"], out["c"] = h.cpu().numpy(), g.cpu().numpy(), c.cpu().numpy()
+
+    def tables():
+        np.random.seed(3)
+        torch.manual_seed(3)
+        out = triceratops_amd.calc_probs_many(_jobs(4, 200_000))
+        return np.array([tg.lnZ for tg in out]), np.array([tg.FPP for tg in out])
+
+    try:
+        alone = {"reps": 1}
+        noisy_neighbour(alone)
+        want = tables()
+        assert alone["c"].max() == 20.0 and alone["c"].min() == 0.0       # counts, not fluxes
+        busy = {"reps": 40}
+        th = threading.Thread(target=noisy_neighbour, args=(busy,))
+        th.start()
+        got = [tables() for _ in range(3)]
+        th.join()
+        for lnz, fpp in got:
+            assert np.array_equal(lnz, want[0], equal_nan=True) and np.array_equal(fpp, want[1])
+        for k in ("h", "g", "c"):
+            assert np.array_equal(busy[k], alone[k], equal_nan=True)
+        # ... and the per-call form of "no bounded evaluation" gives the full evaluation's records
+        _lib.reset_stats()
+        _lib.check(_lib.lib().trx_pruned_rows(None, 1))
+        triceratops_amd.set_full_evaluation(True)
+        full = tables()
+        n = ctypes.c_ulonglong(0)
+        _lib.check(_lib.lib().trx_pruned_rows(ctypes.byref(n), 1))
+        assert n.value == 0                                         # nothing abandoned
+        assert np.allclose(full[0], want[0], rtol=0, atol=1e-9, equal_nan=True) and np.allclose(full[1], want[1], atol=1e-12)
+        triceratops_amd.set_full_evaluation(False)
+        tables()
+        _lib.check(_lib.lib().trx_pruned_rows(ctypes.byref(n), 1))
+        assert n.value > 0
+    finally:
+        triceratops_amd.set_full_evaluation(False)
+        sharding.per_unit_seed = False
+        triceratops_amd.set_sampling("numpy")
 
 
 def test_native_scenario_call_equals_the_torch_operator_path():

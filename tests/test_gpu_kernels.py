@@ -66,6 +66,34 @@ def test_launch_knobs_do_not_change_results(stepping, tiers, rows_per_wave):
     _cmp_h(got, want)
 
 
+def test_per_call_flags_equal_the_process_wide_switches_of_the_testing_library():
+    """TRX_FLAG_ALL_SUBEXPOSURES / _NO_STENCIL / _COUNT_EVALUATIONS (include/trx.h) against trx_set_supersample_tiers(0) /
+    trx_set_stencil(0) / trx_set_debug_node_counts(1) (include/trx_debug.h): the same launches, bit for bit"""
+    rng, t, flux = _lc(2000)
+    t_d, f_d = _lib.dev(t), _lib.dev(flux)
+    rows = _lib.dev(synth.tp_rows(rng, 1500, True))
+    L = _lib.lib()
+    pairs = ((_lib.FLAG_ALL_SUBEXPOSURES, lambda on: L.trx_set_supersample_tiers(0 if on else 1)),
+             (_lib.FLAG_NO_STENCIL, lambda on: L.trx_set_stencil(0 if on else 1)))
+    ref = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows, synth.EXPTIME, 20).cpu().numpy()
+    for flag, switch in pairs:
+        by_flag = _lib.lnl_batch(0, flag, t_d, f_d, synth.SIGMA, rows, synth.EXPTIME, 20).cpu().numpy()
+        try:
+            switch(True)
+            by_switch = _lib.lnl_batch(0, 0, t_d, f_d, synth.SIGMA, rows, synth.EXPTIME, 20).cpu().numpy()
+        finally:
+            switch(False)
+        assert np.array_equal(by_flag, by_switch) and not np.array_equal(by_flag, ref)
+        assert np.max(np.abs(by_flag - ref) / ref) < 1e-9
+    c_flag, _ = _lib.flux_grid(0, _lib.FLAG_COUNT_EVALUATIONS, t_d, rows[:, :200].contiguous(), synth.EXPTIME, 20, False)
+    try:
+        L.trx_set_debug_node_counts(1)
+        c_switch, _ = _lib.flux_grid(0, 0, t_d, rows[:, :200].contiguous(), synth.EXPTIME, 20, False)
+    finally:
+        L.trx_set_debug_node_counts(0)
+    assert bool((c_flag == c_switch).all()) and float(c_flag.max()) == 20.0
+
+
 def _raw_stress_rows(rng, n):
     """pytransit-shaped rows far outside the bench's ranges: deep and grazing geometries, k up to
     1.5, e up to 0.95, periods from 0.3 to 100 d, orbits down to 1.5 stellar radii"""

@@ -67,6 +67,13 @@ def set_precision(mode):
     _lib.set_precision(mode)
 
 
+def set_full_evaluation(on):
+    """True: every masked draw of every scenario is evaluated to the end (TRX_FLAG_FULL_EVALUATION) instead of the
+    bounded evaluation; same results to rounding, several times slower on a real detection"""
+    from . import _lib
+    _lib.set_full_evaluation(bool(on))
+
+
 def set_threads(n):
     """Host threads (each with its own HIP stream) that evaluate the scenarios of calc_probs /
     calc_probs_many side by side; effective with set_sampling("device") only (the numpy modes consume one

@@ -12,20 +12,33 @@ import numpy as np
 import torch  # noqa: F401  (imported first so libtrx binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TRX_LIB") or os.path.join(_HERE, "libtrx.so")   # TRX_LIB: A/B builds
+# The production library: no switches, no environment variables, no debug exports (include/trx.h).  TRX_LIB: A/B builds.
+LIB_PATH = os.environ.get("TRX_LIB") or os.path.join(_HERE, "libtrx.so")
+# The testing library (the same sources with -DTRX_TESTING): + include/trx_debug.h.  tests/ and profiles/ switch to it
+# with use_testing_library() (or TRX_TESTING=1 in the environment, for old scripts); the product never does.
+TESTING_LIB_PATH = os.environ.get("TRX_TESTING_LIB") or os.path.join(_HERE, "libtrx_testing.so")
 
 MODEL_TP, MODEL_EB, MODEL_EB_TWIN, MODEL_RAW = 0, 1, 2, 3
 FLAG_COMPANION_IS_HOST, FLAG_SCALAR_K, FLAG_FP32_MODEL, FLAG_EVALUATE_EXCLUDED = 1, 2, 4, 8
+# result-neutral per-call choices (include/trx.h)
+FLAG_ALL_SUBEXPOSURES, FLAG_NO_STENCIL, FLAG_COUNT_EVALUATIONS, FLAG_FULL_EVALUATION = 16, 32, 64, 128
 N_PARAM = {MODEL_TP: 10, MODEL_EB: 11, MODEL_EB_TWIN: 11, MODEL_RAW: 9}
 ERR_NTOTAL = 4
 
-# every symbol include/trx.h declares (tests check the library exports all of them)
+# every symbol include/trx.h declares (tests check that libtrx.so exports all of them and nothing of trx_debug.h)
 ABI_SYMBOLS = (
     "trx_lnl_batch", "trx_flux_grid", "trx_chi2_grid", "trx_workspace_bytes",
     "trx_log_mean_exp", "trx_lnz_scenario", "trx_lnz_from_halfchi2", "trx_lnl_batch_host", "trx_flux_grid_host",
-    "trx_log_mean_exp_host", "trx_set_rows_per_wave", "trx_debug_batch_plan", "trx_set_supersample_tiers", "trx_set_stencil", "trx_set_skip_excluded", "trx_skipped_rows",
-    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_set_debug_poison", "trx_set_debug_bug", "trx_set_probe_rows", "trx_set_star_chain", "trx_pruned_rows", "trx_set_kepler_stepping", "trx_set_debug_node_counts", "trx_set_cell_packing_below", "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_star_enqueue", "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error",
-    "trx_device_count",
+    "trx_log_mean_exp_host", "trx_skipped_rows", "trx_pruned_rows",
+    "trx_draw_scenario", "trx_draw_args_size", "trx_scenario_evidence", "trx_scenario_enqueue", "trx_star_enqueue",
+    "trx_scenario_args_size", "trx_release_scratch", "trx_version", "trx_last_error", "trx_device_count",
+)
+# ... and include/trx_debug.h: the testing library only
+DEBUG_SYMBOLS = (
+    "trx_set_rows_per_wave", "trx_set_cell_packing_below", "trx_debug_batch_plan", "trx_set_supersample_tiers",
+    "trx_set_stencil", "trx_set_skip_excluded", "trx_set_debug_node_counts", "trx_set_kepler_stepping",
+    "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_set_debug_poison", "trx_set_debug_bug",
+    "trx_set_probe_rows", "trx_set_star_chain", "trx_debug_capture_buffers",
 )
 
 
@@ -68,23 +81,63 @@ def set_precision(mode):
     global EXTRA_FLAGS
     if mode not in ("fp64", "fp32"):
         raise ValueError("precision must be 'fp64' or 'fp32'")
-    EXTRA_FLAGS = FLAG_FP32_MODEL if mode == "fp32" else 0
+    EXTRA_FLAGS = (EXTRA_FLAGS & ~FLAG_FP32_MODEL) | (FLAG_FP32_MODEL if mode == "fp32" else 0)
+
+
+def set_full_evaluation(on):
+    """True: every lnZ_* / calc_probs call evaluates every masked draw to the end (TRX_FLAG_FULL_EVALUATION on every
+    scenario call) instead of the bounded evaluation; same lnZ to rounding, same best draws, slower"""
+    global EXTRA_FLAGS
+    EXTRA_FLAGS = (EXTRA_FLAGS | FLAG_FULL_EVALUATION) if on else (EXTRA_FLAGS & ~FLAG_FULL_EVALUATION)
 
 
 _vp = ctypes.c_void_p
-_lib = None
+_lib = None                 # the library in use
+_production = None
+_testing = None
 
 
 def lib():
-    """Load libtrx.so (once).  Raises TrxError if the HIP extension was not built."""
-    global _lib
+    """The library in use: libtrx.so, loaded once (raises TrxError if the HIP extension was not built) -- or the
+    testing library after use_testing_library()."""
+    global _lib, _production
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if os.environ.get("TRX_TESTING") == "1":
+        return use_testing_library(True)
+    if _production is None:
+        _production = _load(LIB_PATH, False)
+    _lib = _production
+    return _lib
+
+
+def testing_lib():
+    """libtrx_testing.so (include/trx_debug.h), loaded once; does not change the library in use"""
+    global _testing
+    if _testing is None:
+        _testing = _load(TESTING_LIB_PATH, True)
+    return _testing
+
+
+def use_testing_library(on=True):
+    """tests/ and profiles/ only: every wrapper of this module calls the testing library (its own scratch, its own
+    switches, all at their defaults unless set) until use_testing_library(False).  Returns the library now in use."""
+    global _lib, _production
+    if on:
+        _lib = testing_lib()
+    else:
+        if _production is None:
+            _production = _load(LIB_PATH, False)
+        _lib = _production
+    return _lib
+
+
+def _load(path, testing):
+    if not os.path.exists(path):
         raise TrxError(
             "triceratops_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
     c_int, c_long, c_double, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_size_t
     L.trx_lnl_batch.restype = c_int
     L.trx_lnl_batch.argtypes = [c_int, c_int, _vp, _vp, c_int, c_double, _vp, c_long, c_double,
@@ -109,40 +162,24 @@ def lib():
     L.trx_flux_grid_host.argtypes = [c_int, c_int, _vp, c_int, _vp, c_long, c_double, c_int, _vp, _vp]
     L.trx_log_mean_exp_host.restype = c_int
     L.trx_log_mean_exp_host.argtypes = [_vp, c_long, c_long, _vp]
-    L.trx_set_rows_per_wave.restype = c_int
-    L.trx_set_rows_per_wave.argtypes = [c_int]
-    L.trx_set_kepler_stepping.restype = c_int
-    L.trx_set_kepler_stepping.argtypes = [c_int]
-    L.trx_set_skip_excluded.restype = c_int
-    L.trx_set_skip_excluded.argtypes = [c_int]
     L.trx_skipped_rows.restype = c_int
     L.trx_skipped_rows.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), c_int]
-    L.trx_set_bounded_evaluation.restype = c_int
-    L.trx_set_bounded_evaluation.argtypes = [c_int]
-    L.trx_set_debug_bounded_lnl.restype = c_int
-    L.trx_set_debug_bounded_lnl.argtypes = [c_int]
-    L.trx_set_debug_poison.restype = c_int
-    L.trx_set_debug_poison.argtypes = [c_int]
-    L.trx_set_debug_bug.restype = c_int
-    L.trx_set_debug_bug.argtypes = [c_int]
-    L.trx_set_star_chain.restype = c_int
-    L.trx_set_star_chain.argtypes = [c_int]
-    L.trx_set_probe_rows.restype = c_int
-    L.trx_set_probe_rows.argtypes = [c_int]
     L.trx_pruned_rows.restype = c_int
     L.trx_pruned_rows.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), c_int]
-    L.trx_set_stencil.restype = c_int
-    L.trx_set_stencil.argtypes = [c_int]
-    L.trx_set_supersample_tiers.restype = c_int
-    L.trx_set_supersample_tiers.argtypes = [c_int]
-    L.trx_set_debug_node_counts.restype = c_int
-    L.trx_set_debug_node_counts.argtypes = [c_int]
-    L.trx_set_cell_packing_below.restype = c_int
-    L.trx_set_cell_packing_below.argtypes = [c_int]
     L.trx_version.restype = ctypes.c_char_p
     L.trx_last_error.restype = ctypes.c_char_p
     L.trx_device_count.restype = c_int
-    _lib = L
+    L.trx_testing = bool(testing)
+    if testing:
+        for name in ("trx_set_rows_per_wave", "trx_set_kepler_stepping", "trx_set_skip_excluded",
+                     "trx_set_bounded_evaluation", "trx_set_debug_bounded_lnl", "trx_set_debug_poison",
+                     "trx_set_debug_bug", "trx_set_star_chain", "trx_set_probe_rows", "trx_set_stencil",
+                     "trx_set_supersample_tiers", "trx_set_debug_node_counts", "trx_set_cell_packing_below"):
+            fn = getattr(L, name)
+            fn.restype = c_int
+            fn.argtypes = [c_int]
+        L.trx_debug_capture_buffers.restype = c_int
+        L.trx_debug_capture_buffers.argtypes = [ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
     return L
 
 

@@ -86,6 +86,9 @@ struct ChainBranch {
     const ScenFinal* fin;
 };
 constexpr int kChainNotApplicable = -1;
+// the flags every call of a chain must share (the launch plan is made from the first call's)
+constexpr int kChainSharedFlags = TRX_FLAG_FP32_MODEL | TRX_FLAG_EVALUATE_EXCLUDED | TRX_FLAG_ALL_SUBEXPOSURES |
+                                  TRX_FLAG_NO_STENCIL | TRX_FLAG_FULL_EVALUATION;
 constexpr int kChainMaxCalls = 16, kChainMaxBranchesHost = 24;
 size_t chain_branch_scratch_bytes(long n_upper);
 // would lnl_lme_chain take these rows?  (the bounded evaluation's passes apply: see lnl_lme_chain)

@@ -38,6 +38,7 @@
 #include "../../include/trx.h"
 #include "trx_device.hpp"
 #include "trx_internal.hpp"
+#include "trx_knobs.hpp"
 
 namespace {
 
@@ -2168,12 +2169,8 @@ __global__ __launch_bounds__(64) void lme_final_kernel(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// Process-wide diagnostics switches (include/trx.h, "Diagnostics"): read once per enqueue, relaxed
-// atomics so that a concurrent setter is a data-race-free (if unordered) change of mode.
-std::atomic<int> g_rows_per_wave{0};  // 0 = auto
-// rows per wave of the probe pass of a split launch: 0 = as many as its LDS holds, 1 = as the other passes (A/B, tests), n = n
-std::atomic<int> g_probe_rows{getenv("TRX_PROBE_ROWS") ? atoi(getenv("TRX_PROBE_ROWS")) : 0};
-std::atomic<int> g_step{1};           // sub-exposure Kepler stepping (0 = full solve per sub-exposure)
+// Tuning and diagnostics switches: trx_knobs.hpp.  Compile-time constants in the production library; process-wide
+// atomics with setters (include/trx_debug.h) in the testing build, read once per enqueue.
 
 int n_params(int model)
 {
@@ -2194,19 +2191,6 @@ int n_params(int model)
 // of the measure (Stieltjes recurrence, roots by bisection between the roots of degree n-1),
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
 // decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
-std::atomic<int> g_tiers{1};
-// bounded evaluation in trx_scenario_evidence: 0 never, 1 light curves of one row per wave, 2 always (the default since
-// round 4; TRX_BOUNDED in the environment sets the initial value: A/B runs of whole programs)
-static int initial_prune_mode()
-{
-    const char* e = getenv("TRX_BOUNDED");
-    return (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : 2;
-}
-std::atomic<int> g_prune{initial_prune_mode()};
-std::atomic<int> g_prune_lnl{0};      // tests: trx_lnl_batch applies it too (as for an evidence without prior)
-std::atomic<int> g_skip_excluded{1};  // rows excluded by the EB secondary rule are not evaluated (likelihood calls)
-std::atomic<int> g_stencil{1};      // centre-value stencil on dense uniform time grids (0 = Gauss nodes everywhere)
-std::atomic<int> g_debug_nodes{0};  // grid mode writes the number of model evaluations per cell instead of the flux
 bool compute_tiers(TierTable& T, int S)
 {
     static const int nn[kTiers] = {3, 4, 5, 6, 7, 8, 9};
@@ -2374,8 +2358,6 @@ struct StencilMemo {
 };
 StencilMemo g_stencil_memo;
 
-// light curves shorter than this go through cells_kernel (0 = never, for A/B runs)
-std::atomic<int> g_cells_below{320};
 
 // what the last launch_cells of this thread did (trx::lnl_draws hands it to the reduction that follows)
 thread_local const double* t_last_rowc = nullptr;
@@ -2548,45 +2530,43 @@ struct CellsPlan {
     int probe_wave_doubles;
 };
 
-std::atomic<int> g_debug_bug{0};      // trx_set_debug_bug (tests)
-
 template <int MODE>
 int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
 {
     // rows per wave (batch_rows); with the row count on the device the LDS layout takes the largest value
-    a.forced_B = g_rows_per_wave.load(std::memory_order_relaxed);
+    a.forced_B = knob_rows_per_wave();
     a.B = long_rows ? 1 : batch_rows(a.n_dev ? -1 : a.n, a.n_time, a.forced_B);
     a.s2 = a.sigma * a.sigma;
     a.rs2 = 1.0 / a.s2;
     a.dS = (double)a.S;
     a.rS = 1.0 / a.dS;
     a.nbatch = 8 * batch_plan(a.n, a.B).P;          // wave positions of the launch (batch_plan)
-    a.debug_bug = g_debug_bug.load(std::memory_order_relaxed);
+    a.debug_bug = knob_debug_bug();
     a.mark_unwritten = (MODE == MODE_LNL) ? 1 : 0;
     bool tiers_ok = false;
     if (tier_device(a.S, a.tiers, &a.tier_xw, &tiers_ok)) return fail(TRX_ERR_HIP, "tier table upload failed%s", "", 0);
-    a.use_tiers = tiers_ok && g_tiers.load(std::memory_order_relaxed);
+    a.use_tiers = tiers_ok && knob_tiers() && !(a.flags & TRX_FLAG_ALL_SUBEXPOSURES);
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
     // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
     // 46 -> 39 ms; at 100 binned points the batched variant gains or loses ~3 % (the probe phase, the pilot
     // launch and the second window pass eat what the abandoned rows save): profiles/r03_bounded_e2e.txt)
-    const int prune_mode = a.prune == 2 ? 2 : g_prune.load(std::memory_order_relaxed);
+    const int prune_mode = (a.flags & TRX_FLAG_FULL_EVALUATION) ? 0 : (a.prune == 2 ? 2 : knob_bounded());
     // (batched variant: the verdict after the probe phase reads flat + corrections - hrem, and hrem holds only the
     // in-window cells of the window passes done so far -- a valid bound only when the batch's cells fit ONE window;
     // a forced rows-per-wave or a raised trx_set_cell_packing_below can exceed it: those launches evaluate in full)
-    const bool prune = MODE == MODE_LNL && a.prune && g_step.load(std::memory_order_relaxed) &&
+    const bool prune = MODE == MODE_LNL && a.prune && knob_kepler_stepping() &&
                        (prune_mode == 2 || (prune_mode == 1 && long_rows)) &&
                        (long_rows || (long)a.B * a.n_time <= (long)kCellsWindowBatch) &&
                        a.n_time >= kProbeMinPoints;
     a.prune = prune ? 1 : 0;
     // probe cells per row: every (n_time / kProbeCells)-th stamp (TRX_PROBE_CELLS in the environment: experiments)
-    static const int probe_cells = getenv("TRX_PROBE_CELLS") ? atoi(getenv("TRX_PROBE_CELLS")) : kProbeCells;
+    static const int probe_cells = (int)env_long("TRX_PROBE_CELLS", kProbeCells);
     a.pstride = prune ? (a.n_time / probe_cells > 1 ? a.n_time / probe_cells : 2) : 1;
-    static const int third_stride = getenv("TRX_THIRD_STRIDE") ? atoi(getenv("TRX_THIRD_STRIDE")) : kThirdStride;
+    static const int third_stride = (int)env_long("TRX_THIRD_STRIDE", kThirdStride);
     a.pstride3 = (prune && third_stride > 1 && a.n_time >= 4 * third_stride) ? third_stride : 0;
     a.use_stencil = (!prune && long_rows && a.use_tiers && a.exptime > 0.0 && a.S >= 8 && a.n_time >= 64 &&
-                     g_stencil.load(std::memory_order_relaxed)) ? 1 : 0;
-    a.skip_excl = g_skip_excluded.load(std::memory_order_relaxed) && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
+                     knob_stencil() && !(a.flags & TRX_FLAG_NO_STENCIL)) ? 1 : 0;
+    a.skip_excl = knob_skip_excluded() && !(a.flags & TRX_FLAG_EVALUATE_EXCLUDED);
     a.need_sec = (a.model == TRX_MODEL_EB && MODE == MODE_LNL) ||
                  ((a.model == TRX_MODEL_EB || a.model == TRX_MODEL_EB_TWIN) && a.out_sec != nullptr);
     // LDS: [node tables | atan constants | the staged light curve (short curves)] shared by the workgroup's waves,
@@ -2628,8 +2608,8 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     P.probe_wave_doubles = a.wave_doubles;
     a.probe_rows = 0;
     a.wave_floor = a.wave_floor3 = 3200;
-    if (split && g_probe_rows.load(std::memory_order_relaxed) != 1) {
-        const int forced = g_probe_rows.load(std::memory_order_relaxed);
+    if (split && knob_probe_rows() != 1) {
+        const int forced = knob_probe_rows();
         const int per_row = a.n_time / a.pstride + 1;                      // probe cells of a row
         const size_t fixed = (kCellsPairs + cells_window(false)) * sizeof(unsigned short) + sizeof(CellState);
         const size_t room = (32 * 1024 - shared) / cells_waves(false);       // five workgroups per CU
@@ -2649,7 +2629,7 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     P.split = split;
     P.lds = lds;
     P.fp32 = (a.flags & TRX_FLAG_FP32_MODEL) != 0;
-    P.step = g_step.load(std::memory_order_relaxed) != 0;
+    P.step = knob_kepler_stepping() != 0;
     // Row count on the device: `n` is its upper bound (every draw of the scenario), the geometry mask
     // keeps 2-11 % of them, so the grid takes a quarter of the bound -- blocks
     // beyond the batches leave at once, batches beyond the grid are reached by the grid-stride loop.
@@ -2675,9 +2655,9 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     // per slot with one row per wave.  Measured in one job each (profiles/r04_ab_cap.txt): 64 TOIs on three streams
     // 0.265 -> 0.185 s per step (four streams 0.175), the 75-scenario calc_probs 22.0 -> 20.4 ms, 15 scenarios
     // 3.8 -> 3.1 ms, Kepler-10b 12.0 -> 10.6 ms.  (Environment: experiments only.)
-    static const long cap_probe = getenv("TRX_GRID_CAP") ? atol(getenv("TRX_GRID_CAP")) : 1280;
-    static const long cap_plain = getenv("TRX_GRID_CAP_PLAIN") ? atol(getenv("TRX_GRID_CAP_PLAIN")) : 5120;
-    static const long cap_long = getenv("TRX_GRID_CAP_LONG") ? atol(getenv("TRX_GRID_CAP_LONG")) : 16384;
+    static const long cap_probe = env_long("TRX_GRID_CAP", 1280);
+    static const long cap_plain = env_long("TRX_GRID_CAP_PLAIN", 5120);
+    static const long cap_long = env_long("TRX_GRID_CAP_LONG", 16384);
     const long cap = (a.n_dev || prune) ? (long_rows ? cap_long : (prune ? cap_probe : cap_plain)) : 0;
     P.grid_main = grid_for(long_rows ? a.n : a.nbatch, long_rows, cap);
     {
@@ -2695,8 +2675,8 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
         // of the open rows is the opposite case: serial chains of ~1000 fp64 instructions, eight rows a workgroup -- 61 us
         // with the guessed grid, 123 at 512 workgroups a branch, 373 at 128 (profiles/r05/trace_env.sh).  Environment:
         // experiments.)
-        static const long rowc_cap = getenv("TRX_ROWC_CAP") ? atol(getenv("TRX_ROWC_CAP")) : 512;
-        static const long scan_cap = getenv("TRX_SCAN_CAP") ? atol(getenv("TRX_SCAN_CAP")) : 1L << 30;
+        static const long rowc_cap = env_long("TRX_ROWC_CAP", 512);
+        static const long scan_cap = env_long("TRX_SCAN_CAP", 1L << 30);
         long rb = (a.n + 63) / 64;
         if (a.n_dev) rb = (rb + 3) / 4 < 64 ? 64 : (rb + 3) / 4;      // see grid_for; rowc_kernel strides over the rest
         if (a.n_dev && rb > rowc_cap) rb = rowc_cap;
@@ -2819,7 +2799,7 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
 template <int MODE>
 int launch_rows(const RowsArgs& a0, hipStream_t st)
 {
-    const bool batches = a0.n_time > 0 && a0.n_time < g_cells_below.load(std::memory_order_relaxed);
+    const bool batches = a0.n_time > 0 && a0.n_time < knob_cells_below();
     return launch_cells<MODE>(a0, st, !batches);
 }
 
@@ -3066,7 +3046,7 @@ bool lnl_chain_applicable(int flags, int n_time, long N, int S)
     static const long dummy_n = 0;
     a.n_dev = &dummy_n;              // (never read on the host: "the row count lives on the device")
     a.prune = 1;
-    const bool batches = n_time < g_cells_below.load(std::memory_order_relaxed);
+    const bool batches = n_time < knob_cells_below();
     CellsPlan P;
     if (plan_cells<MODE_LNL>(a, !batches, P) != TRX_OK) return false;
     return P.prune && P.step && P.passes;
@@ -3089,7 +3069,7 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
     a.n_dev = br[0].n_dev; a.src_idx = br[0].src_idx; a.src_stride = N; a.twin_cols = br[0].twin;
     a.dense = 1;
     a.prune = 1;
-    const bool batches = n_time > 0 && n_time < g_cells_below.load(std::memory_order_relaxed);
+    const bool batches = n_time > 0 && n_time < knob_cells_below();
     CellsPlan P;
     if (int rc = plan_cells<MODE_LNL>(a, !batches, P)) return rc;
     if (!P.prune || !P.step || !P.passes) return kChainNotApplicable;
@@ -3100,7 +3080,7 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
         const ChainBranch& c = br[i];
         if (c.model == TRX_MODEL_RAW || !c.n_dev || !c.src_idx || !c.h || !c.cols || !c.flux || !c.scratch || !c.scan_count ||
             !c.ws || !c.amin_pv || !c.amin_pi || ((uintptr_t)c.h % 16) != 0 ||
-            ((c.flags ^ br[0].flags) & (TRX_FLAG_FP32_MODEL | TRX_FLAG_EVALUATE_EXCLUDED)))
+            ((c.flags ^ br[0].flags) & kChainSharedFlags))
             return fail(TRX_ERR_ARG, "lnl_lme_chain: bad argument in branch%s %ld", "", (long)i);
         BranchArgs& b = bt.b[i];
         b.model = c.model; b.flags = c.flags; b.twin_cols = c.twin; b.need_sec = (c.model == TRX_MODEL_EB) ? 1 : 0;
@@ -3128,8 +3108,8 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
     // survivors' pass of a 64-target step ran one row per wave in most branches under the per-launch rule -- lanes 0.65
     // active: same job, 0.114 -> 0.107-0.109 s per step with the floor divided; any value from 1 to 300 does the same,
     // profiles/r05/ab_probe_rows.txt.  Environment: experiments.)
-    static const int floor_env = getenv("TRX_WAVE_FLOOR") ? atoi(getenv("TRX_WAVE_FLOOR")) : 0;
-    static const int floor3_env = getenv("TRX_WAVE_FLOOR3") ? atoi(getenv("TRX_WAVE_FLOOR3")) : 0;
+    static const int floor_env = (int)env_long("TRX_WAVE_FLOOR", 0);
+    static const int floor3_env = (int)env_long("TRX_WAVE_FLOOR3", 0);
     a.wave_floor = floor_env > 0 ? floor_env : (3200 / nbr > 256 ? 3200 / nbr : 256);
     a.wave_floor3 = floor3_env > 0 ? floor3_env : a.wave_floor;
     auto cells = [&](unsigned grid, int part) {
@@ -3209,7 +3189,7 @@ int trx_lnl_batch(int model, int flags, const double* time, const double* flux, 
     RowsArgs a{};
     a.model = model; a.flags = flags; a.time = time; a.flux = flux; a.n_time = n_time; a.sigma = sigma;
     a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_halfchi2;
-    if (g_prune_lnl.load(std::memory_order_relaxed)) { a.prune = 2; a.prune_c0 = 0.0; a.prune_lp = nullptr; }
+    if (knob_bounded_lnl()) { a.prune = 2; a.prune_c0 = 0.0; a.prune_lp = nullptr; }
     return launch_rows<MODE_LNL>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -3223,7 +3203,7 @@ int trx_flux_grid(int model, int flags, const double* time, int n_time, const do
     RowsArgs a{};
     a.model = model; a.flags = flags; a.time = time; a.n_time = n_time; a.sigma = 1.0;
     a.params = params; a.n = n; a.exptime = exptime; a.S = nsupersample; a.out = out_flux; a.out_sec = out_secdepth;
-    a.debug_nodes = g_debug_nodes.load(std::memory_order_relaxed);
+    a.debug_nodes = (knob_debug_nodes() || (flags & TRX_FLAG_COUNT_EVALUATIONS)) ? 1 : 0;
     return launch_rows<MODE_GRID>(a, static_cast<hipStream_t>(stream));
 }
 
@@ -3350,6 +3330,36 @@ int trx_log_mean_exp_host(const double* logw, long n, long n_total, double* out)
     return TRX_OK;
 }
 
+/* statistics (include/trx.h): rows skipped on the current device since the last reset */
+static int read_row_stat(int which, unsigned long long* out, int reset)
+{
+    static unsigned long long host[kStatShards][kStatPad];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    constexpr size_t slice = sizeof(host);                 // one counter's shards
+    TRX_HIP(hipDeviceSynchronize());
+    TRX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_row_stats), slice, (size_t)which * slice));
+    if (out) {
+        unsigned long long sum = 0;
+        for (int i = 0; i < kStatShards; ++i) sum += host[i][0];
+        *out = sum;
+    }
+    if (reset) {
+        // only this counter's slice is cleared (a copy of the WHOLE table written back would roll back what kernels of
+        // another host thread added to the other counter between the read and the write: advisor, round 4)
+        memset(host, 0, slice);
+        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), host, slice, (size_t)which * slice));
+    }
+    return TRX_OK;
+}
+
+int trx_skipped_rows(unsigned long long* out, int reset) { return read_row_stat(0, out, reset); }
+
+/* statistics (include/trx.h): rows abandoned by the bounded evaluation on the current device since the last reset */
+int trx_pruned_rows(unsigned long long* out, int reset) { return read_row_stat(1, out, reset); }
+
+#ifdef TRX_TESTING
+// ---- include/trx_debug.h: the testing library only ---------------------------------------------------------
 // (tests, host only: no device is touched) the plan the batched cells_kernel deals its rows by -- walks every position
 // of the eight XCDs exactly as cells_body does and checks that the batches tile [0, rows) once, in order within an
 // XCD, none larger than rows_per_wave; *positions = positions per XCD, *waves_min = the smallest batch met
@@ -3386,7 +3396,7 @@ int trx_set_rows_per_wave(int rows)
 {
     if (rows < 0 || rows > kCellsMaxRows)
         return fail(TRX_ERR_ARG, "rows per wave must be 0 (automatic) .. 22%s (got %ld)", "", (long)rows);
-    g_rows_per_wave = rows;
+    g_knob_rows_per_wave = rows;
     return TRX_OK;
 }
 
@@ -3394,54 +3404,29 @@ int trx_set_rows_per_wave(int rows)
 int trx_set_cell_packing_below(int n_time)
 {
     if (n_time < 0) return fail(TRX_ERR_ARG, "n_time threshold must be >= 0%s (got %ld)", "", (long)n_time);
-    g_cells_below = n_time;
+    g_knob_cells_below = n_time;
     return TRX_OK;
 }
 
 /* diagnostics (include/trx.h): 0 = evaluate the light curve of every row, also of those the EB rule excludes */
 int trx_set_skip_excluded(int on)
 {
-    g_skip_excluded = on ? 1 : 0;
+    g_knob_skip_excluded = on ? 1 : 0;
     return TRX_OK;
 }
-
-/* statistics (include/trx.h): rows skipped on the current device since the last reset */
-static int read_row_stat(int which, unsigned long long* out, int reset)
-{
-    static unsigned long long host[kStatShards][kStatPad];
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    constexpr size_t slice = sizeof(host);                 // one counter's shards
-    TRX_HIP(hipDeviceSynchronize());
-    TRX_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_row_stats), slice, (size_t)which * slice));
-    if (out) {
-        unsigned long long sum = 0;
-        for (int i = 0; i < kStatShards; ++i) sum += host[i][0];
-        *out = sum;
-    }
-    if (reset) {
-        // only this counter's slice is cleared (a copy of the WHOLE table written back would roll back what kernels of
-        // another host thread added to the other counter between the read and the write: advisor, round 4)
-        memset(host, 0, slice);
-        TRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), host, slice, (size_t)which * slice));
-    }
-    return TRX_OK;
-}
-
-int trx_skipped_rows(unsigned long long* out, int reset) { return read_row_stat(0, out, reset); }
 
 /* diagnostics (include/trx.h): 0 = trx_scenario_evidence evaluates every masked draw to the end */
 int trx_set_bounded_evaluation(int mode)
 {
     if (mode < 0 || mode > 2) return fail(TRX_ERR_ARG, "bounded evaluation mode must be 0, 1 or 2%s (got %ld)", "", (long)mode);
-    g_prune = mode;
+    g_knob_bounded = mode;
     return TRX_OK;
 }
 
 /* tests (include/trx.h): trx_lnl_batch / trx_lnz_scenario evaluate their rows the bounded way, too */
 int trx_set_debug_bug(int on)
 {
-    g_debug_bug = on ? 1 : 0;
+    g_knob_debug_bug = on ? 1 : 0;
     return TRX_OK;
 }
 
@@ -3449,37 +3434,34 @@ int trx_set_debug_bug(int on)
 int trx_set_probe_rows(int rows)
 {
     if (rows < 0 || rows > kCellsMaxRows) return fail(TRX_ERR_ARG, "probe rows must be 0 (automatic) .. 22%s (got %ld)", "", (long)rows);
-    g_probe_rows = rows;
+    g_knob_probe_rows = rows;
     return TRX_OK;
 }
 
 int trx_set_debug_bounded_lnl(int on)
 {
-    g_prune_lnl = on ? 1 : 0;
+    g_knob_bounded_lnl = on ? 1 : 0;
     return TRX_OK;
 }
-
-/* statistics (include/trx.h): rows abandoned by the bounded evaluation on the current device since the last reset */
-int trx_pruned_rows(unsigned long long* out, int reset) { return read_row_stat(1, out, reset); }
 
 /* diagnostics (include/trx.h): 0 = Gauss nodes everywhere, no centre-value stencil */
 int trx_set_stencil(int on)
 {
-    g_stencil = on ? 1 : 0;
+    g_knob_stencil = on ? 1 : 0;
     return TRX_OK;
 }
 
 /* diagnostics (include/trx.h): 0 = full Kepler solve per sub-exposure */
 int trx_set_kepler_stepping(int on)
 {
-    g_step = on ? 1 : 0;
+    g_knob_kepler_stepping = on ? 1 : 0;
     return TRX_OK;
 }
 
 /* diagnostics (include/trx.h): 0 = evaluate all S sub-exposures of every cell */
 int trx_set_supersample_tiers(int on)
 {
-    g_tiers = on ? 1 : 0;
+    g_knob_tiers = on ? 1 : 0;
     return TRX_OK;
 }
 
@@ -3487,9 +3469,21 @@ int trx_set_supersample_tiers(int on)
    evaluations planned for each cell (0, a reduced node count, or nsupersample) instead of the flux */
 int trx_set_debug_node_counts(int on)
 {
-    g_debug_nodes = on ? 1 : 0;
+    g_knob_debug_nodes = on ? 1 : 0;
     return TRX_OK;
 }
+
+/* (tests) scratch buffers of captured calls: how many a live graph still owns, how many wait in the pool for reuse */
+int trx_debug_capture_buffers(long* live, long* idle)
+{
+    long a = 0, b = 0;
+    trx::capture_scratch_stats(&a, &b);
+    if (live) *live = a;
+    if (idle) *idle = b;
+    return TRX_OK;
+}
+
+#endif  // TRX_TESTING
 
 #ifdef TRX_CENSUS
 int trx_debug_census(unsigned long long* out32, int reset)
@@ -3515,16 +3509,6 @@ int trx_debug_phase_cycles(unsigned long long* out8)
     return TRX_OK;
 }
 #endif
-
-/* (tests) scratch buffers of captured calls: how many a live graph still owns, how many wait in the pool for reuse */
-int trx_debug_capture_buffers(long* live, long* idle)
-{
-    long a = 0, b = 0;
-    trx::capture_scratch_stats(&a, &b);
-    if (live) *live = a;
-    if (idle) *idle = b;
-    return TRX_OK;
-}
 
 /* frees every per-stream scratch buffer of the library (all devices); the streams must be idle */
 int trx_release_scratch(void)

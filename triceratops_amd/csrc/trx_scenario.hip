@@ -38,10 +38,9 @@
 #include "../../include/trx.h"
 #include "trx_device.hpp"
 #include "trx_internal.hpp"
+#include "trx_knobs.hpp"
 
 namespace {
-
-std::atomic<int> g_poison{0};         // trx_set_debug_poison (tests)
 
 #define TRXS_HIP(call)                                   \
     do {                                                 \
@@ -116,7 +115,7 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         return rc;
     };
     if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, A.at<double>(o_cols0), st)) return bail(rc);
-    if (g_poison.load(std::memory_order_relaxed))          // tests: an unwritten row must show (include/trx.h)
+    if (trx::knob_poison())          // tests: an unwritten row must show (include/trx_debug.h)
         for (int b = 0; b < nbr; ++b) TRXS_HIP(hipMemsetAsync(h[b], 0, sizeof(double) * (size_t)N, st));
     for (int b = 0; b < nbr; ++b) {
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
@@ -285,34 +284,29 @@ int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, doubl
     long per = 0;
     int groups = 0;
     if (int rc = trx::draw_chain(stage, dev_tab, n, A.at<int>(o_cnt), fills, &per, &groups, st)) return bail(rc);
-    if (g_poison.load(std::memory_order_relaxed))          // tests: an unwritten row must show (include/trx.h)
+    if (trx::knob_poison())          // tests: an unwritten row must show (include/trx_debug.h)
         for (int b = 0; b < nbr_total; ++b) TRXS_HIP(hipMemsetAsync(br[b].h, 0, sizeof(double) * (size_t)N, st));
-    if (int rc = trx::lnl_lme_chain(br, nbr_total, s0.time, s0.n_time, N, s0.exptime, s0.nsupersample, st)) return bail(rc);
+    if (int rc = trx::lnl_lme_chain(br, nbr_total, s0.time, s0.n_time, N, s0.exptime, s0.nsupersample, st)) {
+        // (kChainNotApplicable cannot happen in the production library -- trx_star_enqueue asked lnl_chain_applicable with
+        // the same arguments and nothing it depends on can change; in the testing library a switch of trx_debug.h was
+        // flipped by another thread in between: the draw kernels are already enqueued, so this is an error, not a fall-back)
+        if (rc == trx::kChainNotApplicable) rc = trx::fail_hip(hipErrorInvalidValue);
+        return bail(rc);
+    }
     for (int i = 0; i < n; ++i)
         if (copy_back[i])
             TRXS_HIP(hipMemcpyAsync(out[which[i]], res_of[i], sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), hipMemcpyDeviceToHost, st));
     return TRX_OK;
 }
 
-std::atomic<int> g_chain{-1};          // trx_set_star_chain: -1 = from the environment (TRX_STAR_CHAIN, default on)
-
-bool chain_enabled()
-{
-    int v = g_chain.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("TRX_STAR_CHAIN");
-        v = (e && e[0] == '0' && !e[1]) ? 0 : 1;
-        g_chain = v;
-    }
-    return v != 0;
-}
+bool chain_enabled() { return trx::knob_star_chain() != 0; }
 
 // may call j join a chain that starts with call i?  (same stream is the caller's business)
 bool chain_compatible(const trx_scenario_args& a, const trx_scenario_args& b)
 {
     return a.draw->N == b.draw->N && a.n_time == b.n_time && a.time == b.time && a.nsupersample == b.nsupersample &&
            a.exptime == b.exptime &&
-           ((a.flags ^ b.flags) & (TRX_FLAG_FP32_MODEL | TRX_FLAG_EVALUATE_EXCLUDED)) == 0;
+           ((a.flags ^ b.flags) & trx::kChainSharedFlags) == 0;
 }
 
 }  // namespace
@@ -334,7 +328,7 @@ extern "C" int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, dou
     // launch chain (enqueue_chain), up to kChainMaxCalls calls / kChainMaxBranchesHost branches at a time -- when the
     // bounded evaluation's passes apply to them and their scratch together stays below the budget (TRX_CHAIN_DRAWS,
     // default 2.5e7 draws' worth per chain: ~0.36 GB per 1e6 draws and call); everything else goes call by call.
-    static const double draw_budget = getenv("TRX_CHAIN_DRAWS") ? atof(getenv("TRX_CHAIN_DRAWS")) : 2.5e7;
+    static const double draw_budget = trx::env_double("TRX_CHAIN_DRAWS", 2.5e7);
     int i = 0;
     while (i < n_calls) {
         hipStream_t st = static_cast<hipStream_t>(streams[i]);
@@ -362,11 +356,13 @@ extern "C" int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, dou
     return TRX_OK;
 }
 
+#ifdef TRX_TESTING
 extern "C" int trx_set_star_chain(int on)
 {
-    g_chain = on ? 1 : 0;
+    trx::g_knob_star_chain = on ? 1 : 0;
     return TRX_OK;
 }
+#endif
 
 extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
 {
@@ -385,8 +381,10 @@ extern "C" int trx_scenario_evidence(const trx_scenario_args* s, void* stream)
 
 extern "C" size_t trx_scenario_args_size(void) { return sizeof(trx_scenario_args); }
 
+#ifdef TRX_TESTING
 extern "C" int trx_set_debug_poison(int on)
 {
-    g_poison = on ? 1 : 0;
+    trx::g_knob_poison = on ? 1 : 0;
     return TRX_OK;
 }
+#endif

@@ -117,14 +117,11 @@ NATIVE = os.environ.get("TRX_NATIVE", "1") != "0"      # TRX_NATIVE=0: A/B runs 
 # the draw kernel's fp32 pre-test of the geometry (csrc/trx_draw.hip, may_transit): the fp64 mask is evaluated
 # only for the draws it lets through.  Same masks; TRX_PRETEST=0 / PRETEST = False evaluates every draw (tests)
 PRETEST = os.environ.get("TRX_PRETEST", "1") != "0"
-_bound = False
-_bound_scenario = False
 
 
 def _fn_scenario():
-    global _bound_scenario
     L = _lib.lib()
-    if not _bound_scenario:
+    if not getattr(L, "trx_bound_scenario", False):          # (per library: tests switch to the testing build and back)
         _fn()
         L.trx_scenario_evidence.restype = ctypes.c_int
         L.trx_scenario_evidence.argtypes = [ctypes.POINTER(ScenarioArgs), _vp]
@@ -137,7 +134,7 @@ def _fn_scenario():
         if L.trx_scenario_args_size() != ctypes.sizeof(ScenarioArgs):
             raise _lib.TrxError("trx_scenario_args layout mismatch: library %d bytes, binding %d"
                                 % (L.trx_scenario_args_size(), ctypes.sizeof(ScenarioArgs)))
-        _bound_scenario = True
+        L.trx_bound_scenario = True
     return L.trx_scenario_enqueue
 
 
@@ -202,7 +199,8 @@ def _check_status(recs, planet):
         if np.any(bad):
             raise _lib.TrxError("libtrx: %d lnZ_* call(s) of this pass report rows of their likelihood that no kernel "
                                 "wrote (branch %d; record status 1) -- an internal error, the results are not usable; "
-                                "trx_set_bounded_evaluation(0) evaluates every row in one pass" % (int(bad.sum()), b))
+                                "triceratops_amd.set_full_evaluation(True) (TRX_FLAG_FULL_EVALUATION) evaluates every "
+                                "row in one pass" % (int(bad.sum()), b))
 
 
 _stats_lock = threading.Lock()
@@ -336,16 +334,15 @@ def _record_slot():
 
 
 def _fn():
-    global _bound
     L = _lib.lib()
-    if not _bound:
+    if not getattr(L, "trx_bound_draw", False):
         L.trx_draw_scenario.restype = ctypes.c_int
         L.trx_draw_scenario.argtypes = [ctypes.POINTER(DrawArgs), _vp]
         L.trx_draw_args_size.restype = ctypes.c_size_t
         if L.trx_draw_args_size() != ctypes.sizeof(DrawArgs):
             raise _lib.TrxError("trx_draw_args layout mismatch: library %d bytes, binding %d"
                                 % (L.trx_draw_args_size(), ctypes.sizeof(DrawArgs)))
-        _bound = True
+        L.trx_bound_draw = True
     return L.trx_draw_scenario
 
 
