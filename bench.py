@@ -254,12 +254,21 @@ def main():
     ctx = dict(args=args, world=world, rank=rank, device=device, debug_one=debug_one, extras=extras,
                traffic=traffic)
     out = run_grid(ctx) if args.mode == "grid" else run_batch(ctx)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
         dist.barrier()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when NCCL_DEBUG is
+        # WARN or VERSION (it is on the GPU boxes), and libc's buffer would otherwise be flushed after Python's
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                  # noqa: BLE001
+            pass
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 def _sync(ctx):

@@ -674,18 +674,30 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
     const double clo = (c.ax * e - R) / A, chi = (c.ax * e + R) / A;
     const double psi = remainder(Etr - phi, kTwoPi);
     double plo, phi2;  // arc [plo, phi2] of psi = E - phi containing psi
-    const bool open_hi = !(chi < 1.0), open_lo = !(clo > -1.0);
-    const double xlo = acos(fmin(fmax(clo, -1.0), 1.0)), xhi = acos(fmin(fmax(chi, -1.0), 1.0));
-    if (open_hi && open_lo) {
-        plo = psi - kTwoPi;
-        phi2 = psi + kTwoPi;
-    } else if (open_hi) {
-        plo = -xlo;
-        phi2 = xlo;
-    } else if (open_lo) {
-        if (psi >= 0.0) { plo = xhi; phi2 = kTwoPi - xhi; } else { plo = xhi - kTwoPi; phi2 = -xhi; }
-    } else {
-        if (psi >= 0.0) { plo = xhi; phi2 = xlo; } else { plo = -xlo; phi2 = -xhi; }
+    // the arc of the strip |X| < r that holds conjunction; returns true in the case with a mirror arc (both ends closed)
+    double xlo = 0.0, xhi = 0.0;
+    auto strip_arc = [&](double clo_, double chi_, double& lo_, double& hi_) -> bool {
+        const bool open_hi = !(chi_ < 1.0), open_lo = !(clo_ > -1.0);
+        xlo = acos(fmin(fmax(clo_, -1.0), 1.0));
+        xhi = acos(fmin(fmax(chi_, -1.0), 1.0));
+        if (open_hi && open_lo) {
+            lo_ = psi - kTwoPi;
+            hi_ = psi + kTwoPi;
+        } else if (open_hi) {
+            lo_ = -xlo;
+            hi_ = xlo;
+        } else if (open_lo) {
+            if (psi >= 0.0) { lo_ = xhi; hi_ = kTwoPi - xhi; } else { lo_ = xhi - kTwoPi; hi_ = -xhi; }
+        } else {
+            if (psi >= 0.0) { lo_ = xhi; hi_ = xlo; } else { lo_ = -xlo; hi_ = -xhi; }
+            return true;
+        }
+        return false;
+    };
+    bool widened = false;
+    const double Ay = sqrt(c.ay * c.ay + c.by * c.by);          // Y(E) = Ay cos(E - phy) - ay e
+    const double phy = atan2(c.by, c.ay);
+    if (strip_arc(clo, chi, plo, phi2)) {
         // The strip |X| < 1+k is met on a second arc, the mirror image about psi = 0.  It normally
         // lies on the far side of the orbit (Y < 0: no transit), but on a very eccentric orbit seen
         // nearly along its major axis its end next to psi = 0 can still be on the near side: a
@@ -694,8 +706,6 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
         // ay e is a sinusoid too: if its maximum over the mirror arc is not negative the window
         // becomes the hull of the two arcs (the cells in between are evaluated and come out as 1).
         const double o1 = (psi >= 0.0) ? -xlo : xhi, o2 = (psi >= 0.0) ? -xhi : xlo;
-        const double Ay = sqrt(c.ay * c.ay + c.by * c.by);
-        const double phy = atan2(c.by, c.ay);
         const double d1 = remainder(Etr + (o1 - psi) - phy, kTwoPi), span = o2 - o1;
         const bool peak = (d1 <= 0.0 && d1 + span >= 0.0) || (d1 + span >= kTwoPi);
         double s1, c1, s2, c2;
@@ -705,12 +715,55 @@ __device__ __forceinline__ void orbit_init(RowC& c, double k, double t0, double 
         if (!(Ay * cmax - c.ay * e < -1e-9 * (Ay + fabs(c.ay * e)))) {
             plo = fmin(plo, o1);
             phi2 = fmax(phi2, o2);
+            widened = true;
         }
     }
-    const double Elo = Etr + (plo - psi), Ehi = Etr + (phi2 - psi);
+    double Elo = Etr + (plo - psi), Ehi = Etr + (phi2 - psi);
     double sl, cl, sh, ch;
     sincos_red(Elo, sl, cl);
     sincos_red(Ehi, sh, ch);
+#ifndef TRX_STRIP_WINDOW
+    // From the strip to the DISC (round 6).  The strip |X| < 1 + k ignores the impact parameter: a transit's chord is
+    // shorter than the star's diameter by sqrt(1 - b^2 / (1 + k)^2), pi/4 of it on average, and every cell of the
+    // strip outside the disc was filed, planned -- a Kepler step and the node criteria, as dear as an evaluation -- and
+    // found to need nothing (a third of the planned cells of BASELINE config 1: profiles/r06/window_census.txt).
+    // On the arc, z^2 = X^2 + (Y cos i)^2 >= X^2 + (min |Y| cos i)^2, so the disc lies inside the NARROWER strip
+    // |X| < sqrt(R^2 - (min |Y| cos i)^2): a superset of the cells that see the planet, by construction.  Y is a sinusoid
+    // of E: over an arc shorter than pi its smallest value sits at an end, or at its trough when the arc holds it.  One
+    // such step from the strip's ends gets within ~(R / a)^2 of the true contacts; it is not taken when the arc is the
+    // hull of two passages, when Y is not positive over the whole arc, or when anything is NaN (every comparison false).
+    if (!widened && (phi2 - plo) < kPi) {
+        const double Yl = fma(c.ay, cl - e, c.by * sl), Yh = fma(c.ay, ch - e, c.by * sh);
+        const double d1 = remainder(Elo - phy - kPi, kTwoPi), span = Ehi - Elo;
+        const bool trough = (d1 <= 0.0 && d1 + span >= 0.0) || (d1 + span >= kTwoPi);
+        const double Ymin = trough ? fmin(fmin(Yl, Yh), -Ay - c.ay * e) : fmin(Yl, Yh);
+        if (Ymin > 0.0) {
+            const double yc = Ymin * c.cosi * (1.0 - 1e-9);
+            const double R2 = fma(-yc, yc, R * R);
+            if (R2 > 0.0) {
+                const double Rt = sqrt(R2);
+                double lo2, hi2;
+                strip_arc((c.ax * e - Rt) / A, (c.ax * e + Rt) / A, lo2, hi2);
+                // (inside the arc it came from: the narrower strip's arc around conjunction cannot reach beyond it)
+                lo2 = fmax(lo2, plo);
+                hi2 = fmin(hi2, phi2);
+                if (lo2 <= psi && psi <= hi2) {
+                    plo = lo2;
+                    phi2 = hi2;
+                    Elo = Etr + (plo - psi);
+                    Ehi = Etr + (phi2 - psi);
+                    sincos_red(Elo, sl, cl);
+                    sincos_red(Ehi, sh, ch);
+                }
+            } else if (R2 <= 0.0) {
+                // the body passes the star by: no point of the arc is on the disc (an empty window: wlo > whi)
+                c.wlo = 1e300;
+                c.whi = -1e300;
+                return;
+            }
+        }
+    }
+#endif
     const double mg = 0.5 * fabs(c.nmot * exptime) * (1.0 + 1e-9) + 1e-11;
     c.wlo = (Elo - Etr) - e * (sl - sEt) - mg;
     c.whi = (Ehi - Etr) - e * (sh - sEt) + mg;
