@@ -582,9 +582,17 @@ template <bool FREEZE = false>
 __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE, double& cE)
 {
     double rho = rcp_nr1(fma(-e, cE, 1.0));
-    double d = dM * rho;
-    if (!(fabs(d) < 0.3)) return false;
-    d = fma(-0.5 * e * sE * rho * d, d, d);
+    const double x = dM * rho;
+    if (!(fabs(x) < 0.3)) return false;
+#ifdef TRX_KEPLER_NEWTON
+    // (rounds 1-5, A/B builds: second-order start, Newton steps, settled below 1e-9 -- two to three trips per plan)
+    double d = fma(-0.5 * e * sE * rho * x, x, x);
+#else
+    // Third-order start: with sin d = d - d^3/6, cos d - 1 = -d^2/2 the equation reads d + a2 d^2 + a3 d^3 = x,
+    // a2 = e sinE rho / 2, a3 = e cosE rho / 6, whose inverse series is d = x - a2 x^2 + (2 a2^2 - a3) x^3 + O(x^4).
+    const double a2 = 0.5 * e * sE * rho, a3 = (1.0 / 6.0) * e * cE * rho;
+    double d = x * fma(x, fma(x, fma(2.0 * a2, a2, -a3), -a2), 1.0);
+#endif
     double ds = 0.0, dc = 0.0, step = 0.0;
     bool settled = false;
 #pragma unroll 1
@@ -600,22 +608,48 @@ __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE
             const double g = fma(-e, ds, d) - dM;
             const double gp = fma(-e, cE + dc, 1.0);
             // Newton on 1 / g', twice: over a step of up to 0.3 rad g' moves by up to e x 0.3, one refinement leaves
-            // rho that far off squared, and what a last step of < 1e-9 leaves behind is step x (rho's relative
-            // error) -- with one refinement up to 1e-14 in E, which a wide orbit (a / R = 30) turns into several
-            // 1e-13 of flux where the Mandel-Agol expressions are badly conditioned (z near k; found by
-            // profiles/fuzz_kernels.py, profiles/r03_fuzz.txt).  The second refinement squares it away.
+            // rho that far off squared, and what the last step leaves behind is step x (rho's relative error) -- with
+            // one refinement up to 1e-14 in E, which a wide orbit (a / R = 30) turns into several 1e-13 of flux where
+            // the Mandel-Agol expressions are badly conditioned (z near k; found by profiles/fuzz_kernels.py,
+            // profiles/r03_fuzz.txt).  The second refinement squares it away.
+#ifdef TRX_KEPLER_NEWTON
             rho = rho * fma(-gp, rho, 2.0);
             rho = rho * fma(-gp, rho, 2.0);
             step = g * rho;
             d -= step;
             settled = fabs(step) < 1e-9;
+#else
+            // (1 / g' afresh, to 2^-48: what a step leaves behind includes step x (the reciprocal's relative error), and
+            // with steps of up to 1e-6 counting as the last one, two refinements of the previous reciprocal -- 1e-4
+            // relative after a first step across e rho d ~ 0.3 -- are no longer enough: 3e-10 in flux, found by the fuzz)
+            rho = rcp_nr1(gp);
+            // Halley's step (round 6): t / (1 - t h) = t + t^2 h + O(t^3 h^2) with t = g / g' and h = g'' / (2 g') =
+            // e sin(E + d) / (2 g') -- sin(E + d) is at hand -- converges cubically: a step below 1e-6 leaves
+            // (h^2 + e rho / 6) x 1e-18 behind even at e rho = 9, where a Newton step had to be below 1e-9 for the same.
+            // With the third-order start a plan settles in ONE trip up to x ~ 0.05 (a transit of P / 60) and in two up
+            // to the 0.3 this function takes; rounds 1-5 took two and three (profiles/r06/ab_kepler.txt).
+            const double t = g * rho;
+            const double h = 0.5 * e * (sE + ds) * rho;
+            step = fma(t * t, h, t);
+            d -= step;
+            settled = fabs(step) < 1e-6;
+#endif
         }
         if (__all(settled)) break;
     }
+#ifdef TRX_KEPLER_NEWTON
     if (!(fabs(step) < 1e-7)) return false;       // (a lane that did not settle: full solve)
     const double s1 = sE + ds, c1 = cE + dc;
     sE = fma(-step, c1, s1);
     cE = fma(step, s1, c1);
+#else
+    if (!settled) return false;                   // (a lane that did not settle: full solve)
+    // (ds, dc) were evaluated one step back; the step is up to 1e-6: second-order correction (the third order is 2e-19)
+    const double s1 = sE + ds, c1 = cE + dc;
+    const double hs = 0.5 * step * step;
+    sE = fma(-hs, s1, fma(-step, c1, s1));
+    cE = fma(-hs, c1, fma(step, s1, c1));
+#endif
     return true;
 }
 
@@ -810,6 +844,7 @@ struct CellPlan {
     double sE = 0.0, cE = 1.0, Mprev = 0.0;     // eccentric-anomaly state carried along the nodes
     bool anchored = false;                       // state holds a solution (at the exposure centre)
     bool st_ok = false;                          // no limb contact within the stencil radius (cells_kernel)
+    bool lazy = false;                           // the tier has not been looked for (plan_cell<..., LAZY>): see plan_tiers
 };
 
 // th_lds: the table's radii [kTiers] and node counts [kTiers] (as doubles) in LDS, or null.  cells_kernel stages them
@@ -817,7 +852,14 @@ struct CellPlan {
 // (the compiler then parks scalars in VGPR lanes -- v_writelane / v_readlane, VALU issue both -- inside the chunk loop);
 // an LDS read at a wave-uniform or lane-chosen address costs an LDS slot, no VALU issue.
 constexpr int kTierHeadDoubles = 2 * kTiers;
-template <bool CHECK_WINDOW = true, bool FREEZE = false, bool LDS_HEAD = false>
+// LAZY (the stencil instantiation of cells_kernel, st_radius > 0): a cell that passes the test at the stencil's radius
+// will most likely take its exposure average from its neighbours' centre values and never need a tier; when every
+// active lane of the wave passes it (or is off the disc altogether) the search for the tier -- three more tests and
+// their selects, a fifth of this function -- is left out and the plan says so (CellPlan::lazy); plan_tiers() supplies
+// it for the few cells that turn out to need their own nodes after all (a chunk's first and last cells).  Passing at
+// the stencil's radius (>= 2.2 half exposures) implies passing at the smallest tier's (1.8): such a cell is never a
+// contact cell.
+template <bool CHECK_WINDOW = true, bool FREEZE = false, bool LDS_HEAD = false, bool LAZY = false>
 __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double exptime, int S,
                                               const TierHead& tt, bool use_tiers, double st_radius = 0.0,
                                               const double* th_lds = nullptr)
@@ -874,6 +916,16 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
         return G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
     };
     static_assert(kTiers == 7, "bisection over seven tiers");
+    if (LAZY && st_radius > 0.0) {
+        p.st_ok = admissible(st_radius);
+        const double tau1z = 1.5 * hx;
+        const bool off = z2 > opp2 && G >= 1.25 * fma(g2 * tau1z, tau1z, g1 * tau1z) && om * tau1z <= 0.15;
+        if (!__any(!p.st_ok && !off)) {
+            p.lazy = true;
+            if (off) p.n = 0;
+            return p;
+        }
+    }
     // (the table's entries as VALUES, read with literal indices before any choice is made: `c ? tt.radius[1] : tt.radius[5]`
     // is a choice between two ADDRESSES to the compiler, and a loop over q an indexed one -- either keeps a kernel's
     // patched local copy of its argument block (star_args, trx_kernels.hip) from being split into registers, and the
@@ -926,6 +978,48 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     const double tau1 = 1.5 * hx;
     if (z2 > opp2 && G >= 1.25 * fma(g2 * tau1, tau1, g1 * tau1) && om * tau1 <= 0.15) p.n = 0;
     return p;
+}
+
+// The tier of a cell planned with LAZY whose exposure-centre solution (p.sE, p.cE) is at hand: the same quantities and
+// the same search as plan_cell, so the same tier.  Only for cells that passed the test at the stencil's radius (a tier
+// exists).
+__device__ __forceinline__ void plan_tiers(const RowC& c, double exptime, CellPlan& p, const double* th_lds)
+{
+    const double opp = 1.0 + c.k, opp2 = opp * opp, omk = 1.0 - c.k;
+    const double rho = rcp_fast(fma(-c.e, p.cE, 1.0));
+    const double ce = p.cE - c.e;
+    const double X = fma(c.ax, ce, c.bx * p.sE), Y = fma(c.ay, ce, c.by * p.sE);
+    const double yc = Y * c.cosi;
+    const double nr = c.nmot * rho;
+    const double Xp = fma(c.bx, p.cE, -c.ax * p.sE) * nr, Yp = fma(c.by, p.cE, -c.ay * p.sE) * nr;
+    const double ycp = Yp * c.cosi;
+    const double z2 = fma(X, X, yc * yc);
+    const double g1 = fabs(2.0 * fma(X, Xp, yc * ycp));
+    const double g2 = fabs(fma(Xp, Xp, ycp * ycp) - (nr * nr) * rho * z2);
+    const double G = fmin(fabs(z2 - opp2), fabs(z2 - omk * omk));
+    const double kd = fmin(c.k, 1.0);
+    const double hx = 0.5 * fabs(exptime) * fma(0.5 * kd, kd, 1.0);
+    const double om = fabs(nr) * rho;
+    auto admissible = [&](double radius) -> bool {
+        const double tau = radius * hx;
+        return G >= 1.25 * fma(g2 * tau, tau, g1 * tau) && om * tau <= 0.15 && Y > fabs(Yp) * tau;
+    };
+    if (th_lds[kTiers + kTiers - 1] > 0.0) {
+        const bool ok3 = admissible(th_lds[3]);
+        const bool ok1 = admissible(th_lds[ok3 ? 1 : 5]);
+        const bool ok2 = admissible(th_lds[ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)]);
+        const int q = (ok3 ? (ok1 ? 0 : 2) : (ok1 ? 4 : 6)) + (ok2 ? 0 : 1);
+        if (q < kTiers) {
+            p.tier = q;
+            p.n = (int)th_lds[kTiers + q];
+        }
+    } else {
+        for (int q = kTiers - 1; q >= 0; --q) {
+            const bool ok = th_lds[kTiers + q] > 0.0 && admissible(th_lds[q]);
+            if (ok) { p.tier = q; p.n = (int)th_lds[kTiers + q]; }
+        }
+    }
+    p.lazy = false;
 }
 
 // A cell already known to need all S sub-exposures (the contact cells' second sweep): only the exposure

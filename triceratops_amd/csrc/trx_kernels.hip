@@ -293,6 +293,9 @@ __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows
 #ifndef TRX_CELLS_WAVES_PER_EU
 #define TRX_CELLS_WAVES_PER_EU 4
 #endif
+#ifndef TRX_LAZY_TIERS
+#define TRX_LAZY_TIERS 1
+#endif
 #ifndef TRX_CELLS_PAIRS
 #define TRX_CELLS_PAIRS 640
 #endif
@@ -977,6 +980,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // (not in the diagnostic instantiations that solve Kepler's equation per pair; not with one row per wave: 2000 irregular
     // stamps -0.5 %, and the stencil instantiation, which never carries, -2.3 % for the registers the code costs)
     constexpr bool kCarry = TRX_CARRY_CELLS && STEP && !LONG;
+    // (the stencil instantiation: tiers on demand, centres evaluated where they were planned -- plan_cell<LAZY>)
+    constexpr bool kLazyTiers = TRX_LAZY_TIERS && ST && STEP && LONG && !PRUNE;
     constexpr int W = cells_waves(LONG);
     const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // (scalar: so is all that follows from it)
     // shared by the workgroup's waves: node tables, atan constants, (short curves) the light curve
@@ -1375,8 +1380,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     if (LONG && sweep == 1) pl = plan_all_subexposures<PRUNE>(c, t, a.S);      // filed as such by the first sweep
                     else
 #endif
-                    pl = plan_cell<false, PRUNE, TRX_TIER_LDS(PRUNE, LONG)>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0, (ST && sweep == 0) ? st_radius : 0.0,
-                                                 thead);
+                    pl = plan_cell<false, PRUNE, TRX_TIER_LDS(PRUNE, LONG), kLazyTiers>(c, t, a.exptime, a.S, a.tiers, a.use_tiers != 0,
+                                                                                        (ST && sweep == 0) ? st_radius : 0.0, thead);
                     if (STEP && !pl.anchored && pl.n > 0) {
                         // every sub-exposure evaluated (diagnostics): the pairs still step from the centre
                         kepler_full(c.nmot * (t - c.t0) + c.Mtr, c.e, pl.sE, pl.cE);
@@ -1384,13 +1389,13 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     }
                 }
                 if (sweep == 0 && a.use_tiers) {
-                    const bool heavy = valid && pl.tier < 0 && pl.n > 0;
+                    const bool heavy = valid && !pl.lazy && pl.tier < 0 && pl.n > 0;
                     const unsigned long long mh = __ballot(heavy && owned);       // filed once, by its owner
                     if (heavy && owned) winlist[nheavy + lanes_below(mh)] = (unsigned short)rel;
                     if (heavy) { pl.n = 0; valid = false; }
                     nheavy += __popcll(mh);
                 }
-                const int tier = pl.tier;
+                int tier = pl.tier;
                 int nodes = (valid && owned) ? pl.n : 0;
                 // Centre-value stencil (LONG, dense uniform grid): a cell whose kStM neighbours on either
                 // side sit next to it in this chunk, all of them planned cells of this sweep, takes its
@@ -1430,14 +1435,55 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                     if (st) nodes = 0;
                     carry_j = j;
                     carry_ok = mok;
+                    if (kLazyTiers) {
+                        // the cells that need their own nodes after all (no neighbours on one side: a row's first and
+                        // last cells in the window): their tier now (plan_cell<LAZY>)
+                        const bool need = pl.lazy && nodes > 0;
+                        if (__any(need)) {
+                            if (need) {
+                                const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
+                                plan_tiers(c, a.exptime, pl, thead);
+                                tier = pl.tier;
+                                nodes = pl.n;
+                            }
+                        }
+                    }
+                }
+                // A chunk none of whose cells has nodes of its own -- every planned cell takes the stencil or is off the
+                // disc: three chunks in five of a row on BASELINE config 1's grid -- evaluates its centres where they
+                // were planned, lane = cell, straight from the plan's registers: no pair table, no cell state in LDS, no
+                // pair loop (its decode, its second look at the row, its Kepler step).  Same arithmetic on the same
+                // numbers: the same centre values, bit for bit.
+                const bool direct = kLazyTiers && ST && sweep == 0 && !__any(nodes > 0);
+                if (direct) {
+                    if (centre) {
+                        const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
+                        const double ce = pl.cE - c.e;
+                        const double X = fma(c.ax, ce, c.bx * pl.sE);
+                        const double Y = fma(c.ay, ce, c.by * pl.sE);
+                        const double yc = Y * c.cosi;
+                        const double z2 = fma(X, X, yc * yc);
+                        const double opp = 1.0 + c.k;
+                        double f = 1.0;
+                        if (Y >= 0.0 && z2 < opp * opp) {
+                            const Limb L{c.cle, c.cld, c.ced};
+                            f = disc_flux<FP32, TRX_ATAN_TAB(PRUNE, LONG)>(sqrt_fast(z2), c.k, L, atab);
+                        } else if (z2 != z2) {
+                            f = z2;
+                        }
+                        ss.fc[kStM + lane] = f;
+                    }
+                    wave_sync();
                 }
                 if (kCarry) wave_sync();        // (the carried cells' reads of the previous chunk's slots are through)
-                cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
-                cs.t[lane] = t;
-                cs.facc[lane] = 0.0;
-                cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u) |
-                                (valid ? 0x20000u : 0u) | ((unsigned)pl.n << 18);
-                if (kCarry) cs.rel[lane] = (unsigned short)rel;
+                if (!direct) {
+                    cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
+                    cs.t[lane] = t;
+                    cs.facc[lane] = 0.0;
+                    cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u) |
+                                    (valid ? 0x20000u : 0u) | ((unsigned)pl.n << 18);
+                    if (kCarry) cs.rel[lane] = (unsigned short)rel;
+                }
                 TRX_TOCK(2, t_plan);
                 TRX_TICK(t_a);
                 // The (cell, node) pairs of the chunk, cell by cell, dealt to all lanes: a pass
@@ -1447,7 +1493,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                 const int ncells = __popcll(__ballot(nodes > 0 || (ST && centre)));
                 int per = ncells > 0 ? kCellsPairs / ncells - (ST ? 1 : 0) : kCellsPairs;
                 per = per > 1000 ? 1000 : (per < 1 ? 1 : per);
-                for (int s0 = 0; __any(s0 < nodes || (ST && s0 == 0 && centre)); s0 += per) {
+                for (int s0 = 0; !direct && __any(s0 < nodes || (ST && s0 == 0 && centre)); s0 += per) {
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
                     TRX_CENSUS_ADD(kCenPass, 1);
@@ -1540,7 +1586,8 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
                         for (int i = -kStM; i <= kStM; ++i) fsum = fma(ss.stw[i + kStM], 1.0 - ss.fc[kStM + lane + i], fsum);
                     }
                     // the cell's flux deficit: nothing, 1 - mean of the S sub-exposures, or the Gauss rule's weighted sum
-                    const double deficit = (pl.n == 0) ? 0.0 : ((tier < 0) ? 1.0 - fsum / a.dS : fsum);
+                    // (a stencil cell's sum is one of deficits like a Gauss rule's -- and its tier may never have been looked for)
+                    const double deficit = (pl.n == 0) ? 0.0 : ((ST && st) ? fsum : ((tier < 0) ? 1.0 - fsum / a.dS : fsum));
                     const RowC& cd = rows[rr];
                     const double m = fma(-deficit, cd.rdil, 1.0);    // dilution(s), :352-357, :427-438
                     if (MODE == MODE_GRID) {
