@@ -316,7 +316,23 @@ typedef struct {
     int want_prior;              /* lnprior_companion enters the evidence (P, S, D, B scenarios) */
     double* out;
     int* out_flag;
+    /* The reference's table of the best draws (marginal_likelihoods.py:152-171: `(-lnL).argsort()[:100]` and the 14
+     * columns gathered at those draws), for callers of lnZ_* themselves (calc_probs reads row 0 only: leave table_rows
+     * at 0 or 1).  table_rows = K > 1: `table` receives, per branch b, TRX_TABLE_BRANCH(K) doubles at
+     * table + b * TRX_TABLE_BRANCH(K): column c of trx_draw_args.cols at [c * (K + 1), c * (K + 1) + K) -- row j = the
+     * masked draw with the j-th smallest chi^2 (NaN last; exact ties: the earlier draw first) --, then at
+     * [14 * (K + 1), 15 * (K + 1)) the K + 1 smallest chi^2/2 values themselves (a caller that must reproduce numpy's
+     * order among exact ties can see from them whether there are any).  Fewer than K masked draws: the rows beyond
+     * them hold draws 0, 1, 2 ... (of all N draws, whatever their mask), as the reference's argsort of equal -inf
+     * log-likelihoods may.  Such a call evaluates EVERY masked draw to the end (TRX_FLAG_FULL_EVALUATION is implied:
+     * the bounded evaluation leaves only the best draw and the evidence exact) and is enqueued on its own, not in a
+     * launch chain.  `table`: pinned host memory (written by the device, valid once the stream has passed the call)
+     * or device memory.  K <= TRX_TABLE_MAX_ROWS. */
+    int table_rows;
+    double* table;
 } trx_scenario_args;
+#define TRX_TABLE_MAX_ROWS 127
+#define TRX_TABLE_BRANCH(K) (15 * ((K) + 1))
 int trx_scenario_evidence(const trx_scenario_args* args, void* stream);
 /* The same call without the final synchronisation: everything is enqueued on `stream` and the function
  * returns.  args->out / args->out_flag are ignored; the record arrives in

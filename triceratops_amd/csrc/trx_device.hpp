@@ -1151,7 +1151,8 @@ constexpr int kScenTies = 16, kScenStatus = 17;
 struct ScenFinal {
     const int* idx;                   // the branch's list of masked draws
     const double* cols;               // [ncol][N]
-    const double* cols0;              // dense: [ncol] draw 0's columns (no draw passed the mask)
+    const double* cols0;              // dense: [ncol][cols0_stride] columns of draw 0 (the record when no draw passed the mask)
+    int cols0_stride;                 // 0 or 1: [ncol]; K: the block also holds draws 1 .. K - 1 (a table's spare rows)
     int dense;                        // the masked draws' columns sit densely in `cols` (compact_fill_kernel): row r at
                                       // position r (branch 1: N - 1 - r); 0: at their draw index idx[r]
     long N, n_total;
@@ -1205,7 +1206,7 @@ __device__ __forceinline__ void scenario_final(const ScenFinal& f, const double*
     else lnz = log(t.s) + t.m - log((double)f.n_total);           // :51
     if (f.dense) {
         const long best = f.branch ? f.N - 1 - bi : bi;
-        if (lane < f.ncol) f.res[lane] = (bi >= 0) ? f.cols[(long)lane * f.N + best] : f.cols0[lane];
+        if (lane < f.ncol) f.res[lane] = (bi >= 0) ? f.cols[(long)lane * f.N + best] : f.cols0[(long)lane * (f.cols0_stride > 1 ? f.cols0_stride : 1)];
     } else {
         const long best = (bi >= 0) ? (long)f.idx[bi] : 0;
         if (lane < f.ncol) f.res[lane] = f.cols[(long)lane * f.N + best];

@@ -731,7 +731,8 @@ __device__ __forceinline__ void fill_wave_sync()
 template <int W>
 __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long per, int groups, int gper,
                                                   const int* __restrict__ blk_cnt, int* __restrict__ idx0,
-                                                  int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0)
+                                                  int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0,
+                                                  const int n_pad = 1)
 {
     __shared__ Tables T;
     __shared__ int hits_all[W][kFillList];
@@ -763,7 +764,7 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
     const long N = a.N;
     const long end = ((long)g1 * per < N) ? (long)g1 * per : N;
     int nh = 0;
-    bool zero_done = !first;
+    int pad_next = first ? 0 : n_pad;      // stand-in draws 0 .. n_pad - 1 still to be filled (the first wave's job)
     long i0 = (long)g0 * per;
     // (ONE call site of draw_one: with two inlined copies of the draw in one kernel the compiler once moved the
     // 1.2 KB argument block to scratch memory)
@@ -784,10 +785,15 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
             at += __popcll(m);
             nh += __popcll(m);
         }
-        if (i0 >= end && !zero_done) {     // draw 0 once more, for the stand-in record (position -1: cols0)
-            if (lane == 0) { hits[nh] = 0; hpos[nh] = -1; }
-            ++nh;
-            zero_done = true;
+        if (i0 >= end && pad_next < n_pad) {
+            // draw 0 once more, for the stand-in record (position -1: cols0) -- and, when a table of the K best draws is
+            // asked for, draws 1 .. K - 1 too (positions -2 ...: the rows of a table that has fewer masked draws than rows)
+            int add = n_pad - pad_next;
+            add = add < kFillList - nh ? add : kFillList - nh;
+            add = add < 64 ? add : 64;
+            if (lane < add) { hits[nh + lane] = (int)((long)(pad_next + lane) % N); hpos[nh + lane] = -1 - (pad_next + lane); }
+            nh += add;
+            pad_next += add;
         }
         if (nh == 0) break;
         fill_wave_sync();
@@ -796,9 +802,9 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
             bool h0, h1;
             const int pos = hpos[lane];
             const long at_col = br ? (N - 1 - (long)pos) : (long)pos;
-            double* col_at = (pos < 0) ? cols0 : a.cols + at_col;
+            double* col_at = (pos < 0) ? cols0 + (-1 - pos) : a.cols + at_col;
             double* prior_at = (pos < 0 || !a.lnprior) ? nullptr : a.lnprior + at_col;
-            draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1, col_at, (pos < 0) ? 1L : N, prior_at);
+            draw_one<2>(a, T, (long)hits[lane], parallel, h0, h1, col_at, (pos < 0) ? (long)n_pad : N, prior_at);
         }
         fill_wave_sync();
         int carry = 0, carry_pos = 0;
@@ -812,9 +818,10 @@ __device__ __forceinline__ void compact_fill_body(const trx_draw_args& a, long p
 
 __global__ __launch_bounds__(64) void compact_fill_kernel(trx_draw_args a, long per, int groups, int gper,
                                                           const int* __restrict__ blk_cnt, int* __restrict__ idx0,
-                                                          int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0)
+                                                          int* __restrict__ idx1, long* __restrict__ n_out, double* __restrict__ cols0,
+                                                          int n_pad)
 {
-    compact_fill_body<1>(a, per, groups, gper, blk_cnt, idx0, idx1, n_out, cols0);
+    compact_fill_body<1>(a, per, groups, gper, blk_cnt, idx0, idx1, n_out, cols0, n_pad);
 }
 
 // chain: grid = (draw workgroups / kFillWaves, 2 branches, calls); a planet call has one branch and one draw workgroup per wave
@@ -890,14 +897,14 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
 // reference's priors -- two waves of fills): 27-39 us for the planet scenarios (profiles/r04_j_draw_kernel.txt; with
 // 2048 draw workgroups of 512 draws it was 23-31, and the draw kernel 4 us slower: trx_internal.hpp).
 int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
-                      double* cols0, hipStream_t st)
+                      double* cols0, hipStream_t st, int n_pad)
 {
-    if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || !cols0 || groups < 1) return TRX_ERR_ARG;
+    if (a.N < 1 || !idx0 || !n_dev || !blk_cnt || !cols0 || groups < 1 || n_pad < 1) return TRX_ERR_ARG;
     // (binary scenarios: two branches scan the same draws, half as many masked draws each -- two draw workgroups per wave)
     const int gper = a.planet ? 1 : 2;
     const int chunks = (groups + gper - 1) / gper;
     hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks, a.planet ? 1u : 2u), dim3(64), 0, st, a, per, groups, gper,
-                       blk_cnt, idx0, idx1, n_dev, cols0);
+                       blk_cnt, idx0, idx1, n_dev, cols0, n_pad);
     return hipGetLastError() == hipSuccess ? TRX_OK : TRX_ERR_HIP;
 }
 

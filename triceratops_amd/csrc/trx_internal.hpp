@@ -108,6 +108,7 @@ struct ChainFill {
     long* n_dev;
     double* cols0;         // [ncol]: draw 0's columns (the stand-in for the best draw of a branch no draw passed)
 };
+// (trx_scenario_enqueue with a table of K best draws: cols0 is [ncol][n_pad], the columns of draws 0 .. n_pad - 1)
 int draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab, int n_calls, int* blk_cnt, const ChainFill* fills,
                long* per_out, int* groups_out, hipStream_t st);
 
@@ -125,7 +126,7 @@ int draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* group
 // behind it: the ordered lists of the draws that passed a mask (idx0 / idx1, their lengths in n_dev[0 / 1]) and the
 // columns and the prior of those draws (and of draw 0)
 int compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
-                 double* cols0, hipStream_t st);
+                 double* cols0, hipStream_t st, int n_pad = 1);
 
 // fail() of trx_kernels.hip for the other translation units (thread-local message of trx_last_error)
 int fail_hip(hipError_t e);

@@ -64,6 +64,95 @@ struct Arena {
 
 constexpr int kLmeParts = 2048;            // lme_blocks() never exceeds it
 
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's table of the K best draws of a branch (marginal_likelihoods.py:152-171): the masked draws with the K
+// smallest chi^2 (NaN last; exact ties: the earlier draw first), in that order, and the columns gathered at them.
+// Not a hot path -- calc_probs keeps the best draw only, which the reduction's final stage already finds -- but what a
+// caller of lnZ_* itself gets back, and until round 6 only the torch-operator chain could produce it (torch.topk).
+// ONE workgroup streams the branch's chi^2 values through LDS, 2048 - 128 new ones at a time next to the 128 best so
+// far, and sorts the 2048 (bitonic, (value, row) keys) whenever a new one can enter the best 128; then thread j
+// gathers row j's columns -- or, past the masked count, the columns of draw j - count from the stand-in block
+// compact_fill_kernel filled (the reference's table then holds draws of log-likelihood -inf in argsort's order of
+// equals; the operator chain pads with draws 0, 1, 2 ...: so does this).
+constexpr int kTableKeep = 128, kTableTile = 2048;
+static_assert(TRX_TABLE_MAX_ROWS + 1 <= kTableKeep, "one more than the table's rows is kept (the caller's tie check)");
+struct TableArgs {
+    const double* h;          // chi^2/2 of the masked draws, in list order
+    const long* n_dev;        // their number
+    const double* cols;       // [ncol][N], dense (row r at position r; the twin branch: N - 1 - r)
+    const double* cols_pad;   // [ncol][K]: draws 0 .. K - 1
+    long N;
+    int ncol, branch, K;
+    double* table;            // this branch's TRX_TABLE_BRANCH(K) doubles
+};
+
+__device__ __forceinline__ bool table_before(double a, int ia, double b, int ib)
+{
+    const bool na = a != a, nb = b != b;
+    if (na != nb) return nb;                 // NaN last (numpy's argsort, torch.topk(largest=False))
+    if (!na && a != b) return a < b;
+    return ia < ib;
+}
+
+__global__ __launch_bounds__(256) void table_kernel(TableArgs t)
+{
+    __shared__ double val[kTableTile];
+    __shared__ int row[kTableTile];
+    __shared__ int any_new;
+    const long n = *t.n_dev;
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < kTableKeep; i += 256) { val[i] = NAN; row[i] = 0x7fffffff; }      // (sorts behind every real entry)
+    __syncthreads();
+    for (long base = 0; base < n || base == 0; base += kTableTile - kTableKeep) {
+        if (tid == 0) any_new = 0;
+        __syncthreads();
+        const double worst = val[kTableKeep - 1];
+        const int wrow = row[kTableKeep - 1];
+        bool mine = false;
+        for (int i = kTableKeep + tid; i < kTableTile; i += 256) {
+            const long r = base + (i - kTableKeep);
+            const bool in = r < n;
+            const double v = in ? t.h[r] : NAN;
+            val[i] = v;
+            row[i] = in ? (int)r : 0x7fffffff;
+            mine = mine || (in && table_before(v, (int)r, worst, wrow));
+        }
+        if (mine) any_new = 1;
+        __syncthreads();
+        if (any_new) {
+            for (int k = 2; k <= kTableTile; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < kTableTile; i += 256) {
+                        const int p = i ^ j;
+                        if (p > i) {
+                            const bool up = (i & k) == 0;
+                            const double a = val[i], b = val[p];
+                            const int ia = row[i], ib = row[p];
+                            if (table_before(b, ib, a, ia) == up) { val[i] = b; row[i] = ib; val[p] = a; row[p] = ia; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        if (n == 0) break;
+    }
+    const int K = t.K;
+    if (tid <= K) {
+        const bool real = row[tid] != 0x7fffffff;
+        // the K + 1 smallest values (NaN where there is no such draw)
+        t.table[14 * (K + 1) + tid] = real ? val[tid] : NAN;
+        if (tid < K) {
+            const long r = row[tid];
+            const long pos = t.branch ? t.N - 1 - r : r;
+            const long pad = ((long)tid - n) % (t.N > 0 ? t.N : 1);           // draw index of a spare row (tid >= n there)
+            for (int c = 0; c < t.ncol; ++c)
+                t.table[c * (K + 1) + tid] = real ? t.cols[(long)c * t.N + pos] : t.cols_pad[(long)c * K + (pad < K ? pad : 0)];
+        }
+    }
+}
+
 int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
 {
     trx_draw_args d = *s->draw;
@@ -71,6 +160,11 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
     if (N < 1 || N > 0x7fffffffL) return TRX_ERR_ARG;
     const int planet = d.planet != 0;
     const int ncol = planet ? 11 : 14, nbr = planet ? 1 : 2;
+    // a table of the K best draws (include/trx.h): every masked draw evaluated to the end, K stand-in draws
+    const int K = s->table_rows > 1 ? s->table_rows : 0;
+    if (K > TRX_TABLE_MAX_ROWS || (K && !s->table)) return TRX_ERR_ARG;
+    const int n_pad = K ? K : 1;
+    const int flags = s->flags | (K ? TRX_FLAG_FULL_EVALUATION : 0);
     trx::StreamLock turn(st);              // the whole call is enqueued back to back on the stream's scratch
 
     // Where the record goes: straight into the caller's buffer when the device can write there (pinned host memory:
@@ -88,7 +182,8 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
     const size_t o_state = A.reserve(trx::kScratchZeroed);     // persistent: finished-block counter, the draw kernel's flag
     const size_t o_cols = A.reserve(sizeof(double) * ncol * N), o_mask = A.reserve(N), o_mask2 = A.reserve(planet ? 0 : N),
                  o_prior = A.reserve(s->want_prior ? sizeof(double) * N : 0),
-                 o_n = A.reserve(2 * sizeof(long)), o_cols0 = A.reserve(sizeof(double) * 16),
+                 o_n = A.reserve(2 * sizeof(long)), o_cols0 = A.reserve(sizeof(double) * 16 * n_pad),
+                 o_table = A.reserve(K ? sizeof(double) * 2 * TRX_TABLE_BRANCH(K) : 0),
                  o_res = A.reserve(sizeof(double) * (2 * TRX_SCENARIO_OUT + 1)),
                  o_ws = A.reserve(sizeof(double) * 2 * 3 * kLmeParts), o_pv = A.reserve(sizeof(double) * 2 * kLmeParts),
                  o_pi = A.reserve(sizeof(long) * 2 * 2 * kLmeParts), o_cnt = A.reserve(sizeof(int) * 2 * trx::kDrawMaxGroups),
@@ -114,19 +209,30 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
         (void)hipMemsetAsync(state, 0, trx::kScratchZeroed, st);
         return rc;
     };
-    if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, A.at<double>(o_cols0), st)) return bail(rc);
+    if (int rc = trx::compact_fill(d, per, groups, A.at<int>(o_cnt), idx[0], idx[1], n_dev, A.at<double>(o_cols0), st, n_pad))
+        return bail(rc);
+    double* table_dev = nullptr;           // where the device writes the table: the caller's buffer if it can
+    if (K) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, s->table) == hipSuccess && attr.devicePointer &&
+            (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice))
+            table_dev = static_cast<double*>(attr.devicePointer);
+        else
+            (void)hipGetLastError();
+    }
     if (trx::knob_poison())          // tests: an unwritten row must show (include/trx_debug.h)
         for (int b = 0; b < nbr; ++b) TRXS_HIP(hipMemsetAsync(h[b], 0, sizeof(double) * (size_t)N, st));
     for (int b = 0; b < nbr; ++b) {
         const int model = planet ? TRX_MODEL_TP : (b ? TRX_MODEL_EB_TWIN : TRX_MODEL_EB);
         const double* bounds = nullptr;
-        if (int rc = trx::lnl_draws(model, s->flags, s->time, s->flux, s->n_time, s->sigma, d.cols, N, n_dev + b, idx[b], N,
+        if (int rc = trx::lnl_draws(model, flags, s->time, s->flux, s->n_time, s->sigma, d.cols, N, n_dev + b, idx[b], N,
                                     b, s->exptime, s->nsupersample, h[b], d.lnprior, s->lnsigma, &bounds, st))
             return bail(rc);
         trx::ScenFinal fin{};
         fin.idx = idx[b];
         fin.cols = d.cols;
         fin.cols0 = A.at<double>(o_cols0);
+        fin.cols0_stride = n_pad;
         fin.dense = 1;
         fin.N = N;
         fin.n_total = N;
@@ -140,7 +246,18 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
                                     A.at<double>(o_ws) + (size_t)b * 3 * kLmeParts, A.at<double>(o_pv) + (size_t)b * kLmeParts,
                                     A.at<long>(o_pi) + (size_t)b * 2 * kLmeParts, bounds, fin, st))
             return bail(rc);
+        if (K) {
+            TableArgs t{};
+            t.h = h[b]; t.n_dev = n_dev + b; t.cols = d.cols; t.cols_pad = A.at<double>(o_cols0); t.N = N;
+            t.ncol = ncol; t.branch = b; t.K = K;
+            t.table = (table_dev ? table_dev : A.at<double>(o_table)) + (size_t)b * TRX_TABLE_BRANCH(K);
+            hipLaunchKernelGGL(table_kernel, dim3(1), dim3(256), 0, st, t);
+            if (hipGetLastError() != hipSuccess) return bail(TRX_ERR_HIP);
+        }
     }
+    if (K && !table_dev)
+        TRXS_HIP(hipMemcpyAsync(s->table, A.at<double>(o_table), sizeof(double) * (size_t)nbr * TRX_TABLE_BRANCH(K),
+                                hipMemcpyDefault, st));
     if (!rec_dev)
         TRXS_HIP(hipMemcpyAsync(out_host, res, sizeof(double) * (2 * TRX_SCENARIO_OUT + 1), hipMemcpyDeviceToHost, st));
     return TRX_OK;
@@ -259,6 +376,7 @@ int enqueue_chain(const trx_scenario_args* calls, const int* which, int n, doubl
             f.idx = c.src_idx;
             f.cols = d.cols;
             f.cols0 = A.at<double>(co[i].cols0);
+            f.cols0_stride = 1;
             f.dense = 1;
             f.N = N;
             f.n_total = N;
@@ -334,9 +452,10 @@ extern "C" int trx_star_enqueue(const trx_scenario_args* calls, int n_calls, dou
         hipStream_t st = static_cast<hipStream_t>(streams[i]);
         int which[trx::kChainMaxCalls];
         int n = 0, nbr = 0;
-        if (chain_enabled() && trx::lnl_chain_applicable(calls[i].flags, calls[i].n_time, calls[i].draw->N, calls[i].nsupersample)) {
+        if (chain_enabled() && calls[i].table_rows <= 1 &&
+            trx::lnl_chain_applicable(calls[i].flags, calls[i].n_time, calls[i].draw->N, calls[i].nsupersample)) {
             for (int j = i; j < n_calls && n < trx::kChainMaxCalls; ++j) {
-                if (streams[j] != streams[i] || !chain_compatible(calls[i], calls[j])) break;
+                if (streams[j] != streams[i] || calls[j].table_rows > 1 || !chain_compatible(calls[i], calls[j])) break;
                 const int add = calls[j].draw->planet ? 1 : 2;
                 if (nbr + add > trx::kChainMaxBranchesHost) break;
                 if ((double)(n + 1) * (double)calls[i].draw->N > draw_budget && n > 0) break;

@@ -30,6 +30,7 @@ N_BEST = ml.N_BEST
 # evaluates the units of a calc_probs with the device generator, which turns the top-101 selection
 # (a device sort, ~15 launches per branch) into one argmin.  Direct lnZ_* calls keep 100.
 TABLE_ROWS = N_BEST
+TABLE_MAX_ROWS = 127       # TRX_TABLE_MAX_ROWS (include/trx.h)
 # True: with the device generator (set_sampling("device")) the random numbers are made inside the
 # draw kernel (Philox4x32-10 keyed by one 62-bit seed per call taken from torch's CPU generator, so
 # torch.manual_seed reproduces a run); False: torch's device generator fills staged arrays
@@ -105,7 +106,13 @@ class ScenarioArgs(ctypes.Structure):
                 ("n_time", ctypes.c_int), ("nsupersample", ctypes.c_int),
                 ("sigma", ctypes.c_double), ("lnsigma", ctypes.c_double), ("exptime", ctypes.c_double),
                 ("flags", ctypes.c_int), ("want_prior", ctypes.c_int),
-                ("out", ctypes.POINTER(ctypes.c_double)), ("out_flag", ctypes.POINTER(ctypes.c_int))]
+                ("out", ctypes.POINTER(ctypes.c_double)), ("out_flag", ctypes.POINTER(ctypes.c_int)),
+                ("table_rows", ctypes.c_int), ("table", _vp)]
+
+
+def _table_branch(K):
+    """TRX_TABLE_BRANCH(K): doubles of one branch's table (include/trx.h)"""
+    return 15 * (K + 1)
 
 
 SCENARIO_OUT = 18      # TRX_SCENARIO_OUT
@@ -149,9 +156,10 @@ RECORD = 2 * SCENARIO_OUT + 1      # doubles per call: two branch records + the 
 class Pending:
     """one trx_scenario_enqueue call whose record has not been read yet"""
 
-    def __init__(self, scen, out, stream, keep, ncol, n_time, is_host=False):
+    def __init__(self, scen, out, stream, keep, ncol, n_time, is_host=False, table=None, table_rows=0):
         self.scen, self.out, self.stream, self.keep, self.ncol, self.n_time = scen, out, stream, keep, ncol, n_time
         self.is_host = is_host
+        self.table, self.table_rows = table, table_rows        # pinned [2][15][K + 1] block of a call with a table
 
     def result(self):
         """the call's result dict(s); the stream must have been synchronised"""
@@ -167,12 +175,17 @@ class Pending:
             return self.scen.run_operator_chain(self.is_host, ncol)
         self.keep = None
         res = []
+        K = self.table_rows
         for b in range(1 if planet else 2):
             row = rec[b * SCENARIO_OUT:(b + 1) * SCENARIO_OUT]
             n = int(row[ncol + 1])
             with _stats_lock:
                 _lib.count_launch(n, self.n_time)
-            res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
+            if K > 1:
+                blk = self.table.numpy()[b].reshape(15, K + 1)
+                res.append(self.scen._table(blk[:ncol, :K].copy(), float(row[ncol]), b == 1))
+            else:
+                res.append(self.scen._table(row[:ncol].reshape(ncol, 1).copy(), float(row[ncol]), b == 1))
         return res[0] if planet else (res[0], res[1])
 
 
@@ -186,6 +199,17 @@ class Pending:
         if not isinstance(dp.RNG, dp.NumpyStreamRng) or self.scen.philox:
             return False
         nbr = 1 if self.scen.a.planet else 2
+        K = self.table_rows
+        if K > 1:
+            # a table of the K best draws: the reference's order needs the K + 1 smallest chi^2 to be finite and
+            # strictly increasing, and more than K masked draws (the operator chain's own rule, _best below: anything
+            # else goes through numpy's argsort on the host)
+            for b in range(nbr):
+                n = int(rec[b * SCENARIO_OUT + self.ncol + 1])
+                hv = self.table.numpy()[b].reshape(15, K + 1)[14]
+                if n <= K or not (np.isfinite(hv[-1]) and np.all(hv[1:] > hv[:-1])):
+                    return True
+            return False
         return any(rec[b * SCENARIO_OUT + SCEN_TIES] > 1.0 for b in range(nbr))
 
 
@@ -711,7 +735,11 @@ class _Scenario:
         # production chain -- trx_star_enqueue, bounded evaluation -- on the reference's draws
         # (tests/test_gpu_production_pin.py).  The best draw is the FIRST of equal minima (numpy's argmin); the
         # reference's argsort may order exact ties differently (the operator chain below reproduces that too).
-        if NATIVE and TABLE_ROWS == 1 and DUMP is None and _lib.TRACE is None:
+        # A direct lnZ_* call (TABLE_ROWS = 100, marginal_likelihoods.py:152-171) takes the library's chain too, since
+        # round 6: the table of the K best draws is selected and gathered on the device (trx_scenario_args.table_rows;
+        # every masked draw evaluated to the end).  The operator chain below remains as the cross-check, the path of the
+        # dump / trace hooks, and the replay of exact ties in the seeded numpy modes.
+        if NATIVE and DUMP is None and _lib.TRACE is None and TABLE_ROWS <= TABLE_MAX_ROWS:
             return self._run_native(is_host, ncol)
         return self.run_operator_chain(is_host, ncol)
 
@@ -777,7 +805,11 @@ class _Scenario:
         sa.want_prior = int(self.want_prior)
         out, deferred = _record_slot()
         stream = torch.cuda.current_stream(dev)
-        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time, is_host)
+        table, K = None, int(TABLE_ROWS)
+        if K > 1:
+            table = torch.empty((2, _table_branch(K)), dtype=F64).pin_memory()
+            sa.table_rows, sa.table = K, table.data_ptr()
+        pend = Pending(self, out, stream, self.keep + [self.time, self.flux], ncol, sa.n_time, is_host, table, K if K > 1 else 0)
         self.keep = []
         if deferred and getattr(_tls, "batch", None) is not None:
             _tls.batch.append((sa, out, stream, dev))      # (sa.draw points at self.a: alive in the Pending)
