@@ -595,6 +595,8 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
     triceratops_amd.set_sampling("device")
     if fp32:
         triceratops_amd.set_precision("fp32")
+    # (a process of its own: the collector's permanent generation may be used -- opt-in since round 6, sharding.freeze_gc)
+    sharding.freeze_gc = True
     try:
         tri = os.path.join(GOLD, "trilegal_synth.csv")
         cc = os.path.join(GOLD, "contrast_curve_synth.csv")

@@ -439,6 +439,11 @@ __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.
 #define TRX_PILOT_ROWS 1024
 #endif
 constexpr long kPilotRows = TRX_PILOT_ROWS;
+// rows per wave of the pilot of a split launch (batches of short light curves)
+#ifndef TRX_PILOT_B
+#define TRX_PILOT_B 1
+#endif
+constexpr int kPilotB = TRX_PILOT_B;
 // Light curves shorter than this are evaluated in full: with fewer than three stamps per probe cell there is nothing to
 // probe.  (Until the fuzz of profiles/fuzz_bounded.py such a launch still ran the passes with a probe stride of 1: the
 // probe pass then declined to probe while the third pass waited for its list -- rows behind the pilot were never
@@ -1084,7 +1089,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
         if (!LONG && (a.part == 3 || (a.part == 2 && rlist))) B = listed_pass_rows(a, row1 - row0, a.part);
         // the pilot's rows one per wave: six per wave were 683 waves on 256 CUs for 4096 rows, each a serial chain of a
         // whole batch -- 108 us before the launch proper could start (TOI-465.01, 100 points); short waves fill the chip
-        if (!LONG && a.part == 1 && a.split) B = 1;
+        if (!LONG && a.part == 1 && a.split) B = kPilotB < Bl ? kPilotB : Bl;
         nbatch = (row1 - row0 + B - 1) / B;
     }
     // probing pays when many rows lie far above the best (pilot_stats_kernel's verdict; the pilot never probes, nor
@@ -1750,7 +1755,7 @@ __device__ __forceinline__ void cells_entry(const RowsArgs& a)
         if (PRUNE && a.part) {
             const long np = nd < kPilotRows ? nd : kPilotRows;
             rows_here = a.part == 1 ? np : nd - np;
-            if (!LONG && a.part == 1 && a.split) B = 1;
+            if (!LONG && a.part == 1 && a.split) B = kPilotB < a.B ? kPilotB : a.B;
             if (!LONG && a.part == 2 && a.split) {
                 // (the probe pass: the rows depth_screen_kernel listed -- none when nothing is probed)
                 rows_here = a.rowc[nd * kRowDoubles + kHdrProbe] != 0.0 ? (long)*a.probe_count : 0;
@@ -2710,7 +2715,8 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     {
         // pilot rows (evaluated to the end; first values of the running bounds)
         const long np = a.n < kPilotRows ? a.n : kPilotRows;
-        const long pilot_batches = (long_rows || split) ? np : (np + a.B - 1) / a.B;      // (split: one pilot row per wave)
+        const int pilot_B = kPilotB < a.B ? kPilotB : a.B;
+        const long pilot_batches = long_rows ? np : (split ? (np + pilot_B - 1) / pilot_B : (np + a.B - 1) / a.B);   // (split: kPilotB pilot rows per wave)
         const long pilot_groups = (pilot_batches + cells_waves(long_rows) - 1) / cells_waves(long_rows);
         P.grid_pilot = (unsigned)(8 * ((pilot_groups + 7) / 8));
         P.passes = a.n_dev || a.n > kPilotRows;

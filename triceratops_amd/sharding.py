@@ -55,12 +55,39 @@ last_seed_bases = None
 last_share = {"calls": [0], "stars": [0], "jobs": [0]}
 last_own_jobs = set()
 _warned_bases = False
-# True: the first device pass calls gc.freeze() once (see _run_units); set to False to leave the collector alone
-freeze_gc = True
+# Opt-in (advisor, round 5): True makes the first device pass call gc.freeze() once -- every object alive then moves to
+# the collector's permanent generation, so that the full collection which follows a held-off pass looks at the pass's own
+# objects only (a 64-target step lost 75 ms to one every fourth step, profiles/r05/gc_pause.txt).  freeze() is for good:
+# cyclic garbage that forms LATER among the frozen objects is never reclaimed until release() (gc.unfreeze()), which a
+# long-lived service may not want decided for it -- so the default leaves the collector's generations alone (bench.py
+# and TRX_FREEZE_GC=1 switch it on).  Either way the collector is held off (gc.disable(), process-wide: it affects the
+# caller's other threads too) only while a pass enqueues and waits, and is switched back on afterwards.
+freeze_gc = os.environ.get("TRX_FREEZE_GC", "0") == "1"
 _gc_frozen = False
-# The library keeps ~0.36 GB of scratch per stream per 1e6 draws; the streams of one pass are capped so that
-# their scratch together stays near this many draws' worth (6 streams at N = 1e6, 2 at N >= 3e6)
-scratch_budget_draws = 6_000_000
+# Device scratch of one stream of a pass (include/trx.h): a launch chain of c calls holds c x (~0.36 GB of draw-side
+# buffers + ~0.16 GB of likelihood scratch per branch, 1.5 branches a call on average) per 1e6 draws -- c = chain_calls
+# (12), or fewer when TRX_CHAIN_DRAWS (2.5e7 draws' worth) bounds the chain: ~7 GB per stream at N = 1e6, ~15 GB at
+# N = 2-3e6 (advisor, round 5: the round-4 figure of 0.36 GB per stream predates the chains).  The streams of a pass
+# are capped so that their scratch together stays near this many bytes: 6 streams at N = 1e6, 3 at 3e6, 2 from ~5e6 on.
+# A sixth of an MI355X's 288 GB by default; several ranks sharing one device should divide it (TRX_SCRATCH_GB).
+scratch_budget_bytes = float(os.environ.get("TRX_SCRATCH_GB", "48")) * 1e9
+
+
+def stream_scratch_bytes(n_draws):
+    """estimate of the library's scratch per stream for calls of n_draws draws (see scratch_budget_bytes)"""
+    per_call = (0.36e9 + 1.5 * 0.16e9) * n_draws / 1e6
+    calls = max(1.0, min(float(chain_calls), 2.5e7 / max(n_draws, 1)))
+    return calls * per_call
+
+
+def release():
+    """gives back what a pass with freeze_gc kept: the collector's permanent generation is thawed (gc.unfreeze()) and
+    the next device pass freezes afresh if freeze_gc is still set"""
+    import gc
+    global _gc_frozen
+    if _gc_frozen:
+        gc.unfreeze()
+        _gc_frozen = False
 
 # relative cost of a unit by its drop key: EB calls evaluate two branches plus the 25-point
 # secondary-eclipse scan; companion/background hosts add per-draw stellar relations
@@ -317,7 +344,7 @@ def _run_units(units, live, owner, base, dist, world, rank, verbose, as_rows=Fal
         import torch
         device = torch.cuda.current_device()
         n_draws = max([units[k][7] for k in mine_k if len(units[k]) > 7] + [1])
-        cap = max(2, int(scratch_budget_draws // n_draws))
+        cap = max(2, int(scratch_budget_bytes // stream_scratch_bytes(n_draws)))
         pool = _worker_streams(device, max(1, min(streams, cap, len(mine_k))))
         torch.cuda.current_stream().synchronize()    # inputs staged on the caller's stream
         _fused.begin_deferred(len(mine_k))
