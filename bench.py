@@ -696,7 +696,7 @@ def triceratops_amd_hw_queues():
 def batch_object(ctx, steps=3, warmup=2):
     """`batch` object of the grid-mode line: the configs[3] strong-scaling step measured in the same job
     (two untimed steps first: the second step of a process still builds its argument blocks ~10 % slower than the
-    fourth, profiles/r05_o_batch_timing.txt)"""
+    fourth, profiles/r05/o_batch_timing.txt)"""
     args = ctx["args"]
     elapsed, out, jobs, timing = batch_leg(ctx, args.tois, args.batch_n, 200, steps, warmup, fp32=args.fp32_model)
     if ctx["rank"] != 0:

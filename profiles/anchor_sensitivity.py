@@ -15,7 +15,7 @@ are reported as paired differences against the baseline over the same seeds (dev
 depend on seed and index only, so a variant and the baseline share their draws and the difference is far less noisy
 than either), mean +- standard error.
 
-    python profiles/anchor_sensitivity.py [n_seeds=100] > profiles/r04_anchor_sensitivity.txt
+    python profiles/anchor_sensitivity.py [n_seeds=100] > profiles/r04/anchor_sensitivity.txt
 
 Variants
   bin:*     the bin-edge conventions lightkurve / astropy may have used (lightkurve is not in this image): the last

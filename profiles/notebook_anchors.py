@@ -1,7 +1,7 @@
 """Device-mode calc_probs on the inputs of the reference's example notebooks, 20 seeds each at
 N = 1e6, against the numbers those notebooks printed (the only reference results that passed
 through the real pytransit).  Writes the tables tests/test_gpu_notebook_anchors.py asserts on.
-    python profiles/notebook_anchors.py [n_seeds] [sampling] > profiles/r03_notebook_anchors.txt"""
+    python profiles/notebook_anchors.py [n_seeds] [sampling] > profiles/r03/notebook_anchors.txt"""
 import os
 import sys
 import time

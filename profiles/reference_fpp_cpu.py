@@ -2,7 +2,7 @@
 tests/golden/make_golden.py: oracle QuadraticModel at the pytransit seam) at N = 1e6 on the
 notebook inputs, on the CPU of the build container.  Tells apart "our device path differs from the
 current reference code" from "the notebooks were made by an older release / by pytransit itself".
-    python profiles/reference_fpp_cpu.py toi465_nocc 5 [N] [first seed] > profiles/r03_reference_fpp_cpu.txt"""
+    python profiles/reference_fpp_cpu.py toi465_nocc 5 [N] [first seed] > profiles/r03/reference_fpp_cpu.txt"""
 import contextlib
 import io
 import os

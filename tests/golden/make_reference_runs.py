@@ -6,11 +6,11 @@ TRILEGAL table).  ~80-100 s per run, hence few runs (16 of TOI-465.01, 16 of TOI
 compares the device path's distribution with (same code base as the device path mirrors, unlike the stored
 notebook outputs, which an older release produced).
 
-    python profiles/reference_fpp_cpu.py toi465_nocc 6 >  profiles/r04_reference_fpp_cpu.txt
-    python profiles/reference_fpp_cpu.py toi411 4      >> profiles/r04_reference_fpp_cpu.txt      (round 3: seeds 1000-1003)
-    python profiles/reference_fpp_cpu.py toi411 12 1000000 1004 >> profiles/r04_reference_fpp_cpu.txt   (round 4: 1004-1015)
-    python profiles/reference_fpp_cpu.py toi465_nocc 10 1000000 1006 >> profiles/r04_reference_fpp_cpu.txt   (round 4: 1006-1015)
-    python tests/golden/make_reference_runs.py profiles/r04_reference_fpp_cpu.txt
+    python profiles/reference_fpp_cpu.py toi465_nocc 6 >  profiles/r04/reference_fpp_cpu.txt
+    python profiles/reference_fpp_cpu.py toi411 4      >> profiles/r04/reference_fpp_cpu.txt      (round 3: seeds 1000-1003)
+    python profiles/reference_fpp_cpu.py toi411 12 1000000 1004 >> profiles/r04/reference_fpp_cpu.txt   (round 4: 1004-1015)
+    python profiles/reference_fpp_cpu.py toi465_nocc 10 1000000 1006 >> profiles/r04/reference_fpp_cpu.txt   (round 4: 1006-1015)
+    python tests/golden/make_reference_runs.py profiles/r04/reference_fpp_cpu.txt
 """
 import os
 import re

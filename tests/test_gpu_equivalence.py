@@ -13,7 +13,7 @@ Philox counters in the draw kernel), so the comparison is statistical:
    ~4e-4 of the share, so a wrong sampler, mask or column on the device side shows at once (two-sample
    Kolmogorov-Smirnov over the 20 + 20 runs and agreement of the means within 4 standard errors).
 
-The table goes to stdout (pytest -s) and, from profiles/mc_scatter.py, into profiles/r03_mc_scatter.txt."""
+The table goes to stdout (pytest -s) and, from profiles/mc_scatter.py, into profiles/r03/mc_scatter.txt."""
 import os
 
 import numpy as np

@@ -873,7 +873,7 @@ def test_exposure_centres_stepped_from_conjunction_are_solved_to_rounding(below)
     """A deep (45 %) eclipse on a wide eccentric orbit (a / R = 30, e = 0.37) sampled where the occulting disc's
     edge crosses the star's centre: the Mandel-Agol expressions turn 2e-15 in z into several 1e-13 in flux there.
     The exposure-centre solution reached by Newton steps from conjunction once carried 1e-14 in E (its running
-    reciprocal of g' was refined once per iteration) and this row came out 6e-13 off (profiles/r03_fuzz.txt)."""
+    reciprocal of g' was refined once per iteration) and this row came out 6e-13 off (profiles/r03/fuzz.txt)."""
     row = np.array([1.23759087e+00, 5.99053086e-02, 2.87708804e+01, 8.93703694e+01, 3.03686223e+12, 1.44694079e+00,
                     3.71469911e-01, 2.44530025e-01, 3.66301601e-01, 6.16838000e+01, 4.60773272e-02])[:, None]
     rng = np.random.default_rng(3)

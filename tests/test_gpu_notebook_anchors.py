@@ -23,7 +23,7 @@ the runs were looked at) and is held against
 What the notebooks do NOT pin, and is therefore reported, not gated:
  * TOI-411.02's TP : PTP : STP (cell 25: 0.751 : 0.119 : 0.0338; here 0.797 : 0.156 : 0.0448, the current reference
    code 0.80 : 0.15 : 0.046).  In log space the notebook sits -0.214 (PTP/TP) and -0.221 (STP/TP) from this
-   implementation -- the SAME factor 0.81 on both bound-companion scenarios.  profiles/r04_anchor_sensitivity.txt
+   implementation -- the SAME factor 0.81 on both bound-companion scenarios.  profiles/r04/anchor_sensitivity.txt
    changes every input this repository had to make up (lightkurve's bin edges, the sigma it reports, the last
    printed digit of the star table, sampling mode, parallel, exposure settings, N) one at a time over 100 paired
    seeds: none moves ln(PTP/TP) by more than 0.02.  A transit-arithmetic difference would not hit PTP and STP
@@ -38,7 +38,7 @@ What the notebooks do NOT pin, and is therefore reported, not gated:
    to the rank test against those runs.  The reference's own tests document fixes that postdate the notebooks
    (tests/test_background_prior_log_base.py: log10 -> ln in the background priors; tests/test_beb_collision_mask.py),
    which move the D and B scenarios by construction.
-Tables of a 300-seed run of every case: profiles/r03_notebook_anchors_300.txt (profiles/notebook_anchors.py)."""
+Tables of a 300-seed run of every case: profiles/r03/notebook_anchors_300.txt (profiles/notebook_anchors.py)."""
 import numpy as np
 import pytest
 

@@ -11,7 +11,7 @@ import os as _os
 # The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise, and two streams that
 # share a queue serialise: calc_probs on three streams then runs slower than on two (64 TOIs: 0.223 s a step on two
 # streams, 0.263 on three, 0.226 on four, 0.190 on six; with 8 queues 0.224 / 0.185 / 0.172 / 0.180 --
-# profiles/r04_hw_queues.txt).  Read by the runtime when it initialises (the first HIP call of the process), so it
+# profiles/r04/hw_queues.txt).  Read by the runtime when it initialises (the first HIP call of the process), so it
 # has to be in the environment before that; a value the user has set is left alone.
 def _request_hw_queues():
     """Sets GPU_MAX_HW_QUEUES = 8 unless the user has, and records whether the runtime can still see it: the variable
@@ -40,7 +40,7 @@ _HW_QUEUES = _request_hw_queues()
 def hw_queues():
     """{'value', 'set_by': 'user' | 'package', 'in_effect'}: what GPU_MAX_HW_QUEUES this process asked for and whether
     the HIP runtime was still uninitialised when the package set it (False: the runtime's default of 4 applies and
-    calc_probs on more than two streams runs ~10 % slower, profiles/r04_hw_queues.txt; import triceratops_amd before
+    calc_probs on more than two streams runs ~10 % slower, profiles/r04/hw_queues.txt; import triceratops_amd before
     the first GPU call, or export the variable)."""
     return dict(_HW_QUEUES)
 

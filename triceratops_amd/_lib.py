@@ -239,7 +239,7 @@ def dev(x, device=None):
 
     Host arrays go up asynchronously on a stream of their own, through a pinned staging block: a copy from
     pageable memory returns when it has COMPLETED, and with the GPU busy that was 0.5 ms per small table (a
-    third of the host time of a 64-target batch step, profiles/r03_f_batch_host_profile.txt).  Nothing waits on
+    third of the host time of a 64-target batch step, profiles/r03/f_batch_host_profile.txt).  Nothing waits on
     the host: the upload leaves an event, the stream that is current here waits for it on the device, and so does
     every stream a library call is enqueued on while the event is pending (wait_uploads; cached tables are read
     by calls on other streams a few microseconds later).  A tensor from dev() is therefore ordered for the stream

@@ -611,7 +611,7 @@ __device__ __forceinline__ bool kepler_step_wide(double dM, double e, double& sE
             // rho that far off squared, and what the last step leaves behind is step x (rho's relative error) -- with
             // one refinement up to 1e-14 in E, which a wide orbit (a / R = 30) turns into several 1e-13 of flux where
             // the Mandel-Agol expressions are badly conditioned (z near k; found by profiles/fuzz_kernels.py,
-            // profiles/r03_fuzz.txt).  The second refinement squares it away.
+            // profiles/r03/fuzz.txt).  The second refinement squares it away.
 #ifdef TRX_KEPLER_NEWTON
             rho = rho * fma(-gp, rho, 2.0);
             rho = rho * fma(-gp, rho, 2.0);
@@ -820,7 +820,7 @@ __device__ __forceinline__ bool in_window(double wlo, double whi, double dMc)
 // of n model values, exact for polynomials of degree 2n-1.  The model is analytic away from the
 // limb contacts z = 1 + k and z = |1 - k|; the rule's error falls geometrically with the
 // distance to the nearest (real or complex) contact time in units of the half exposure
-// (profiles/r01_q_tier_error.txt), so each tier carries the zero-free radius it needs.
+// (profiles/r01/q_tier_error.txt), so each tier carries the zero-free radius it needs.
 constexpr int kTiers = 7, kTierMaxNodes = 10;
 struct TierTable {
     int n[kTiers];                         // nodes per tier, ascending; 0 = tier unused

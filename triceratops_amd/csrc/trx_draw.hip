@@ -894,7 +894,7 @@ int trx::draw_counted(const trx_draw_args& a, int* blk_cnt, long* per_out, int* 
 
 // Ordered compaction of the mask(s) + the columns and the prior of the draws that passed: see compact_fill_kernel.
 // One workgroup of one wave per workgroup of draw_kernel (1024 at N = 1e6: ~1000 draws each, ~100 of which pass at the
-// reference's priors -- two waves of fills): 27-39 us for the planet scenarios (profiles/r04_j_draw_kernel.txt; with
+// reference's priors -- two waves of fills): 27-39 us for the planet scenarios (profiles/r04/j_draw_kernel.txt; with
 // 2048 draw workgroups of 512 draws it was 23-31, and the draw kernel 4 us slower: trx_internal.hpp).
 int trx::compact_fill(const trx_draw_args& a, long per, int groups, const int* blk_cnt, int* idx0, int* idx1, long* n_dev,
                       double* cols0, hipStream_t st, int n_pad)

@@ -117,7 +117,7 @@ int draw_chain(const trx_draw_args* host_args, const trx_draw_args* dev_tab, int
 // (1024 workgroups of 256 threads for N = 1e6, ~1000 draws each: of a chunk of 1024 pre-tested draws ~100 go on to the
 // fp64 mask, on 256 lanes; with 2048 workgroups of ~500 draws the fp64 pass ran on a fifth of its lanes -- draw_kernel<2>
 // 43.5 -> 39.8 us per call, compact_fill_kernel 33.6 -> 38.8 (half as many one-wave workgroups), 64-TOI step 0.173 ->
-// 0.166 s, 75 scenarios 19.0 -> 18.3 ms: profiles/r04_ab_draw.txt; 512 workgroups lose)
+// 0.166 s, 75 scenarios 19.0 -> 18.3 ms: profiles/r04/ab_draw.txt; 512 workgroups lose)
 #ifndef TRX_DRAW_GROUPS
 #define TRX_DRAW_GROUPS 1024
 #endif

@@ -229,7 +229,7 @@ __device__ __forceinline__ double k_rule(double k, bool scalar_rule)
 // its own cell's nodes.  That loses lanes four ways, the more the shorter the light curve (the
 // reference's real operating point is 100-200 binned points, examples/TSCIII_tutorial.ipynb cell
 // 4): the per-row prologue runs on 1-4 of the 64 lanes (a third of the wave's cycles at 100 points,
-// profiles/r01_r_phase_cycles.txt); a 100-point row fills 64 + 36 lanes; a 64-cell chunk of a
+// profiles/r01/r_phase_cycles.txt); a 100-point row fills 64 + 36 lanes; a 64-cell chunk of a
 // coarse time grid spans 0.3 d, so in- and out-of-transit cells share every chunk and the lanes of
 // the out-of-window cells idle through the plan and the orbit stage; and neighbouring cells have
 // different node counts (3-9 Gauss nodes, S next to a contact), so a per-lane node loop runs to
@@ -319,11 +319,11 @@ __host__ __device__ constexpr int cells_window(bool long_rows) { return long_row
 constexpr int kCellsPairs = TRX_CELLS_PAIRS;       // (cell, node) pairs per pass (pair table in LDS)
 
 // Rows per wave of the batched variant: about 640 cells per wave, at most kCellsMaxRows rows.  Measured
-// (profiles/r02_g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 -- larger
+// (profiles/r02/g_cells_batch_sweep.txt): 12 rows at 50 points, 6 at 100, 3-4 at 200, 2 at 400 -- larger
 // batches fill the chunks better, but the batches of a launch differ in work (rows with long transits),
 // and with fewer, longer waves the last round over the chip's wave slots leaves more of them idle.
 // Few rows: fewer per wave, down to ~3200 waves a launch (with the tapered plan below the best rows per wave at 100
-// points are 3 for 10 000 rows and 6 from 20 000 on, profiles/r04_few_rows_sweep.txt; until then the rule asked for
+// points are 3 for 10 000 rows and 6 from 20 000 on, profiles/r04/few_rows_sweep.txt; until then the rule asked for
 // 10 000 waves and 30 000 rows ran 6 % slower at 3 per wave than at 4-6).  `n` < 0: the largest value any n gives
 // (LDS layout).
 __host__ __device__ inline int batch_rows(long n, int n_time, int forced, int floor = 3200)
@@ -341,12 +341,12 @@ __host__ __device__ inline int batch_rows(long n, int n_time, int forced, int fl
 // then stay in that XCD's L2).  The chip holds 5120 waves of the batched variant (5 per SIMD), a launch of 10^5 rows
 // at six rows per wave is 3.3 rounds over those slots, and the slots that finish their last batch first idle until
 // the last wave of the launch is done: 12 % of the launch (300 000 rows run at 2.35e10 cells/s where 100 000 run
-// at 2.04e10: the untapered sweeps of profiles/r04_ab_taper.txt).  So the last positions of every XCD take fewer rows: half a
+// at 2.04e10: the untapered sweeps of profiles/r04/ab_taper.txt).  So the last positions of every XCD take fewer rows: half a
 // slot's worth of positions at half the rows per wave, then as many at a quarter -- the work still out when the slots
 // start to drain comes in pieces a quarter the size (100 points, 10^5 rows: 2.04e10 -> 2.14e10 cells/s).
 // Positions 0 .. P-1 per XCD; one rule for the host (grid), the workgroup exit test and the batch loop.  Not for the
 // passes of the bounded evaluation (`taper` false): a probe pass has so little to do per row that more, smaller
-// waves cost more than the tail they fill (+10 % on a 200-point call, profiles/r04_ab_taper.txt).
+// waves cost more than the tail they fill (+10 % on a 200-point call, profiles/r04/ab_taper.txt).
 #ifndef TRX_TAPER_SLOTS
 #define TRX_TAPER_SLOTS 320
 #endif
@@ -369,7 +369,7 @@ __host__ __device__ inline BatchPlan batch_plan(long rows, int B, bool taper = t
     if (B > 1 && taper) {
         // an XCD holds 640 waves of this kernel (32 CUs x 4 SIMDs x 5); measured per 18 launches of 10^5 rows x 100
         // points: no taper 8.86-8.96 ms, 2560 positions per tier 8.85-8.90, 1280 8.67-8.74, 640 8.51-8.55, 320 8.49-8.52
-        // (profiles/r04_ab_taper.txt)
+        // (profiles/r04/ab_taper.txt)
         constexpr long kSlotsPerXcd = TRX_TAPER_SLOTS;
         rc = kSlotsPerXcd * p.B3;
         if (rc > (3 * p.R) / 20) rc = (3 * p.R) / 20;
@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     // The survivors' pass of the batched variant (part 3) looks at the bound once more: a row survives the probe pass
     // whenever its ~16 probe cells and its out-of-window cells do not prove it negligible -- the unprobed in-window
     // cells are taken to fit perfectly -- and nine survivors in ten are still far from the best (profiles/
-    // r03_f_prune_potential.txt: 4.6 % of TOI-465.01's rows survive 16 cells, 0.5 % lie within 90 of the best).  Its first
+    // r03/f_prune_potential.txt: 4.6 % of TOI-465.01's rows survive 16 cells, 0.5 % lie within 90 of the best).  Its first
     // phase takes every a.pstride3-th stamp (a quarter of the row), the verdict drops what that proves negligible, the
     // second phase finishes the rest.
     const bool third_two = PRUNE && !LONG && a.part == 3 && a.pstride3 > 1;
@@ -1736,7 +1736,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // device finds no uniform grid, the other one never uses the stencil.
 // (Batches: five waves per SIMD for the bounded instantiation too -- until round 4's last day it was compiled for four and
 // took 97 VGPRs, one more than five waves allow on 512 registers in granules of 8; for five it takes 95, no scratch:
-// the unprobed full evaluations of its third pass gain 8 %, profiles/r04_ab_waves5.txt.)
+// the unprobed full evaluations of its third pass gain 8 %, profiles/r04/ab_waves5.txt.)
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
 __device__ __forceinline__ void cells_entry(const RowsArgs& a)
 {
@@ -1882,7 +1882,7 @@ __device__ __forceinline__ void lme_fold4(Lme& st, double x0, double x1, double 
 }
 
 // Loads per lane per trip (16 B each) and whether the next trip's loads are issued before the
-// current trip is folded (profiles/r02_lme_variants.txt)
+// current trip is folded (profiles/r02/lme_variants.txt)
 #ifndef TRX_LME_LOADS
 #define TRX_LME_LOADS 2
 #endif
@@ -1945,7 +1945,7 @@ __device__ __forceinline__ void lme_partial_body(const double* __restrict__ logw
     long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {
         // 16 B per lane per load, TRX_LME_LOADS independent loads per trip (issuing the next
-        // trip's loads before the fold, TRX_LME_PREFETCH, measured slower: profiles/r02_lme_variants.txt).
+        // trip's loads before the fold, TRX_LME_PREFETCH, measured slower: profiles/r02/lme_variants.txt).
         // The fold itself leans on IEEE max: fmax ignores a NaN operand, so NaN never reaches the
         // running maximum, `x - max > -80` is false for NaN and for -inf, and a +inf drives the
         // maximum to +inf (detected once, after the loop) -- no per-value inf / NaN tests.
@@ -1958,7 +1958,7 @@ __device__ __forceinline__ void lme_partial_body(const double* __restrict__ logw
         constexpr int kL = TRX_LME_LOADS, kV = 2 * kL;
         // Every block streams ONE contiguous segment of the vector (a multiple of 4 KB), its waves 1 KB
         // apart: 6.35 TB/s on the 3.2 GB stress vector against 5.75 with the usual grid-stride loop,
-        // where a block's consecutive loads are gridDim x 4 KB apart (profiles/r02_lme_variants.txt).
+        // where a block's consecutive loads are gridDim x 4 KB apart (profiles/r02/lme_variants.txt).
         const long nv_all = n >> 1;
         const long seg = ((nv_all + nblocks - 1) / nblocks + 255) & ~255L;
         const long seg0 = (long)blockIdx.x * seg;
@@ -2242,7 +2242,7 @@ int n_params(int model)
 // interpolatory rule of the same accuracy.  Nodes = roots of the degree-n orthogonal polynomial
 // of the measure (Stieltjes recurrence, roots by bisection between the roots of degree n-1),
 // weights = Christoffel numbers; long double, once per launch.  Radii from the measured error
-// decay (profiles/r01_q_tier_error.txt): <= ~2e-14 per tier.
+// decay (profiles/r01/q_tier_error.txt): <= ~2e-14 per tier.
 bool compute_tiers(TierTable& T, int S)
 {
     static const int nn[kTiers] = {3, 4, 5, 6, 7, 8, 9};
@@ -2419,7 +2419,7 @@ thread_local bool t_last_pruned = false;
 // of the finite ones lie more than 150 above the smallest, the main launch evaluates its rows in one pass
 // (a scenario no draw of which comes near the data -- a faint neighbour that would need a 50 % deep eclipse --
 // has all its rows within a few tens of each other: nothing to abandon; and measured per call in round 4,
-// profiles/r04_bounded_short.txt: with 37 % of the rows abandoned -- TOI-411.02, a 166 ppm signal -- the probe pass
+// profiles/r04/bounded_short.txt: with 37 % of the rows abandoned -- TOI-411.02, a 166 ppm signal -- the probe pass
 // costs more than it saves (0.54 -> 0.73 ms), with 76 % it pays (0.59 -> 0.50), with 93 % it halves the call.  The share
 // of pilot rows 150 above the best overstates what the probe cells can prove: 0.8 for TOI-411.02, 0.995 and more for
 // the cases that gain -- hence 90 %).
@@ -2601,7 +2601,7 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     // bounded evaluation (trx_scenario_evidence): ~16 probe cells per row; its instantiations carry no stencil
     // (default: light curves of one row per wave only -- measured on calc_probs at N = 1e6: Kepler-10b, 478 points,
     // 46 -> 39 ms; at 100 binned points the batched variant gains or loses ~3 % (the probe phase, the pilot
-    // launch and the second window pass eat what the abandoned rows save): profiles/r03_bounded_e2e.txt)
+    // launch and the second window pass eat what the abandoned rows save): profiles/r03/bounded_e2e.txt)
     const int prune_mode = (a.flags & TRX_FLAG_FULL_EVALUATION) ? 0 : (a.prune == 2 ? 2 : knob_bounded());
     // (batched variant: the verdict after the probe phase reads flat + corrections - hrem, and hrem holds only the
     // in-window cells of the window passes done so far -- a valid bound only when the batch's cells fit ONE window;
@@ -2704,7 +2704,7 @@ int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
     // stride over the positions beyond it: one workgroup per slot of the chip (1280) for the passes of the bounded
     // evaluation, four per slot for a full evaluation -- which loses nothing against one workgroup per four batches
     // when a launch runs alone (static striding below that does: +6 % at two per slot, +18 % at one) --, four waves
-    // per slot with one row per wave.  Measured in one job each (profiles/r04_ab_cap.txt): 64 TOIs on three streams
+    // per slot with one row per wave.  Measured in one job each (profiles/r04/ab_cap.txt): 64 TOIs on three streams
     // 0.265 -> 0.185 s per step (four streams 0.175), the 75-scenario calc_probs 22.0 -> 20.4 ms, 15 scenarios
     // 3.8 -> 3.1 ms, Kepler-10b 12.0 -> 10.6 ms.  (Environment: experiments only.)
     static const long cap_probe = env_long("TRX_GRID_CAP", 1280);

@@ -268,7 +268,7 @@ int enqueue(const trx_scenario_args* s, double* out_host, hipStream_t st)
 // bounded evaluation and lme_partial_kernel are launched ONCE each, with the call (draw side) or the branch (likelihood
 // side) as a further grid dimension -- 11 launches and one small upload for up to 16 calls / 24 branches, where the calls
 // one by one take 9 (planet) to 17 (binary) launches EACH.  Round 4 measured why that matters (profiles/
-// r04_concurrency_levels.txt, r04_j_batch_kernel_stats.txt): the chip runs ~3 kernels at a time whatever the number of
+// r04/concurrency_levels.txt, r04/j_batch_kernel_stats.txt): the chip runs ~3 kernels at a time whatever the number of
 // streams, a 64-target step was 10 183 launches, most of them 8-45 us long on a tenth of the machine, and the host spent
 // 113 of the step's 155 ms enqueueing them.  The calls of a chain must share N, the time stamps, the exposure settings
 // and the precision flag (the calls of one target do: triceratops.py:767-1428); flux and sigma may differ (a nearby

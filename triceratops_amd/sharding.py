@@ -40,7 +40,7 @@ threads = 1
 # results are read after one wait.  The library keeps ~0.3 GB of scratch per stream at N = 1e6.
 # Four: a call is a chain of dependent launches, most of them small, so a stream keeps the chip busy only while its
 # likelihood kernel runs, and the other streams fill those gaps.  64 TOIs x 18 scenarios, the stream counts visited in
-# turn over seven rounds (profiles/batch_timing.py, profiles/r04_hw_queues.txt): 0.35 s a step on one stream, 0.225 on
+# turn over seven rounds (profiles/batch_timing.py, profiles/r04/hw_queues.txt): 0.35 s a step on one stream, 0.225 on
 # two, 0.19 on three, 0.175 on four, 0.18-0.19 on six and on eight -- with one hardware queue per stream
 # (GPU_MAX_HW_QUEUES = 8, set by the package: with the runtime's default of 4, streams share queues and three streams
 # run slower than two).
