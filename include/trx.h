@@ -281,6 +281,15 @@ typedef struct {
     unsigned long long seed;
     double* dump;                /* [9][N] or NULL (tests): the random numbers each draw used, rows =
                                     P q_c R_p inc q ecc_u argp index ecc_beta (as uniforms / values) */
+    /* Replaying the reference's own interpolation of the contrast curve (funcs.py:222-238: np.interp).  On a curve whose
+     * contrasts are NOT monotonic np.interp returns the interval its search ends in, and numpy starts that search from
+     * the PREVIOUS draw's interval: the value of draw i depends on draw i - 1.  The kernel bisects (no such memory).  A
+     * caller that must reproduce the reference draw for draw -- the seeded validation mode -- asks trx_draw_scenario for
+     * every draw's contrast (dm_out [N]: the signed delta magnitude the prior is evaluated at, NaN where the scenario
+     * has none), runs np.interp over |dm| itself, in draw order, and hands the separations back (sep_in [N], arcsec):
+     * where sep_in is given the kernel takes sep_in[i] instead of interpolating.  Both NULL: the kernel's own search. */
+    const double* sep_in;
+    double* dm_out;
 } trx_draw_args;
 
 int trx_draw_scenario(const trx_draw_args* args, void* stream);

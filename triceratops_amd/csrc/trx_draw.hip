@@ -196,9 +196,10 @@ __device__ __forceinline__ double interp(const double* xp, const double* fp, int
 }
 
 // ln of the bound-companion rate (priors.py:580-984) at |delta_mag| = dm
-__device__ __forceinline__ double bound_rate(const trx_draw_args& a, const Tables& T, double dm, bool keep_close)
+__device__ __forceinline__ double bound_rate(const trx_draw_args& a, const Tables& T, double dm, bool keep_close, long i)
 {
-    const double seps = a.dist_pc * interp(T.cc_con, T.cc_sep, a.n_cc, dm);
+    // (sep_in: the reference's own np.interp of this draw, replayed by the caller -- include/trx.h)
+    const double seps = a.dist_pc * (a.sep_in ? a.sep_in[i] : interp(T.cc_con, T.cc_sep, a.n_cc, dm));
     const double s_au = seps * kAu;
     const double lp = log10(sqrt(a.kepler_c * (s_au * s_au * s_au)) / 86400.0);
     const double f1 = a.f1, f2 = a.f2, f3 = a.f3;
@@ -514,7 +515,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
             if (a.use_cc) { const double f = flux_rel(T, TRX_SPL_F_BAND, mc); fr = ratio(f / (f + a.f0_band)); }
             dm = 2.5 * log10(fr);
             dm_set = true;
-            lnprior = bound_rate(a, T, fabs(dm), false);
+            lnprior = bound_rate(a, T, fabs(dm), false, i);
         }
     } else {
         dEcc = rnd(a.uEcc, 5u);
@@ -565,7 +566,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
             }
             dm = 2.5 * log10(term);
             dm_set = true;
-            lnprior = bound_rate(a, T, fabs(dm), true);
+            lnprior = bound_rate(a, T, fabs(dm), true, i);
         } else if (a.prior == TRX_PRIOR_FIELD && a.host == TRX_HOST_FIELD) {
             // lnZ_BEB: background star + its EB (marginal_likelihoods.py:2161-2208)
             double term;
@@ -587,7 +588,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
             dm = a.use_cc ? a.f_delta[k] : 2.5 * log10(ratio(frc));
         }
         if (a.use_cc) {
-            const double s = interp(T.cc_con, T.cc_sep, a.n_cc, fabs(dm));
+            const double s = a.sep_in ? a.sep_in[i] : interp(T.cc_con, T.cc_sep, a.n_cc, fabs(dm));
             lnprior = log(a.bg_amp * (s * s));
         } else {
             lnprior = a.bg_const;
@@ -597,6 +598,7 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
         lnprior = (lnprior > 0.0) ? 0.0 : lnprior;     // clamp_max: NaN stays NaN
         if (dm > 0.0) lnprior = -INFINITY;
     }
+    if (PHASE == 0 && a.dm_out) a.dm_out[i] = (dm_set || a.prior == TRX_PRIOR_FIELD) ? dm : NAN;
     if (PHASE == 0 && a.lnprior) a.lnprior[i] = lnprior;
     if (PHASE == 2 && prior_at) *prior_at = lnprior;
     if (PHASE == 0 && a.dump) {

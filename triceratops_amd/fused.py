@@ -97,7 +97,8 @@ class DrawArgs(ctypes.Structure):
                                       "uP", "uQc", "uRp", "uInc", "uQ", "uEcc", "uW", "ecc_in", "qc_in",
                                       "idx", "cols", "mask", "mask_twin", "lnprior", "flag")]
                 + [("use_philox", ctypes.c_int), ("range_P", ctypes.c_int), ("n_field_draw", ctypes.c_long),
-                   ("pretest", ctypes.c_int), ("seed", ctypes.c_ulonglong), ("dump", _vp)])
+                   ("pretest", ctypes.c_int), ("seed", ctypes.c_ulonglong), ("dump", _vp),
+                   ("sep_in", _vp), ("dm_out", _vp)])
 
 
 class ScenarioArgs(ctypes.Structure):
@@ -498,7 +499,9 @@ def _contrast_curve(cc_file, device):
             seps, cons = funcs.file_to_contrast_curve(cc_file)
         if cons.size > MAX_CC:
             raise ValueError("contrast curve has more than %d points" % MAX_CC)
-        _cc_cache[key] = (_lib.dev(seps, device), _lib.dev(cons, device), int(cons.size))
+        # (the host copies and whether the contrasts are monotonic: _Scenario._replay_interp)
+        _cc_cache[key] = (_lib.dev(seps, device), _lib.dev(cons, device), int(cons.size), seps, cons,
+                          bool(cons.size > 1 and np.any(np.diff(cons) <= 0)))
     return _cc_cache[key]
 
 
@@ -676,7 +679,7 @@ class _Scenario:
 
     def _cc(self, cc_file, filt, M_s):
         a = self.a
-        seps, cons, n = _contrast_curve(cc_file, self.dev)
+        seps, cons, n, self.cc_host_seps, self.cc_host_cons, self.cc_nonmono = _contrast_curve(cc_file, self.dev)
         a.cc_seps, a.cc_cons, a.n_cc = seps.data_ptr(), cons.data_ptr(), n
         a.use_cc = int(cc_file is not None)
         self.band = filt if (cc_file is not None and filt in ("J", "H", "K")) else "TESS"
@@ -723,6 +726,36 @@ class _Scenario:
 
     want_prior = False
     band = "TESS"
+    cc_nonmono = False
+
+    def _replay_interp(self, ncol):
+        """The reference interpolates the contrast curve with np.interp (funcs.py:222-238), and on a curve whose contrasts
+        are not monotonic -- TOI-465.01's measured curve wiggles beyond 9 mag -- np.interp returns the interval its search
+        ends in, a search numpy starts from the PREVIOUS draw's interval: the reference's prior of a draw on such a
+        plateau depends on the draw before it.  The draw kernel bisects.  In the seeded validation mode
+        ("numpy-device": the reference's draws) the reference's own values are replayed: one pass of the draw kernel
+        gives every draw's contrast (trx_draw_args.dm_out), np.interp runs over them HERE, in draw order -- numpy's search
+        with numpy's memory -- and the separations go back in (sep_in).  Until round 6 this was a documented deviation
+        (|d lnZ| <= 8.5e-8 on TOI-465.01's D and B scenarios, tolerance 1e-6 there); now those rows meet the 1e-8 of
+        all the others.  One host synchronisation, in a mode that spends its time drawing 3e8 numpy uniforms anyway."""
+        a, N, dev = self.a, self.N, self.dev
+        cols = torch.empty((ncol, N), dtype=F64, device=dev)
+        mask = torch.empty(N, dtype=torch.uint8, device=dev)
+        mask2 = torch.empty(N, dtype=torch.uint8, device=dev) if not a.planet else None
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        dm = torch.empty(N, dtype=F64, device=dev)
+        a.cols, a.mask, a.mask_twin, a.lnprior, a.flag = cols.data_ptr(), mask.data_ptr(), _ptr(mask2), None, flag.data_ptr()
+        a.dm_out, a.sep_in = dm.data_ptr(), None
+        with torch.cuda.device(dev):
+            _lib.wait_uploads(torch.cuda.current_stream(dev))
+            rc = _fn()(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.TrxError("trx_draw_scenario failed with status %d" % rc)
+        x = dm.abs().cpu().numpy()
+        self.sep = _lib.dev(np.interp(x, self.cc_host_cons, self.cc_host_seps), dev)
+        self.keep.append(self.sep)
+        a.dm_out, a.sep_in = None, self.sep.data_ptr()
+        a.cols = a.mask = a.mask_twin = a.flag = None
 
     # -----------------------------------------------------------------------------------
     def run(self, is_host):
@@ -730,6 +763,9 @@ class _Scenario:
         tab = _spline_table(dev, self.band)
         a.splines = tab.data_ptr()
         ncol = 11 if a.planet else 14
+        if (self.cc_nonmono and a.use_cc and not self.philox and isinstance(dp.RNG, dp.NumpyStreamRng)
+                and a.prior in (PRIOR_BOUND_TP, PRIOR_BOUND_EB, PRIOR_FIELD)):
+            self._replay_interp(ncol)
         # calc_probs (TABLE_ROWS == 1) takes the library's own chain in BOTH device modes: with numpy's stream the staged
         # uniforms go in through trx_draw_args.uP ... uW (use_philox = 0), so a seeded "numpy-device" run is the
         # production chain -- trx_star_enqueue, bounded evaluation -- on the reference's draws
