@@ -239,16 +239,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-        if not args.no_rccl_world1 and (args.mode == "batch" or not args.no_batch_leg):
-            # a one-rank RCCL group: the batch leg sends one step through the collective branch (batch_leg)
-            try:
-                store = "/tmp/trx_bench_pg_%d" % os.getpid()
-                if os.path.exists(store):
-                    os.remove(store)
-                dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1,
-                                        device_id=torch.device("cuda", 0))
-            except Exception as exc:                  # noqa: BLE001  (the bench line does not depend on it)
-                sys.stderr.write("bench: one-rank RCCL group unavailable (%s: %s)\n" % (type(exc).__name__, exc))
     _lib.require_gpu()
     device = torch.device("cuda", local_rank if (world > 1 and not debug_one) else 0)
     ctx = dict(args=args, world=world, rank=rank, device=device, debug_one=debug_one, extras=extras,
@@ -659,10 +649,24 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
         timing["calls"] = sharding.last_share["calls"]
         timing["stars"] = sharding.last_share["stars"]
         timing["jobs"] = sharding.last_share["jobs"]
+        own_group = False
+        if world == 1 and not ctx["args"].no_rccl_world1 and dist.is_available() and not dist.is_initialized():
+            # A one-rank RCCL group, set up only NOW: a live RCCL communicator costs the timed steps 6-8 % (64-target step
+            # 94-96 ms without one in the process, 102 with: profiles/r06/rccl_group_cost.txt -- it holds queues / CUs of
+            # its own), and a single-GPU run has no use for one.
+            try:
+                store = "/tmp/trx_bench_pg_%d" % os.getpid()
+                if os.path.exists(store):
+                    os.remove(store)
+                dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1,
+                                        device_id=torch.device("cuda", 0))
+                own_group = True
+            except Exception as exc:                  # noqa: BLE001  (the bench line does not depend on it)
+                sys.stderr.write("bench: one-rank RCCL group unavailable (%s: %s)\n" % (type(exc).__name__, exc))
         if world == 1 and dist.is_available() and dist.is_initialized():
             # One rank has nothing to gather and the timed steps skip the collective.  So that the RCCL branch of
             # sharding._run_units is executed on the hardware there is -- device tensors, header row, padding, through
-            # all_gather_into_tensor of the one-rank "nccl" group main() set up -- one more step goes through it, not
+            # all_gather_into_tensor of a one-rank "nccl" group -- one more step goes through it, not
             # timed as part of `value`, next to the same step without it (per-unit seeds on both sides: same tables).
             twin = synth.toi_jobs(tois, n_time=n_time, N=N, seed=synth.SEED, trilegal_fname=tri, contrast_curve_file=cc)
             sharding.per_unit_seed = True
@@ -680,6 +684,10 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
                 timing["gather_s"] = [float(sharding.timing["gather_s"])]
             finally:
                 sharding.collective_at_world_one = False
+                if own_group:
+                    # (gone again before the legs that follow -- shapes, e2e -- are timed)
+                    torch.cuda.synchronize()
+                    dist.destroy_process_group()
         return elapsed, out, jobs, timing
     finally:
         triceratops_amd.set_sampling(prev)

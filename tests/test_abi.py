@@ -136,4 +136,4 @@ def test_hw_queues_report():
     import triceratops_amd
     q = triceratops_amd.hw_queues()
     assert set(q) == {"value", "set_by", "in_effect"} and q["set_by"] in ("user", "package")
-    assert q["value"] == 8 or q["set_by"] == "user"
+    assert q["value"] == 16 or q["set_by"] == "user"

@@ -13,8 +13,11 @@ import os as _os
 # streams, 0.263 on three, 0.226 on four, 0.190 on six; with 8 queues 0.224 / 0.185 / 0.172 / 0.180 --
 # profiles/r04/hw_queues.txt).  Read by the runtime when it initialises (the first HIP call of the process), so it
 # has to be in the environment before that; a value the user has set is left alone.
+# Sixteen since round 6: a live RCCL communicator takes hardware queues of its own, and with eight the worker streams of a
+# rank then share -- a 64-target step 0.100 s with a one-rank "nccl" group in the process against 0.0947 without, and
+# 0.0945 either way with sixteen (24: 0.0955; profiles/r06/rccl_queues.txt).  Every rank of a multi-GPU run has one.
 def _request_hw_queues():
-    """Sets GPU_MAX_HW_QUEUES = 8 unless the user has, and records whether the runtime can still see it: the variable
+    """Sets GPU_MAX_HW_QUEUES = 16 unless the user has, and records whether the runtime can still see it: the variable
     is read once, by the first HIP call of the process.  If torch had already initialised the GPU when this package
     was imported, the setting is a silent no-op -- hw_queues() then says so and require_gpu() warns once."""
     import sys as _sys
@@ -27,8 +30,8 @@ def _request_hw_queues():
         except Exception:        # pragma: no cover
             late = False
     if user is None:
-        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
-    return {"value": int(user) if (user or "").isdigit() else (None if user else 8),
+        _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    return {"value": int(user) if (user or "").isdigit() else (None if user else 16),
             "set_by": "user" if user is not None else "package",
             # None: unknown to this process (a user setting is the user's business); False: HIP was up before the import
             "in_effect": (None if user is not None else (not late))}

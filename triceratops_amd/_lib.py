@@ -211,10 +211,10 @@ def require_gpu():
     from . import hw_queues
     if hw_queues()["in_effect"] is False:
         import warnings
-        warnings.warn("triceratops_amd was imported after the HIP runtime had been initialised: GPU_MAX_HW_QUEUES=8 "
+        warnings.warn("triceratops_amd was imported after the HIP runtime had been initialised: GPU_MAX_HW_QUEUES=16 "
                       "did not take effect (the runtime keeps its default of 4 hardware queues; calc_probs on more "
                       "than two streams runs ~10 % slower).  Import triceratops_amd before the first GPU call or "
-                      "export GPU_MAX_HW_QUEUES=8.", RuntimeWarning, stacklevel=3)
+                      "export GPU_MAX_HW_QUEUES=16.", RuntimeWarning, stacklevel=3)
 
 
 def compute_device():

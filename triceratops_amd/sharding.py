@@ -42,7 +42,7 @@ threads = 1
 # likelihood kernel runs, and the other streams fill those gaps.  64 TOIs x 18 scenarios, the stream counts visited in
 # turn over seven rounds (profiles/batch_timing.py, profiles/r04/hw_queues.txt): 0.35 s a step on one stream, 0.225 on
 # two, 0.19 on three, 0.175 on four, 0.18-0.19 on six and on eight -- with one hardware queue per stream
-# (GPU_MAX_HW_QUEUES = 8, set by the package: with the runtime's default of 4, streams share queues and three streams
+# (GPU_MAX_HW_QUEUES = 16 since round 6 -- 8 until then --, set by the package: with the runtime's default of 4, streams share queues and three streams
 # run slower than two).
 streams = int(os.environ.get("TRX_STREAMS", "4"))
 # host seconds of the last single-thread pass: enqueueing every call, then waiting for the streams
