@@ -650,7 +650,13 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
         timing["stars"] = sharding.last_share["stars"]
         timing["jobs"] = sharding.last_share["jobs"]
         own_group = False
+        saved_stdout = None
         if world == 1 and not ctx["args"].no_rccl_world1 and dist.is_available() and not dist.is_initialized():
+            # (RCCL prints a version banner through C stdio when NCCL_DEBUG is WARN or VERSION -- it is on the GPU boxes --:
+            # file descriptor 1 points at stderr while the group lives, so that stdout carries the JSON line and nothing else)
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
             # A one-rank RCCL group, set up only NOW: a live RCCL communicator costs the timed steps 6-8 % (64-target step
             # 94-96 ms without one in the process, 102 with: profiles/r06/rccl_group_cost.txt -- it holds queues / CUs of
             # its own), and a single-GPU run has no use for one.
@@ -688,6 +694,14 @@ def batch_leg(ctx, tois, N, n_time, steps, warmup, fp32=False, before_timed=None
                     # (gone again before the legs that follow -- shapes, e2e -- are timed)
                     torch.cuda.synchronize()
                     dist.destroy_process_group()
+        if saved_stdout is not None:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:              # noqa: BLE001
+                pass
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         return elapsed, out, jobs, timing
     finally:
         triceratops_amd.set_sampling(prev)
