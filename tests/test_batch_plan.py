@@ -1,4 +1,4 @@
-"""The plan by which the batched likelihood kernel deals rows to waves (batch_plan / batch_at, trx_kernels.hip): rows in
+"""The plan by which the batched likelihood kernel deals rows to waves (batch_plan / batch_at, trx_cells.hpp): rows in
 batches of `rows per wave`, an XCD's batches consecutive in its eighth of the rows, the last positions of every XCD
 tapered to half and a quarter of the rows per wave.  Host code of libtrx.so, checked here without a GPU through
 trx_debug_batch_plan: every row in exactly one batch, for every row count around the plan's thresholds.  (A rule like

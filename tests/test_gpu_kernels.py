@@ -766,7 +766,7 @@ def test_scratch_is_per_stream_and_can_be_released():
                                               (2600, 0.00139, 12), (3000, 0.00139, 20)])
 def test_centre_value_stencil_on_dense_uniform_grids(n_time, exptime, S):
     """On a uniform grid of 1/7 .. 0.3 exposures per cell the one-row variant takes cells far from every
-    limb contact from the centre values of their 13 nearest cells (trx_kernels.hip, kStM).  Against the
+    limb contact from the centre values of their 13 nearest cells (trx_cells.hpp, kStM).  Against the
     same kernel with the stencil off and with every sub-exposure evaluated: flux within 3e-13, exactly 1
     and NaN in the same places; against the oracle within the usual 5e-13; grids outside the band,
     jittered stamps and short curves do not use it."""

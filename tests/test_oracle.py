@@ -249,7 +249,7 @@ def test_eccentric_supersampled_row_end_to_end_in_arbitrary_precision():
 
 
 def test_depth_bound_of_the_bounded_evaluation_holds_for_the_disc_model():
-    """cells_kernel<PRUNE>'s depth screen (csrc/trx_kernels.hip, depth_bound) settles a row from its constants: a body
+    """cells_kernel<PRUNE>'s depth screen (csrc/trx_cells.hpp, depth_bound) settles a row from its constants: a body
     of radius ratio k cannot take more than k^2 Imax / Imean of the flux, Imax the largest intensity of the
     quadratic law on the disc, Imean = 1 - u1/3 - u2/6.  The same expression here against the oracle's
     Mandel-Agol flux over all separations, for limb-darkening pairs inside and outside the physical range."""

@@ -340,7 +340,7 @@ __device__ __forceinline__ double ma_flux(double z, double p, const Limb& L, con
         const double f14 = f1 * f4, f34 = f3 * f4;
         const double area4 = sqrt_fast(f14 * (f2 * f3));
         const double x0 = (f14 > 0.0) ? area4 * rcp_fast(f14) : INFINITY, x1 = area4 * rcp_fast(f34);
-        // (TAB 2: decided by a test of the pointer at run time -- both versions in the binary; see trx_kernels.hip TRX_ATAN_TAB)
+        // (TAB 2: decided by a test of the pointer at run time -- both versions in the binary; see trx_cells.hpp TRX_ATAN_TAB)
         const bool tab = TAB == 1 || (TAB == 2 && atab != nullptr);
         const double kap0 = 2.0 * (tab ? atan_pos_tab(x0, atab) : atan_pos(x0));
         const double kap1 = 2.0 * (tab ? atan_pos_tab(x1, atab) : atan_pos(x1));
@@ -928,7 +928,7 @@ __device__ __forceinline__ CellPlan plan_cell(const RowC& c, double t, double ex
     }
     // (the table's entries as VALUES, read with literal indices before any choice is made: `c ? tt.radius[1] : tt.radius[5]`
     // is a choice between two ADDRESSES to the compiler, and a loop over q an indexed one -- either keeps a kernel's
-    // patched local copy of its argument block (star_args, trx_kernels.hip) from being split into registers, and the
+    // patched local copy of its argument block (star_args, trx_cells.hpp) from being split into registers, and the
     // whole block then lives in scratch memory)
     if (LDS_HEAD) {
         // (the table in LDS: the bisection reads three radii and one count at addresses it computes)

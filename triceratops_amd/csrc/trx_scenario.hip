@@ -14,14 +14,14 @@
 //                        from position N - 1 down: a draw passes at most one of the two masks)
 //   rowc_kernel          } the likelihood of the masked draws: coalesced reads of those dense columns; the row count
 //   (sec_scan_kernel)    } is read from n[branch] on the device and the grids are sized for a guess
-//   cells_kernel         } (trx_kernels.hip)
+//   cells_kernel         } (trx_cells.hpp)
 //   lme_partial_kernel   first pass of the log-mean-exp and of the search for the smallest chi^2 in one pass; the block
 //                        that finishes LAST folds the partials into the record: the evidence, the best draw (first of
 //                        equals, NaN first: numpy's / torch's argmin), its columns, the masked count and the
 //                        limb-darkening flag (scenario_final, trx_device.hpp), written straight into the caller's
 //                        pinned record
 // (with the bounded evaluation cells_kernel is up to five launches: pilot rows, pilot_stats_kernel, depth_screen_kernel,
-// probe pass, the rows left alive -- trx_kernels.hip)
+// probe pass, the rows left alive -- trx_cells.hpp)
 // 5 launches for a planet scenario (7 in round 3), 9 for a binary one (two branches; 10), no memset, no copy, NO
 // sync: a caller can enqueue every lnZ_* call of a calc_probs on a few streams and wait once (trx_scenario_enqueue);
 // trx_scenario_evidence is the same followed by one hipStreamSynchronize.  Every buffer lives in the stream's scratch
