@@ -503,3 +503,19 @@ def test_deferred_table_warns_where_it_is_deferred_not_where_it_is_read():
         warnings.simplefilter("error")
         tg._defer_finish(units, rec, 15)
         assert tg.FPP_degenerate is False
+
+
+def test_gc_freeze_is_opt_in_and_can_be_released():
+    """advisor, round 5: gc.freeze() is for good -- a library must not decide that for a long-lived service.  Off by
+    default; with sharding.freeze_gc the first device pass freezes once and sharding.release() thaws"""
+    import gc
+    assert sharding.freeze_gc is False or os.environ.get("TRX_FREEZE_GC") == "1"
+    before = gc.get_freeze_count()
+    sharding._gc_frozen = True            # (as a device pass with freeze_gc leaves it)
+    gc.freeze()
+    assert gc.get_freeze_count() > before
+    sharding.release()
+    assert gc.get_freeze_count() == 0 and sharding._gc_frozen is False
+    # the stream cap follows the chains' real scratch (7 GB a stream at N = 1e6, 15 GB from 3e6 on)
+    assert 6.5e9 < sharding.stream_scratch_bytes(1_000_000) < 8e9
+    assert 14e9 < sharding.stream_scratch_bytes(3_000_000) < 16e9 and 14e9 < sharding.stream_scratch_bytes(10_000_000) < 16e9
