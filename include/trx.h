@@ -270,8 +270,8 @@ typedef struct {
     /* in-kernel random numbers: with use_philox = 1 every random input left NULL above is generated
      * in the kernel by Philox4x32-10, key = seed, counter = (draw index, slot, sub-draw): slot 0 P,
      * 1 q_companion, 2 R_p, 3 inc, 4 q, 5 ecc (binaries), 6 argp, 7 field-star index (two slots share
-     * one counter block: (2 | 4, 3), (5, 6), (1 | 7, 0)), 8-9 the two gamma variates of the planets'
-     * Beta(0.867, 3.030) eccentricities (Marsaglia-Tsang, one block per attempt, fp32 arithmetic).  A draw's
+     * one counter block: (2 | 4, 3), (5, 6), (1 | 7, 0)).  The planets' Beta(0.867, 3.030) eccentricity is
+     * the inverse CDF of the slot-5 uniform (tabulated, fp32, within 1e-6 of the exact quantile).  A draw's
      * numbers depend on (seed, draw index) only, not on N or on the launch geometry. */
     int use_philox;
     int range_P;                 /* the period is drawn from [P_lo, P_hi] (implied by uP != NULL) */

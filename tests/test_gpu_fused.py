@@ -181,7 +181,7 @@ def test_in_kernel_random_numbers_equal_the_staged_path_on_the_same_numbers(name
 
 def test_in_kernel_random_numbers_statistics():
     """uniformity, independence between slots and draws, the index draw and the Beta(0.867, 3.030)
-    eccentricities (Marsaglia-Tsang gammas) against scipy"""
+    eccentricities (inverse CDF of the slot-5 uniform, csrc/trx_draw.hip: ecc_from_uniform) against scipy"""
     from scipy import stats
     import triceratops_amd
     from triceratops_amd import fused
@@ -214,6 +214,9 @@ def test_in_kernel_random_numbers_statistics():
     assert stats.chisquare(counts).pvalue > 1e-4 and n_field > 100
     ecc = d1[8]
     assert stats.kstest(ecc, stats.beta(0.867, 3.030).cdf).pvalue > 1e-4
+    # ... and draw by draw: the exact quantile of the uniform the draw used, to the table's 1e-6
+    assert np.abs(ecc - stats.beta(0.867, 3.030).ppf(d1[5])).max() < 2e-6
+    assert stats.kstest(d1[5], "uniform").pvalue > 1e-4 and abs(np.corrcoef(d1[5], d1[6])[0, 1]) < 5 / np.sqrt(N)
     assert abs(ecc.mean() - 0.867 / (0.867 + 3.030)) < 5 * stats.beta(0.867, 3.030).std() / np.sqrt(N)
 
 

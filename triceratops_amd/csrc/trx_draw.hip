@@ -120,11 +120,39 @@ __device__ __forceinline__ double random_ecc_beta(unsigned long long seed, long 
 #endif
 constexpr int kDrawChunk = TRX_DRAW_CHUNK;        // draws a workgroup pre-tests before it regroups the candidates
 
+// 1 (round 6): the planets' eccentricity by inverse CDF from the spare half of the (5, 6) counter block; 0: the
+// Marsaglia-Tsang sampler of rounds 3-5 (random_ecc_beta: two more blocks and six fp32 transcendentals per attempt --
+// ~250 of the ~850 instructions a planet scenario's pre-tested draw costs)
+#ifndef TRX_ECC_ICDF
+#define TRX_ECC_ICDF 1
+#endif
+#include "trx_ecc_icdf.inc"
+
 struct Tables {
     double spl[TRX_DRAW_N_SPLINES][TRX_DRAW_SPLINE_DOUBLES];
     double cc_sep[TRX_DRAW_MAX_CC], cc_con[TRX_DRAW_MAX_CC];
     double lut[2][TRX_DRAW_MAX_LUT];
+    float ecc_lo[kEccIcdfN + 1], ecc_hi[kEccIcdfN + 1];      // inverse CDF of Beta(0.867, 3.030): see ecc_from_uniform
 };
+
+// The planets' eccentricity, Beta(0.867, 3.030) (priors.py:146-148), by inverse CDF: F^-1 tabulated in the variables in
+// which it is smooth at its ends -- w = u^(1/a) below the median (e ~ w near 0), v = (1 - u)^(1/b) above it (1 - e ~ v
+// near 1) -- 256 intervals each, linear interpolation, fp32 arithmetic: within 1e-6 of scipy's betaincinv
+// (profiles/r06/make_ecc_icdf.py, which generates the table), a shift of the sampled distribution far below what 1e6
+// draws resolve -- the same standard the fp32 gamma sampler before it was held to.  One uniform, ~20 instructions.
+__device__ __forceinline__ double ecc_from_uniform(const Tables& T, double u)
+{
+    const bool lo = u < 0.5;
+    const float base = lo ? (float)u : (float)(1.0 - u);
+    const float x = __builtin_amdgcn_exp2f((lo ? (1.0f / 0.867f) : (1.0f / 3.030f)) * __builtin_amdgcn_logf(base));   // 0 -> 0
+    const float f = x * (lo ? (float)kEccIcdfN / kEccIcdfWA : (float)kEccIcdfN / kEccIcdfVB);
+    int j = (int)f;
+    j = j < 0 ? 0 : (j > kEccIcdfN - 1 ? kEccIcdfN - 1 : j);
+    const float fr = f - (float)j;
+    const float* tab = lo ? T.ecc_lo : T.ecc_hi;
+    const float e0 = tab[j], e1 = tab[j + 1];
+    return (double)fmaf(fr, e1 - e0, e0);
+}
 
 // piecewise cubic: i = (number of knots <= v) - 1 clamped, ((c0 d + c1) d + c2) d + c3
 __device__ __forceinline__ double spline_eval(const double* s, double v)
@@ -384,7 +412,11 @@ __device__ __forceinline__ bool may_transit(const trx_draw_args& a, const Tables
     if (a.planet) {
         if (a.ecc_in) ecc = (float)a.ecc_in[i];
         else {
+#if TRX_ECC_ICDF
+            ecc = (float)ecc_from_uniform(T, rnd(nullptr, 5u));
+#else
             ecc = (float)random_ecc_beta(a.seed, i);
+#endif
         }
         const float dRp = (float)rnd(a.uRp, 2u);
         float rp;
@@ -490,7 +522,12 @@ __device__ __forceinline__ void draw_one(const trx_draw_args& a, const Tables& T
     if (a.planet) {
         if (a.ecc_in) ecc = a.ecc_in[i];                                // Beta(0.867, 3.030) draws, priors.py:146-148
         else {
+#if TRX_ECC_ICDF
+            dEcc = rnd(nullptr, 5u);
+            ecc = ecc_from_uniform(T, dEcc);
+#else
             ecc = random_ecc_beta(a.seed, i);
+#endif
         }
         dBeta = ecc;
         dRp = rnd(a.uRp, 2u);
@@ -616,6 +653,8 @@ __device__ __forceinline__ void stage_tables(const trx_draw_args& a, Tables& T)
     for (int i = threadIdx.x; i < nspl; i += blockDim.x) dst[i] = a.splines[i];
     for (int i = threadIdx.x; i < a.n_cc; i += blockDim.x) { T.cc_sep[i] = a.cc_seps[i]; T.cc_con[i] = a.cc_cons[i]; }
     for (int i = threadIdx.x; i < a.n_lut; i += blockDim.x) { T.lut[0][i] = a.lut[i]; T.lut[1][i] = a.lut[a.n_lut + i]; }
+    if (a.planet && !a.ecc_in)
+        for (int i = threadIdx.x; i <= kEccIcdfN; i += blockDim.x) { T.ecc_lo[i] = kEccIcdfLo[i]; T.ecc_hi[i] = kEccIcdfHi[i]; }
     __syncthreads();
 }
 
