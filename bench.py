@@ -534,7 +534,7 @@ def run_grid(ctx):
                     "traffic). achieved = executed model evaluations (census of this run) x %d plain operations / "
                     "launch time. plain_algorithm_* prices the launch as if all %d sub-exposures of every cell "
                     "had been evaluated; the kernel reaches those averages (to 1e-13) from 3-9 Gauss nodes, and on "
-                    "this dense uniform grid from ONE evaluation per cell plus a 13-point stencil over the "
+                    "this dense uniform grid from ONE evaluation per cell plus a 17-point stencil over the "
                     "neighbours' centre values wherever no limb contact is near -- so that figure is an "
                     "algorithmic-equivalence number, not a roofline fraction, and `frac` falls when a shortcut "
                     "removes executed work (gauss_nodes_only: the same run with the stencil off)"

@@ -34,7 +34,7 @@ while True:
                     continue
                 dem = subprocess.run(["c++filt", nm], capture_output=True, text=True).stdout.strip()
                 dem = dem.replace("(anonymous namespace)::", "").split("(")[0]
-                print("%-62s vgpr %3s sgpr %3s sgpr-spill %3s vgpr-spill %3s scratch %s" % (
+                print("%-62s vgpr %3s sgpr %3s sgpr-spill %3s vgpr-spill %3s scratch %s lds %s wg %s" % (
                     dem[-62:], g("vgpr_count").group(1), g("sgpr_count").group(1), g("sgpr_spill_count").group(1),
-                    g("vgpr_spill_count").group(1), g("private_segment_fixed_size").group(1)))
+                    g("vgpr_spill_count").group(1), g("private_segment_fixed_size").group(1), g("group_segment_fixed_size").group(1), g("max_flat_workgroup_size").group(1)))
     at = i + len(magic)

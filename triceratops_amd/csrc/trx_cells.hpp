@@ -378,15 +378,24 @@ __host__ __device__ inline void batch_at(const BatchPlan& p, long xcd, long pos,
 // 1e-15.  plan_cell tests it exactly like a Gauss tier (no limb contact, real or complex, inside
 // the disc).  Anything else -- non-uniform stamps, coarse grids, cells near a contact, the first
 // and last kStM cells of a chunk -- takes the Gauss nodes as before.
-constexpr int kStM = 6;
-constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = 15, kHdrXmax = 16, kHdrProbe = 17;
-// Depth screen of the bounded evaluation (behind the 18 doubles above): a model whose flux deficit never exceeds d cannot
+// Half-width of the stencil.  Round 6: 8 (17 centre values) instead of 6: Cauchy's bound falls with the degree faster
+// than the disc must grow with the span -- radius 17.7 -> 13.4 half exposures on config 1's grid (dt = 0.18 exptime), so
+// the stencil reaches 15 cells closer to every contact, where the cells took 4-5 Gauss nodes: evaluations per cell 1.184
+// -> 1.126, config 1 4.54 -> 4.45 ms.  10 would gain another 0.005 evaluations per cell and lose 6 %: the stencil state of
+// a wave is then 64 B more and its 10.2 KB of LDS no longer fit sixteen times into a CU's 160 KB (profiles/r06/ab_stm.txt).
+#ifndef TRX_ST_M
+#define TRX_ST_M 8
+#endif
+constexpr int kStM = TRX_ST_M;
+constexpr int kHdrFlat = 0, kHdrStRadius = 1, kHdrStW = 2, kHdrHmin = kHdrStW + 2 * kStM + 1, kHdrXmax = kHdrHmin + 1,
+              kHdrProbe = kHdrHmin + 2;
+// Depth screen of the bounded evaluation (behind the slots above): a model whose flux deficit never exceeds d cannot
 // fit the data points that lie deeper than that, whatever its timing: chi^2 >= G(d) = sum_j max(0, (1 - d) - f_j)^2 /
 // sigma^2, a function of the light curve alone.  kHdrGrid holds 64 log-spaced depths (1e-5 .. 1), kHdrG the 64 values
 // G(depth); a row's largest possible deficit follows from its constants (depth_bound), and G at the next grid depth
 // above it is a lower bound of the row's chi^2 before a single cell is looked at.  Most prior draws of a planet
 // scenario are too small for a detected signal: this settles them.
-constexpr int kHdrGrid = 18, kHdrG = kHdrGrid + 64, kHdrDoubles = kHdrG + 64;
+constexpr int kHdrGrid = kHdrProbe + 1, kHdrG = kHdrGrid + 64, kHdrDoubles = kHdrG + 64;
 __host__ __device__ inline double depth_grid(int i) { return pow(10.0, -5.0 + 5.0 * (double)i / 63.0); }
 // Bounded evaluation, several launches (see cells_body, PRUNE, and launch_cells): the first kPilotRows rows are
 // evaluated to the end -- they give the launch's running bounds their first values, so that the bound bites from the
@@ -829,8 +838,8 @@ struct CellState {
 };
 // centre-value stencil (LONG only): the chunk's centre fluxes and the launch's weights
 struct StencilState {
-    double fc[64 + 8];                      // [kStM + h]: the centre flux of lane h; [0, kStM): the previous chunk's last owned cells'
-    double stw[16];
+    double fc[64 + ((kStM + 7) & ~7)];                      // [kStM + h]: the centre flux of lane h; [0, kStM): the previous chunk's last owned cells'
+    double stw[(2 * kStM + 1 + 7) & ~7];
 };
 constexpr int kCentreNode = 1023;           // pair table: "the exposure centre itself" in the node field
 
