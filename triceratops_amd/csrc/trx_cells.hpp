@@ -946,9 +946,33 @@ __device__ __forceinline__ int listed_pass_rows(const RowsArgs& a, long rows, in
 // cells, then the verdict, then the rest.  On a real detection most prior draws miss the observed depth
 // or duration by far: 95 % of the rows of TOI-465.01's lnZ_TTP stop at the probe
 // (profiles/prune_potential.py).  Which rows stop depends on timing, the results do not.
-template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE>
-__device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_radius)
+// The argument block read again from the kernel-argument segment at the top of every trip of the row loop: scalar loads
+// where a field is used, instead of ~60 scalar registers held from the kernel's entry on -- which the compiler parks in
+// VGPR lanes (v_writelane / v_readlane: VALU issue, 138 + 103 of them in the one-row stencil instantiation before this,
+// 107 + 90 after).  ARGS: 0 = the block as passed, 1 = cells_kernel's argument, 2 = cells_kernel_star's (the common block
+// patched with the branch's entries, star_args, derived again: a few dozen scalar loads per trip).
+#ifndef TRX_ARGS_RELOAD
+#define TRX_ARGS_RELOAD 1
+#endif
+struct StarKernArgs {              // cells_kernel_star's argument segment
+    RowsArgs common;
+    BranchTab bt;
+    int part;
+};
+template <typename T>
+__device__ __forceinline__ const T* kernel_arguments()
 {
+    typedef const __attribute__((address_space(4))) T* KernArgs;
+    KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));            // (opaque: the loads stay where the fields are used)
+    return (const T*)p;
+}
+
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE, int ARGS = 0>
+__device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st_radius)
+{
+    constexpr int kReload = TRX_ARGS_RELOAD ? ARGS : 0;
+    const RowsArgs& a = a_in;
     static_assert(!PRUNE || (MODE == MODE_LNL && !ST), "bounded evaluation: likelihood mode, no stencil");
     extern __shared__ double lds_all[];
     // (not in the diagnostic instantiations that solve Kepler's equation per pair; not with one row per wave: 2000 irregular
@@ -1084,6 +1108,12 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
     const long v0 = (long)(blockIdx.x & 7) + 8 * ((long)(blockIdx.x >> 3) * W + wave);
     unsigned n_skipped = 0, n_pruned = 0;          // this wave's rows for trx_skipped_rows / trx_pruned_rows
     for (long v = v0; v < 8 * positions; v += (long)gridDim.x * W) {
+        RowsArgs a_again;
+        if (kReload == 2) {
+            const StarKernArgs* k = kernel_arguments<StarKernArgs>();
+            a_again = star_args(k->common, k->bt, k->part);
+        }
+        const RowsArgs& a = (kReload == 1) ? *kernel_arguments<RowsArgs>() : ((kReload == 2) ? a_again : a_in);
         long base;
         int nb;
         if (LONG) {
@@ -1706,7 +1736,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a, const double st_ra
 // (Batches: five waves per SIMD for the bounded instantiation too -- until round 4's last day it was compiled for four and
 // took 97 VGPRs, one more than five waves allow on 512 registers in granules of 8; for five it takes 95, no scratch:
 // the unprobed full evaluations of its third pass gain 8 %, profiles/r04/ab_waves5.txt.)
-template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
+template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false, int ARGS = 0>
 __device__ __forceinline__ void cells_entry(const RowsArgs& a)
 {
     // the counter of the secondary-eclipse scan's list (rowc_kernel<true> -> sec_scan_kernel, both done by now) goes
@@ -1753,13 +1783,13 @@ __device__ __forceinline__ void cells_entry(const RowsArgs& a)
         if (a.use_stencil == 1 && (st_radius > 0.0) != ST) return;
         if (!ST) st_radius = 0.0;
     }
-    cells_body<MODE, STEP, FP32, LONG, ST, PRUNE>(a, st_radius);
+    cells_body<MODE, STEP, FP32, LONG, ST, PRUNE, ARGS>(a, st_radius);
 }
 
 template <int MODE, bool STEP, bool FP32, bool LONG, bool ST, bool PRUNE = false>
 __global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel(RowsArgs a)
 {
-    cells_entry<MODE, STEP, FP32, LONG, ST, PRUNE>(a);
+    cells_entry<MODE, STEP, FP32, LONG, ST, PRUNE, 1>(a);
 }
 
 // chain (bounded evaluation only): branch = blockIdx.y, `part` = the pass (1 pilot, 2 probe pass / the rest, 3 survivors)
@@ -1767,7 +1797,7 @@ template <bool FP32, bool LONG>
 __global__ __launch_bounds__(64 * cells_waves(LONG), LONG ? TRX_CELLS_WAVES_PER_EU : TRX_BATCH_WAVES_PER_EU) void cells_kernel_star(RowsArgs common, BranchTab bt, int part)
 {
     const RowsArgs a = star_args(common, bt, part);
-    cells_entry<MODE_LNL, true, FP32, LONG, false, true>(a);
+    cells_entry<MODE_LNL, true, FP32, LONG, false, true, 2>(a);
 }
 
 // ---- the small kernels between the passes of the bounded evaluation ----------------------------------------
