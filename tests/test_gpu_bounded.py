@@ -66,6 +66,47 @@ def test_every_row_is_exact_or_a_valid_bound(n_time, irregular):
     assert total > 0.2 * n * len(synth.FAMILIES)        # the rule does bite on these families
 
 
+@pytest.mark.parametrize("sigma", [2e-5, 5e-3])
+def test_probe_pass_in_fp32_reports_valid_bounds_at_any_noise_level(sigma):
+    """The probe pass of a split launch (batches of short light curves) evaluates its cells with the fp32 flux model
+    whatever the call's precision (csrc/trx_kernels.hip: TRX_PROBE_FP32); what an abandoned row reports allows for the
+    model's error, which weighs 1 / sigma in chi^2 (fp32_model_slack, csrc/trx_cells.hpp).  At 20 ppm noise -- where 1e-6
+    of flux is a twentieth of a sigma per cell -- and at 5000 ppm: every reported value is the fp64 chi^2/2 or a lower
+    bound of it above min + 90, and the rows that matter are exact."""
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    t = synth.time_grid(200)
+    t_d = _lib.dev(t)
+    curve, _ = _lib.flux_grid(0, 0, t_d, _lib.dev(synth.reference_tp_row()), synth.EXPTIME, 20, False)
+    f_d = _lib.dev(synth.noisy_light_curve(rng, curve[0].cpu().numpy(), sigma))
+    n = 30000
+    cnt = ctypes.c_ulonglong(0)
+    total = 0
+    try:
+        for fam in synth.FAMILIES[:9]:
+            rows_d = _lib.dev(synth.family_rows(rng, fam, n))
+            flags = _lib.FLAG_COMPANION_IS_HOST if fam[2] else 0
+            L.trx_set_debug_bounded_lnl(0)
+            full = _lib.lnl_batch(fam[1], flags, t_d, f_d, sigma, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_set_debug_bounded_lnl(1)
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            got = _lib.lnl_batch(fam[1], flags, t_d, f_d, sigma, rows_d, synth.EXPTIME, 20).cpu().numpy()
+            L.trx_pruned_rows(ctypes.byref(cnt), 1)
+            total += cnt.value
+            fin = np.isfinite(full)
+            hmin = full[fin].min()
+            exact = np.zeros(n, dtype=bool)
+            exact[fin] = np.abs(got[fin] - full[fin]) <= 1e-11 * np.abs(full[fin])
+            bound = fin & ~exact
+            assert int(bound.sum()) == cnt.value, fam[0]
+            assert np.all(got[bound] <= full[bound] * (1 + 1e-9)), fam[0]
+            assert np.all(got[bound] > hmin + 90.0 - 1e-6), fam[0]
+            assert np.all(exact[fin & (full <= hmin + 90.0)]), fam[0]
+    finally:
+        L.trx_set_debug_bounded_lnl(0)
+    assert total > 0
+
+
 def test_evidence_and_best_draw_do_not_depend_on_which_rows_stop():
     """lnZ and the best draw of trx_lnz_scenario with the bounded rows: equal to the full evaluation's to
     1e-13 (the probe cells of a row are summed first), and bit for bit the same from run to run although the

@@ -843,6 +843,19 @@ struct StencilState {
 };
 constexpr int kCentreNode = 1023;           // pair table: "the exposure centre itself" in the node field
 
+// What a verdict of the bounded evaluation has to allow for when the cells done so far carry the fp32 flux model
+// (ma_flux_f32; the probe pass of a split launch takes it whatever the call's precision -- TRX_PROBE_FP32, trx_kernels.hip --
+// because its rows are either abandoned there or evaluated again from the start by the survivors' pass).  With r_j the
+// residuals against the fp32 model and |m_fp32 - m| <= eps in each of the n probed in-window cells,
+//     sum (r_j + d_j)^2 >= sum r_j^2 - 2 eps sum |r_j| >= sum r_j^2 - 2 eps sqrt(n sum r_j^2),
+// and sum r_j^2 / (2 sigma^2) is at most the bound lb itself: chi^2/2 >= lb - eps sqrt(2 n lb) / sigma.  eps = 1e-5, five
+// times the 2e-6 tests/test_gpu_batch.py holds the fp32 model to (measured: 5e-7).  At sigma = 5e-4 and lb = 1e4 that is
+// 11; a row needs lb > best + 90 to be abandoned.
+__device__ __forceinline__ double fp32_model_slack(double lb, int n_probed, double rs2)
+{
+    return 1e-5 * sqrt(2.0 * (double)n_probed * rs2 * fmax(lb, 0.0));
+}
+
 // exclusive prefix sum over the lanes of a non-negative count < 2^BITS, and the wave total
 template <int BITS>
 __device__ __forceinline__ int lane_prefix(int cnt, int& total)
@@ -1631,6 +1644,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                 if (LONG) {
                     double lb = 0.5 * wave_sum(lacc);
                     lb -= fma(1e-9, fabs(lb), 1e-9);                       // summation order
+                    if (FP32) lb -= fp32_model_slack(lb, n_time / pstride + 1, rs2);
                     const double lp0 = hlp[0];
                     long_dead = hmout[0] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp0) < xmax_run - 90.0;
                     if (long_dead) {
@@ -1643,6 +1657,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                     if (lane < nb && !mask_bit(skipmask, lane)) {
                         double lb = 0.5 * (flat_sum + hacc[lane] - hrem[lane]);
                         lb -= fma(1e-9, fabs(lb) + flat_sum, 1e-9);        // cancellation between the three sums
+                        if (FP32) lb -= fp32_model_slack(lb, n_time / pstride + 1, rs2);
                         dead = hmout[lane] == 1.0 && lb > hmin_run && (a.prune_c0 - lb + lp_row) < xmax_run - 90.0;
 #ifdef TRX_PRUNE_NEVER_DEAD
                         dead = false;

@@ -283,6 +283,16 @@ struct CellsPlan {
     int probe_wave_doubles;
 };
 
+// The probe pass of a split launch (batches of short light curves; bounded evaluation) evaluates its ~16 cells per row with
+// the fp32 flux model whatever the call's precision: a row leaves it abandoned -- reporting a lower bound that allows for
+// the model's error, fp32_model_slack in trx_cells.hpp -- or on the survivors' list, and the survivors' pass evaluates
+// those again from the start in the call's own precision.  No result of the call carries fp32 arithmetic; what changes
+// is which rows are abandoned at the margin (a few more survive).
+#ifndef TRX_PROBE_FP32
+#define TRX_PROBE_FP32 1
+#endif
+constexpr bool kProbeFp32 = TRX_PROBE_FP32 != 0;
+
 template <int MODE>
 int plan_cells(RowsArgs& a, bool long_rows, CellsPlan& P)
 {
@@ -512,12 +522,14 @@ int launch_cells(const RowsArgs& a0, hipStream_t st, bool long_rows)
                                a.probe_count);
             if (split) hipLaunchKernelGGL(depth_screen_kernel, dim3(P.grid_screen), dim3(256), 0, st, a);
             ap.part = 2;
+            // (the probe pass of a split launch: its rows end abandoned or on the survivors' list -- fp32 flux model, kProbeFp32)
+            const bool fp32_probe = fp32 || (kProbeFp32 && split);
             if (split && P.probe_B > a.B) {
                 RowsArgs a2 = ap;
                 a2.B = P.probe_B; a2.probe_rows = P.probe_B; a2.wave_doubles = P.probe_wave_doubles;
-                launch_pruned<MODE>(a2, st, long_rows, fp32, g2, P.probe_lds);
+                launch_pruned<MODE>(a2, st, long_rows, fp32_probe, g2, P.probe_lds);
             } else {
-                launch_pruned<MODE>(ap, st, long_rows, fp32, g2, lds);
+                launch_pruned<MODE>(ap, st, long_rows, fp32_probe, g2, lds);
             }
             if (split) {
                 // batches of short light curves: the launch above was the probe pass; the rows it left alive, compacted
@@ -878,7 +890,8 @@ int lnl_lme_chain(const ChainBranch* br, int nbr, const double* time, int n_time
                 ax.B = P.probe_B; ax.probe_rows = P.probe_B; ax.wave_doubles = P.probe_wave_doubles;
                 lds = P.probe_lds;
             }
-            if (P.fp32) hipLaunchKernelGGL((cells_kernel_star<true, false>), dim3(grid, y), dim3(64 * kBatchWaves), lds, st, ax, bt, part);
+            if (P.fp32 || (kProbeFp32 && part == 2 && P.split))
+                        hipLaunchKernelGGL((cells_kernel_star<true, false>), dim3(grid, y), dim3(64 * kBatchWaves), lds, st, ax, bt, part);
             else        hipLaunchKernelGGL((cells_kernel_star<false, false>), dim3(grid, y), dim3(64 * kBatchWaves), lds, st, ax, bt, part);
         }
     };
