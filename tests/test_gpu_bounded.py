@@ -104,7 +104,8 @@ def test_probe_pass_in_fp32_reports_valid_bounds_at_any_noise_level(sigma):
             assert np.all(exact[fin & (full <= hmin + 90.0)]), fam[0]
     finally:
         L.trx_set_debug_bounded_lnl(0)
-    assert total > 0
+    if sigma < 1e-3:
+        assert total > 0.2 * n * 9          # (at 5000 ppm no row lies 90 above the best: nothing to abandon, every row exact)
 
 
 def test_evidence_and_best_draw_do_not_depend_on_which_rows_stop():
