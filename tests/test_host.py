@@ -278,3 +278,39 @@ def test_field_star_limb_darkening_lookup_equals_the_dense_comparison():
         for i in np.flatnonzero(~ok)[:20]:
             with pytest.raises(ValueError):
                 tab.field_stars(Teffs[i:i + 1], loggs[i:i + 1], Zs[i:i + 1])
+
+
+def test_eccentricity_quantile_table_of_the_draw_kernel():
+    """csrc/trx_ecc_icdf.inc (generated by profiles/r06/make_ecc_icdf.py) is what the draw kernel samples the planets'
+    Beta(0.867, 3.030) eccentricities from (priors.py:146-148; ecc_from_uniform in csrc/trx_draw.hip).  The committed
+    table, read back from the source file and interpolated the way the kernel does it -- fp32, linear in u^(1/a) below
+    the median and in (1 - u)^(1/b) above --, is scipy's quantile to 2e-6 everywhere, monotone, and ends at 0 and 1."""
+    import re
+    from scipy import special
+    src = open(os.path.join(os.path.dirname(__file__), "..", "triceratops_amd", "csrc", "trx_ecc_icdf.inc")).read()
+    M = int(re.search(r"kEccIcdfN = (\d+)", src).group(1))
+    wA, vB = (np.float32(re.search(r"%s = ([0-9.e+-]+)f" % k, src).group(1)) for k in ("kEccIcdfWA", "kEccIcdfVB"))
+    tabs = {}
+    for name in ("kEccIcdfLo", "kEccIcdfHi"):
+        body = re.search(r"%s\[\d+\] = \{(.*?)\};" % name, src, re.S).group(1)
+        tabs[name] = np.array([float(x.rstrip("f")) for x in body.replace("\n", " ").split(",") if x.strip()], dtype=np.float32)
+        assert tabs[name].size == M + 1
+    lo, hi = tabs["kEccIcdfLo"], tabs["kEccIcdfHi"]
+    assert lo[0] == 0.0 and hi[0] == 1.0 and abs(float(lo[-1]) - float(hi[-1])) < 1e-7
+    assert np.all(np.diff(lo) > 0) and np.all(np.diff(hi) < 0)
+    a, b = 0.867, 3.030
+    rng = np.random.default_rng(3)
+    u = np.concatenate([rng.random(400000), [0.0, 0.5, 1 - 2.0 ** -53, 1e-12, 0.4999999, 0.5000001]])
+    is_lo = u < 0.5
+    x = np.where(is_lo, u, 1.0 - u).astype(np.float32)
+    pw = np.where(is_lo, np.float32(1 / a), np.float32(1 / b))
+    with np.errstate(divide="ignore"):
+        x = np.exp2(pw * np.log2(x)).astype(np.float32)                  # 0 -> 0, as v_log_f32 / v_exp_f32 give
+    f = x * np.where(is_lo, np.float32(M) / wA, np.float32(M) / vB)
+    j = np.clip(f.astype(np.int32), 0, M - 1)
+    fr = f - j
+    e0 = np.where(is_lo, lo[j], hi[j])
+    e1 = np.where(is_lo, lo[j + 1], hi[j + 1])
+    ecc = fr * (e1 - e0) + e0
+    assert np.abs(ecc - special.betaincinv(a, b, u)).max() < 2e-6
+    assert ecc.min() >= 0.0 and ecc.max() <= 1.0
