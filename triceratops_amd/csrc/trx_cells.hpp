@@ -256,10 +256,6 @@ __host__ __device__ constexpr int cells_waves(bool long_rows) { return long_rows
 #ifndef TRX_LAZY_TIERS
 #define TRX_LAZY_TIERS 1
 #endif
-// 1 (round 6): a contact cell's sub-exposures that certainly lie off the disc stay out of the pair table (offdisc_nodes)
-#ifndef TRX_SKIP_OFFDISC
-#define TRX_SKIP_OFFDISC 1
-#endif
 #ifndef TRX_CELLS_PAIRS
 #define TRX_CELLS_PAIRS 640
 #endif
@@ -1418,13 +1414,6 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                 }
                 int tier = pl.tier;
                 int nodes = (valid && owned) ? pl.n : 0;
-                // contact cells: which of the S sub-exposures are off the disc for certain (flux exactly 1: no pair).  From
-                // the cell's own plan alone, carried or not: the same mask wherever the cell is evaluated.
-                unsigned skip = 0u;
-                if (TRX_SKIP_OFFDISC && STEP && sweep == 1 && a.use_tiers && nodes > 0 && pl.anchored && tier < 0) {
-                    const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];
-                    skip = offdisc_nodes(c, pl.sE, pl.cE, a.exptime, nodes, a.rS);
-                }
                 // Centre-value stencil (LONG, dense uniform grid): a cell whose kStM neighbours on either
                 // side sit next to it in this chunk, all of them planned cells of this sweep, takes its
                 // exposure average from their centre values -- ONE pair, the centre, instead of its
@@ -1507,7 +1496,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                 if (!direct) {
                     cs.sE[lane] = pl.sE; cs.cE[lane] = pl.cE;
                     cs.t[lane] = t;
-                    cs.facc[lane] = (double)__popc(skip);          // (the sub-exposures off the disc: 1 each, exactly)
+                    cs.facc[lane] = 0.0;
                     cs.meta[lane] = (unsigned)rr | ((unsigned)(tier + 1) << 8) | (pl.anchored ? 0x10000u : 0u) |
                                     (valid ? 0x20000u : 0u) | ((unsigned)pl.n << 18);
                     if (kCarry) cs.rel[lane] = (unsigned short)rel;
@@ -1521,38 +1510,16 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                 const int ncells = __popcll(__ballot(nodes > 0 || (ST && centre)));
                 int per = ncells > 0 ? kCellsPairs / ncells - (ST ? 1 : 0) : kCellsPairs;
                 per = per > 1000 ? 1000 : (per < 1 ? 1 : per);
-                if (TRX_SKIP_OFFDISC && sweep == 1 && per < 32 && __any(skip != 0u)) {
-                    // (what is left of the chunk's contact cells may fit one pass; S <= 32 here)
-                    int left;
-                    lane_prefix<6>(nodes - __popc(skip), left);
-                    if (left <= kCellsPairs) per = 32;
-                }
                 for (int s0 = 0; !direct && __any(s0 < nodes || (ST && s0 == 0 && centre)); s0 += per) {
                     int cnt = nodes - s0;
                     cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
-                    // (contact cells: the nodes of this pass that are left after the off-disc ones; S <= 32 where skip != 0)
-                    unsigned live = 0u;
-                    if (TRX_SKIP_OFFDISC && sweep == 1 && skip != 0u) {
-                        live = (~skip >> s0) & ((cnt >= 32) ? ~0u : ((1u << cnt) - 1u));
-                        cnt = __popc(live);
-                    }
                     TRX_CENSUS_ADD(kCenPass, 1);
                     const int extra = (ST && s0 == 0 && centre) ? 1 : 0;      // the centre rides in the first pass
                     // (first sweep: at most 9 nodes + the centre per cell -- four ballots; contact cells: up to S)
                     int total;
                     const int off = (sweep == 0 && a.use_tiers) ? lane_prefix<4>(cnt + extra, total)
                                                                 : lane_prefix<10>(cnt + extra, total);
-                    if (TRX_SKIP_OFFDISC && sweep == 1 && __any(skip != 0u)) {
-                        if (skip != 0u) {
-                            int i = 0;
-                            for (unsigned m = live; m != 0u; m &= m - 1u)
-                                pdesc[off + i++] = (unsigned short)(lane | ((__ffs(m) - 1) << 6));
-                        } else {
-                            for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
-                        }
-                    } else {
-                        for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
-                    }
+                    for (int si = 0; si < cnt; ++si) pdesc[off + si] = (unsigned short)(lane | (si << 6));
                     if (extra) pdesc[off + cnt] = (unsigned short)(lane | (kCentreNode << 6));
                     wave_sync();
                     // (carried cells: with more of the list to come and every cell's pairs in this one pass, the cells
@@ -1624,7 +1591,7 @@ __device__ __forceinline__ void cells_body(const RowsArgs& a_in, const double st
                 if (MODE == MODE_GRID && a.debug_nodes) {
                     // bench / test knob: the model evaluations every cell cost, its own and those a
                     // neighbouring chunk spent on its centre value (the cells were zeroed by pass 1)
-                    const int spent = nodes - __popc(skip) + ((ST && centre) ? 1 : 0);
+                    const int spent = nodes + ((ST && centre) ? 1 : 0);
                     if (spent > 0 && lane < ldone) atomicAdd(&a.out[(size_t)base * n_time + cell], (double)spent);
                 } else if (valid && owned && lane < ldone) {
                     const RowC& c = (LONG && !TRX_LONG_ROWS_IN_LDS) ? cu : rows[rr];

@@ -1043,55 +1043,6 @@ __device__ __forceinline__ CellPlan plan_all_subexposures(const RowC& c, double 
     return p;
 }
 
-// The sub-exposures of a contact cell that certainly lie off the disc (bit s: sub-exposure s of S, s = 0 .. S - 1): their
-// flux is exactly 1 and cells_kernel leaves them out of the pair table -- at a first or fourth contact that is half of
-// the cell's S evaluations on average, and a contact cell's sub-exposures are two thirds of all the evaluations of a row
-// on BASELINE config 1's grid.
-//
-// f(t) = z^2(t) = X^2 + y^2 (y = Y cos i) about the exposure centre, by Taylor's theorem with the Lagrange remainder:
-//     f(d) = f + f1 d + f2 d^2 / 2 + f3(xi) d^3 / 6,     f1 = 2 (X X' + y y'),     f2 = 2 (X'^2 + y'^2 - kappa f),
-//     f3 = -4 kappa f1 - 2 kappa' f
-// with X'' = -kappa X, y'' = -kappa y (Kepler: kappa = n^2 rho^3, rho = a / r = 1 / (1 - e cos E)) and kappa' = -3 n^3 e
-// sin E rho^5.  Over |d| <= tau = half an exposure with u = n rho^2 tau <= 0.15: rho^-2 changes by at most 2 e u, so
-// kappa grows by at most 1.71 and kappa n rho^2 by 2.44; with |f1| <= A1 = |f1| + |f2| tau (+ the cubic term, solved
-// for) and f <= fm = f + |f1| tau + |f2| tau^2 / 2 the supremum of |f3| over the exposure is below
-// kappa (8.3 A1 + 17.7 e n rho^2 fm).  A sub-exposure counts as off the disc when the quadratic exceeds (1 + k)^2 by
-// TWICE the remainder's bound (and 1e-9 for the arithmetic).  Misjudging at the margin's scale costs nothing either way:
-// a sub-exposure inside the margin is evaluated as before, and one that is inside the disc by less than 1e-11 would have
-// contributed a deficit below 1e-17.  No statement (0) when the exposure turns through more than 0.15 rad, when the
-// body may pass behind the star within it, for S > 32, for NaN anywhere.
-__device__ __forceinline__ unsigned offdisc_nodes(const RowC& c, double sE, double cE, double exptime, int S, double rS)
-{
-    if (S > 32) return 0u;
-    const double rho = rcp_fast(fma(-c.e, cE, 1.0));
-    const double ce = cE - c.e;
-    const double X = fma(c.ax, ce, c.bx * sE), Y = fma(c.ay, ce, c.by * sE);
-    const double yc = Y * c.cosi;
-    const double nr = c.nmot * rho;
-    const double Xp = fma(c.bx, cE, -c.ax * sE) * nr, Yp = fma(c.by, cE, -c.ay * sE) * nr;
-    const double ycp = Yp * c.cosi;
-    const double z2 = fma(X, X, yc * yc);
-    const double kap = (nr * nr) * rho;
-    const double f1 = 2.0 * fma(X, Xp, yc * ycp);
-    const double f2h = fma(Xp, Xp, ycp * ycp) - kap * z2;               // f2 / 2
-    const double tau = 0.5 * fabs(exptime);
-    const double om = fabs(nr) * rho;
-    if (!(om * tau <= 0.15) || !(Y > fabs(Yp) * tau)) return 0u;
-    const double A1 = fma(2.0 * fabs(f2h), tau, fabs(f1));
-    const double fm = fma(tau, fma(fabs(f2h), tau, fabs(f1)), z2);
-    const double F3 = kap * fma(3.0, A1, 6.0 * c.e * om * fm);         // 2 x sup |f3| / 6
-    const double opp = 1.0 + c.k;
-    const double g0 = z2 - fma(opp, opp, 1e-9);
-    unsigned m = 0u;
-#pragma unroll 1
-    for (int s = 0; s < S; ++s) {
-        const double d = exptime * fma((double)(s + 1) - 0.5, rS, -0.5);
-        const double q = fma(d, fma(d, f2h, f1), g0) - fabs(d * d * d) * F3;
-        m |= (q > 0.0) ? (1u << s) : 0u;
-    }
-    return m;
-}
-
 // Node s (1-based) of the plan: advances the orbit; returns z^2 (NaN propagates) and Y (< 0 on
 // the far side of the orbit).  frac = node offset / exptime.
 __device__ __forceinline__ double node_z2(const RowC& c, CellPlan& p, double t, double exptime,
